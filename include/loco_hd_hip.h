@@ -1,0 +1,144 @@
+/*
+ * loco_hd_hip.h -- C ABI of the MI355X-native LoCoHD scoring core (libloco_hd_hip.so).
+ *
+ * This is the drop-in boundary that replaces the reference's PyO3 extension module
+ * `loco_hd.loco_hd` (/root/reference/src/lib.rs:9-17, Cargo.toml:6-9 `crate-type = ["cdylib"]`) for
+ * the scoring path only.  Every entry point names the reference interface it replaces.  Signatures
+ * use plain pointers and sizes only (no torch / pyo3 / C++ types); all functions return 0 on success
+ * and a non-zero lchd_status otherwise, with the message available from lchd_last_error() on the
+ * calling thread.  Status LCHD_EVALUE corresponds to the reference's PyValueError, LCHD_EPANIC to a
+ * Rust panic (pyo3 PanicException) in the reference, LCHD_EDEVICE to a HIP failure / missing GPU and
+ * LCHD_EUNSUPPORTED to an input the reference accepts but this build cannot run yet.  There is NO CPU
+ * fallback: every scoring entry point launches HIP kernels on the context's device.
+ *
+ * Strings never cross the boundary: a category is the index the reference's HashMap would give it
+ * (src/locohd.rs:312-316; -1 = "not in the map", src/locohd/pmf.rs:38-42), a tag is an interned
+ * integer (equal strings <=> equal integers; only equality is ever used,
+ * src/locohd/tag_pairing_rule.rs:49-75).  The caller owns every buffer; the library never frees or
+ * retains caller memory beyond the call (mirrors the reference's copy-in / copy-out ownership).
+ */
+#ifndef LOCO_HD_HIP_H
+#define LOCO_HD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    LCHD_OK = 0,
+    LCHD_EVALUE = 1,       /* reference: ValueError */
+    LCHD_EPANIC = 2,       /* reference: Rust panic */
+    LCHD_EDEVICE = 3,      /* HIP error / no device */
+    LCHD_EUNSUPPORTED = 4  /* valid for the reference, not (yet) for this build */
+} lchd_status;
+
+/* weight_function.rs:22-93 function_name */
+typedef enum { LCHD_WF_HYPER_EXP = 0, LCHD_WF_DAGUM = 1, LCHD_WF_UNIFORM = 2, LCHD_WF_KUMARASWAMY = 3 } lchd_wf_kind;
+/* pmf/statistical_distances.rs:80-85 distance_name */
+typedef enum { LCHD_SD_HELLINGER = 0, LCHD_SD_KOLMOGOROV_SMIRNOV = 1, LCHD_SD_KULLBACK_LEIBLER = 2, LCHD_SD_RENYI = 3 } lchd_sd_kind;
+
+/* One WeightFunction (weight_function.rs:6-17): kind + parameter vector. */
+typedef struct {
+    int32_t kind;         /* lchd_wf_kind */
+    int32_t n_params;
+    const double *params; /* [n_params] */
+} lchd_weight_function;
+
+/* The fields of `struct LoCoHD` (src/locohd.rs:42-55) that the scoring path reads. */
+typedef struct {
+    int32_t n_categories;            /* categories.len() (:312-316); this build: 1..255 */
+    const double *category_weights;  /* [n_categories], all > 0 (:319-346) */
+    int32_t n_weight_functions;      /* 1 for WeightFunctionOptions::Single, dict size for ::Multiple (:27-32) */
+    const lchd_weight_function *weight_functions;
+    int32_t sd_kind;                 /* lchd_sd_kind (:365-370) */
+    int32_t sd_n_params;
+    double sd_params[2];
+    int32_t tag_mode;                /* 0 = WithoutList{accept_same}, 1 = WithList{...} (tag_pairing_rule.rs:5-21) */
+    int32_t tag_accept_same;
+    int32_t tag_accepted_pairs;
+    int32_t tag_ordered;
+    const int32_t *tag_pairs;        /* [n_tag_pairs][2] interned (anchor tag, neighbour tag) */
+    int64_t n_tag_pairs;
+} lchd_config;
+
+typedef struct lchd_ctx lchd_ctx; /* opaque: device, stream, device workspace; replaces the rayon pool (:53,373-383) */
+
+const char *lchd_last_error(void);
+const char *lchd_version(void);
+
+/* ---- host-side leaves (no GPU work; same arithmetic headers as the kernels) ------------------- */
+/* WeightFunction::build validation, weight_function.rs:22-93 */
+int lchd_wf_validate(int32_t kind, const double *params, int32_t n_params);
+/* WeightFunction::integral_vec / integral_point, weight_function.rs:95-116: out[i] = CDF(x[i]); x<0 -> LCHD_EVALUE */
+int lchd_wf_cdf(int32_t kind, const double *params, int32_t n_params, const double *x, int64_t n, double *out);
+/* StatisticalDistance::build validation, statistical_distances.rs:96-121 */
+int lchd_sd_validate(int32_t kind, int32_t n_params);
+/* StatisticalDistance::run, statistical_distances.rs:123-142 */
+int lchd_sd_run(int32_t kind, const double *params, const double *p1, const double *p2, int32_t n, double *out);
+/* LoCoHD::build validation, src/locohd.rs:305-346 (n_given = len of the list passed, n_map = len after de-dup) */
+int lchd_config_validate(int64_t n_categories_given, int64_t n_categories_map, const double *weights, int64_t n_weights);
+
+/* ---- context ----------------------------------------------------------------------------------- */
+/* device < 0 => current HIP device.  Fails with LCHD_EDEVICE when no GPU is usable. */
+int lchd_ctx_create(int32_t device, lchd_ctx **out);
+void lchd_ctx_destroy(lchd_ctx *ctx);
+/* Launch everything on this hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = default stream. */
+int lchd_ctx_set_stream(lchd_ctx *ctx, void *hip_stream);
+/* Upload a LoCoHD configuration; later *_dev calls use it. (The host-pointer drivers below do this themselves.) */
+int lchd_ctx_set_config(lchd_ctx *ctx, const lchd_config *cfg);
+
+/* ---- the four reference drivers, host pointers in / host pointers out -------------------------- */
+/* LoCoHD::from_anchors, src/locohd.rs:392-406 (+ stat_dist_integral :61-226).  wf_index selects
+ * cfg->weight_functions[wf_index] (the shim resolves the key, :230-283).  len_* are passed separately so
+ * the "Lists seq and dists must have equal lengths!" check (:70-73) lives behind the boundary. */
+int lchd_from_anchors(lchd_ctx *ctx, const lchd_config *cfg, const int32_t *seq_a, int64_t len_seq_a, const double *dists_a,
+                      int64_t len_dists_a, const int32_t *seq_b, int64_t len_seq_b, const double *dists_b,
+                      int64_t len_dists_b, int32_t wf_index, double *out);
+
+/* LoCoHD::from_dmxs, src/locohd.rs:410-458.  dmx_x is row-major [rows_x][cols_x]; wf_index NULL or [rows]. */
+int lchd_from_dmxs(lchd_ctx *ctx, const lchd_config *cfg, const int32_t *seq_a, int64_t len_seq_a, const int32_t *seq_b,
+                   int64_t len_seq_b, const double *dmx_a, int64_t rows_a, int64_t cols_a, const double *dmx_b,
+                   int64_t rows_b, int64_t cols_b, const int32_t *wf_index, double *out);
+
+/* LoCoHD::from_coords, src/locohd.rs:463-476.  xyz_x is [n_x][3]; out is [n_a]. */
+int lchd_from_coords(lchd_ctx *ctx, const lchd_config *cfg, const int32_t *seq_a, int64_t len_seq_a, const int32_t *seq_b,
+                     int64_t len_seq_b, const double *xyz_a, int64_t n_a, const double *xyz_b, int64_t n_b,
+                     const int32_t *wf_index, double *out);
+
+/* LoCoHD::from_primitives, src/locohd.rs:479-567.  Primitive atoms as SoA (xyz [n][3], category, tag);
+ * anchors is [n_pairs][2] = (index into a, index into b); out[i] belongs to anchors[i] (order-preserving,
+ * like the reference's indexed rayon collect). */
+int lchd_from_primitives(lchd_ctx *ctx, const lchd_config *cfg, const double *xyz_a, const int32_t *cat_a,
+                         const int32_t *tag_a, int64_t n_a, const double *xyz_b, const int32_t *cat_b,
+                         const int32_t *tag_b, int64_t n_b, const int64_t *anchors, const int32_t *wf_index,
+                         int64_t n_pairs, double threshold_distance, double *out);
+
+/* ---- device-resident path (what bench.py and multi-structure callers use) --------------------- */
+/* A primitive-atom structure resident in HBM as SoA (replaces the per-call Vec<PrimitiveAtom> clone at the
+ * PyO3 boundary, src/locohd/primitive_atom.rs:4-16).  xyz/cat/tag are HOST pointers here. */
+typedef struct lchd_cloud lchd_cloud;
+int lchd_cloud_create(lchd_ctx *ctx, const double *xyz, const int32_t *cat, const int32_t *tag, int64_t n, lchd_cloud **out);
+/* Replace the coordinates of an existing cloud (MD frames: same atoms, new positions). Host pointer [n][3]. */
+int lchd_cloud_set_coords(lchd_ctx *ctx, lchd_cloud *cloud, const double *xyz);
+void lchd_cloud_destroy(lchd_ctx *ctx, lchd_cloud *cloud);
+
+/* from_primitives with everything already on the device: d_anchors is a DEVICE pointer [n_pairs][2] int64,
+ * d_wf_index a DEVICE pointer [n_pairs] int32 or NULL, d_out a DEVICE pointer [n_pairs] double.  Work is
+ * enqueued on the context's stream; the call returns after the (tiny) status word has been read back, i.e.
+ * d_out is complete on return.  Uses the configuration set by lchd_ctx_set_config. */
+int lchd_from_primitives_dev(lchd_ctx *ctx, lchd_cloud *a, lchd_cloud *b, const int64_t *d_anchors,
+                             const int32_t *d_wf_index, int64_t n_pairs, double threshold_distance, double *d_out);
+
+/* Per-kernel timing of the most recent *_dev / driver call, measured with hipEvents on the context's stream.
+ * names: "cells", "anchors", "env", "sweep"; returns milliseconds, <0 if unknown name / timing disabled. */
+int lchd_ctx_enable_timing(lchd_ctx *ctx, int32_t on);
+double lchd_ctx_last_ms(lchd_ctx *ctx, const char *phase);
+/* Environment statistics of the most recent call: sum over anchor pairs of (n_A + n_B) (points incl. anchors). */
+int64_t lchd_ctx_last_env_points(lchd_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOCO_HD_HIP_H */

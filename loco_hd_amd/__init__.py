@@ -1,0 +1,11 @@
+"""loco_hd_amd -- MI355X-native drop-in for the scoring path of fazekaszs/loco_hd.
+
+    from loco_hd_amd import LoCoHD, PrimitiveAtom, WeightFunction, TagPairingRule, StatisticalDistance
+
+mirrors `from loco_hd import ...` (/root/reference/loco_hd/__init__.py:1); the Rust/PyO3 core is replaced
+by libloco_hd_hip.so (C ABI: include/loco_hd_hip.h) which launches hand-written gfx950 kernels.
+"""
+from ._native import DeviceError, PanicException
+from .api import LoCoHD, PrimitiveAtom, StatisticalDistance, TagPairingRule, WeightFunction
+
+__all__ = ["LoCoHD", "PrimitiveAtom", "StatisticalDistance", "TagPairingRule", "WeightFunction", "PanicException", "DeviceError"]

@@ -1,0 +1,793 @@
+// lchd_capi.hip -- host side of the C ABI declared in include/loco_hd_hip.h.
+//
+// Owns: validation (the reference's PyValueError sites), packing of caller buffers into SoA device
+// arrays, the device workspace, kernel sequencing on one HIP stream, the status read-back and its
+// translation into the reference's error classes.  No scoring arithmetic happens on the host: every
+// from_* entry point launches the gfx950 kernels of lchd_kernels.hip and fails with LCHD_EDEVICE when
+// no GPU is usable.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/loco_hd_hip.h"
+#include "lchd_device.h"
+#include "lchd_math.h"
+
+using namespace lchd;
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+extern "C" const char* lchd_last_error(void) { return g_err; }
+extern "C" const char* lchd_version(void) { return "loco_hd_hip 0.1 (gfx950)"; }
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return fail(LCHD_EDEVICE, "HIP error %d (%s) at %s:%d: %s", (int)e_,      \
+                                          hipGetErrorName(e_), __FILE__, __LINE__, #expr);              \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// host-side leaves
+// ------------------------------------------------------------------------------------------------
+static const char* wf_name(int kind) {
+    static const char* names[4] = {"hyper_exp", "dagum", "uniform", "kumaraswamy"};
+    return (kind >= 0 && kind < 4) ? names[kind] : "?";
+}
+
+extern "C" int lchd_wf_validate(int32_t kind, const double* p, int32_t np) {  // weight_function.rs:22-93
+    const char* nm = wf_name(kind);
+    auto exactly = [&](int n) { return np == n ? 0 : fail(LCHD_EVALUE, "For function \"%s\" there must be exactly %d parameters!", nm, n); };
+    switch (kind) {
+        case LCHD_WF_HYPER_EXP:
+            if (np % 2 != 0) return fail(LCHD_EVALUE, "For function \"%s\" there must be an even number of parameters!", nm);
+            for (int i = 0; i < np; ++i)
+                if (p[i] <= 0.0) return fail(LCHD_EVALUE, "For function \"%s\" all parameters must be positive!", nm);
+            return LCHD_OK;
+        case LCHD_WF_DAGUM:
+            if (int rc = exactly(3)) return rc;
+            if (p[0] < 0.0 || p[1] < 0.0 || p[2] < 0.0) return fail(LCHD_EVALUE, "For function \"%s\" all parameters must be positive!", nm);
+            return LCHD_OK;
+        case LCHD_WF_UNIFORM:
+            if (int rc = exactly(2)) return rc;
+            if (p[0] < 0.0) return fail(LCHD_EVALUE, "For function \"%s\" the first parameter must be non-negative!", nm);
+            if (p[1] <= 0.0) return fail(LCHD_EVALUE, "For function \"%s\" the second parameter must be positive!", nm);
+            if (p[0] >= p[1]) return fail(LCHD_EVALUE, "For function \"%s\" the first parameter must be smaller than the second!", nm);
+            return LCHD_OK;
+        case LCHD_WF_KUMARASWAMY:
+            if (int rc = exactly(4)) return rc;
+            if (p[0] < 0.0) return fail(LCHD_EVALUE, "For function \"%s\" the first parameter must be non-negative!", nm);
+            if (p[1] <= 0.0 || p[2] <= 0.0 || p[3] <= 0.0)
+                return fail(LCHD_EVALUE, "For function \"%s\" after the first parameter all parameters must be positive!", nm);
+            if (p[0] >= p[1]) return fail(LCHD_EVALUE, "For function \"%s\" the first parameter must be smaller than the second!", nm);
+            return LCHD_OK;
+        default: return fail(LCHD_EVALUE, "No function implemented with this name!");
+    }
+}
+
+extern "C" int lchd_wf_cdf(int32_t kind, const double* p, int32_t np, const double* x, int64_t n, double* out) {
+    for (int64_t i = 0; i < n; ++i) {  // weight_function.rs:95-116
+        if (x[i] < 0.0) return fail(LCHD_EVALUE, "Invalid input value: %g. All values must be non-negative!", x[i]);
+        out[i] = cdf_eval(kind, p, np, x[i]);
+    }
+    return LCHD_OK;
+}
+
+extern "C" int lchd_sd_validate(int32_t kind, int32_t np) {  // statistical_distances.rs:96-121
+    static const int want[4] = {1, 0, 1, 2};
+    static const char* names[4] = {"Hellinger", "Kolmogorov-Smirnov", "Kullback-Leibler", "Renyi"};
+    if (kind < 0 || kind > 3) return fail(LCHD_EVALUE, "Invalid statistical distance name!");
+    if (np != want[kind]) return fail(LCHD_EVALUE, "Invalid number of parameters for %s: %d", names[kind], np);
+    return LCHD_OK;
+}
+
+extern "C" int lchd_sd_run(int32_t kind, const double* prm, const double* p1, const double* p2, int32_t n, double* out) {
+    if (kind < 0 || kind > 3) return fail(LCHD_EVALUE, "Invalid statistical distance name!");
+    if (n <= 0 && kind == LCHD_SD_KOLMOGOROV_SMIRNOV) return fail(LCHD_EPANIC, "called `Option::unwrap()` on a `None` value");
+    const double a = (kind == LCHD_SD_KOLMOGOROV_SMIRNOV) ? 0.0 : prm[0], b = (kind == LCHD_SD_RENYI) ? prm[1] : 0.0;
+    // Hellinger with a runtime exponent: the reference calls powf even for e == 2 (statistical_distances.rs:5-9)
+    if (kind == LCHD_SD_HELLINGER)
+        *out = sd_hellinger<0>([&](int c) { return p1[c]; }, [&](int c) { return p2[c]; }, n, a);
+    else
+        *out = sd_eval<0>(kind, a, b, [&](int c) { return p1[c]; }, [&](int c) { return p2[c]; }, n);
+    return LCHD_OK;
+}
+
+extern "C" int lchd_config_validate(int64_t n_given, int64_t n_map, const double* w, int64_t nw) {  // src/locohd.rs:305-346
+    if (n_given == 0) return fail(LCHD_EVALUE, "The number of possible categories (primitive types) cannot be zero!");
+    if (nw != n_map)
+        return fail(LCHD_EVALUE, "LoCoHD parameters 'categories' and 'category_weights' must have the same lengths! "
+                                 "Instead, they have lengths of %lld vs. %lld!", (long long)n_map, (long long)nw);
+    long long bad = 0;
+    for (int64_t i = 0; i < nw; ++i) bad += (w[i] <= 0.0);
+    if (bad) return fail(LCHD_EVALUE, "LoCoHD parameter 'category_weights' must only contain positive values! "
+                                      "Instead, it contains %lld non-positive values!", bad);
+    return LCHD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+struct lchd_cloud {
+    double *x = nullptr, *y = nullptr, *z = nullptr;
+    uint8_t* cat = nullptr;
+    int32_t* tag = nullptr;
+    int64_t n = 0;
+    double bbmin[3] = {0, 0, 0}, bbmax[3] = {0, 0, 0};
+    CloudView view() const { return CloudView{x, y, z, cat, tag, (int32_t)n}; }
+};
+
+enum { PH_CELLS = 0, PH_ANCHORS = 1, PH_ENV = 2, PH_SWEEP = 3, PH_N = 4 };
+
+struct lchd_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // configuration
+    bool cfg_set = false;
+    DevConfig h_cfg{};
+    DevConfig* d_cfg = nullptr;
+    char* d_blob = nullptr;
+    size_t blob_cap = 0;
+    // workspace arena
+    char* ws = nullptr;
+    size_t ws_cap = 0;
+    DeviceStatus* d_status = nullptr;
+    DeviceStatus* h_status = nullptr;  // pinned
+    unsigned long long* d_points = nullptr;
+    int cap_hint = 512;
+    // timing
+    bool timing = false;
+    hipEvent_t ev[PH_N + 1] = {};
+    float ms[PH_N] = {-1, -1, -1, -1};
+    // most recent sweep (for lchd_ctx_last_env_points)
+    SweepArgs last{};
+    bool last_valid = false;
+};
+
+struct Arena {
+    char* base;
+    size_t off = 0, cap;
+    bool dry;
+    Arena(char* b, size_t c, bool d) : base(b), cap(c), dry(d) {}
+    template <class T>
+    T* take(size_t n) {
+        off = (off + 255) & ~size_t(255);
+        T* p = dry ? nullptr : reinterpret_cast<T*>(base + off);
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+static int ensure_ws(lchd_ctx* ctx, size_t need) {
+    if (need <= ctx->ws_cap) return LCHD_OK;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->ws) HIP_TRY(hipFree(ctx->ws));
+    ctx->ws = nullptr;
+    ctx->ws_cap = 0;
+    ctx->last_valid = false;
+    const size_t want = need + need / 8 + (1 << 20);
+    HIP_TRY(hipMalloc(&ctx->ws, want));
+    ctx->ws_cap = want;
+    return LCHD_OK;
+}
+
+extern "C" int lchd_ctx_create(int32_t device, lchd_ctx** out) {
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0)
+        return fail(LCHD_EDEVICE, "no usable HIP device (hipGetDeviceCount -> %d, %d devices): the LoCoHD scoring path has no "
+                                  "CPU fallback", (int)e, n_dev);
+    if (device >= 0) HIP_TRY(hipSetDevice(device));
+    lchd_ctx* c = new lchd_ctx();
+    HIP_TRY(hipGetDevice(&c->device));
+    HIP_TRY(hipMalloc(&c->d_cfg, sizeof(DevConfig)));
+    HIP_TRY(hipMalloc(&c->d_status, sizeof(DeviceStatus)));
+    HIP_TRY(hipMalloc(&c->d_points, sizeof(unsigned long long)));
+    HIP_TRY(hipHostMalloc(&c->h_status, sizeof(DeviceStatus)));
+    for (auto& ev : c->ev) HIP_TRY(hipEventCreate(&ev));
+    *out = c;
+    return LCHD_OK;
+}
+
+extern "C" void lchd_ctx_destroy(lchd_ctx* c) {
+    if (!c) return;
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->ws);
+    (void)hipFree(c->d_blob);
+    (void)hipFree(c->d_cfg);
+    (void)hipFree(c->d_status);
+    (void)hipFree(c->d_points);
+    (void)hipHostFree(c->h_status);
+    for (auto& ev : c->ev) (void)hipEventDestroy(ev);
+    delete c;
+}
+
+extern "C" int lchd_ctx_set_stream(lchd_ctx* c, void* s) {
+    if (!c) return fail(LCHD_EVALUE, "null context");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->stream = reinterpret_cast<hipStream_t>(s);
+    return LCHD_OK;
+}
+
+extern "C" int lchd_ctx_enable_timing(lchd_ctx* c, int32_t on) {
+    c->timing = on != 0;
+    return LCHD_OK;
+}
+extern "C" double lchd_ctx_last_ms(lchd_ctx* c, const char* phase) {
+    static const char* names[PH_N] = {"cells", "anchors", "env", "sweep"};
+    for (int i = 0; i < PH_N; ++i)
+        if (!strcmp(phase, names[i])) return c->ms[i];
+    return -1.0;
+}
+extern "C" int64_t lchd_ctx_last_env_points(lchd_ctx* c) {
+    if (!c->last_valid) return -1;
+    launch_env_points(c->stream, c->last, c->d_points);
+    unsigned long long v = 0;
+    if (hipMemcpyAsync(&v, c->d_points, sizeof v, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+    return (int64_t)v;
+}
+
+extern "C" int lchd_ctx_set_config(lchd_ctx* c, const lchd_config* cfg) {
+    if (!c || !cfg) return fail(LCHD_EVALUE, "null context/config");
+    const int C = cfg->n_categories;
+    if (C <= 0) return fail(LCHD_EVALUE, "The number of possible categories (primitive types) cannot be zero!");
+    if (C > 32)
+        return fail(LCHD_EUNSUPPORTED, "this build keeps the category state in registers and supports at most 32 categories (got %d)", C);
+    if (int rc = lchd_config_validate(C, C, cfg->category_weights, C)) return rc;
+    if (cfg->n_weight_functions <= 0) return fail(LCHD_EVALUE, "at least one weight function is required");
+    if (int rc = lchd_sd_validate(cfg->sd_kind, cfg->sd_n_params)) return rc;
+    size_t n_params = 0;
+    for (int i = 0; i < cfg->n_weight_functions; ++i) {
+        const lchd_weight_function& w = cfg->weight_functions[i];
+        if (int rc = lchd_wf_validate(w.kind, w.params, w.n_params)) return rc;
+        n_params += (size_t)w.n_params;
+    }
+    // blob: [cat_w][wf entries][wf params][tag pairs]
+    const size_t o_w = 0, o_e = o_w + sizeof(double) * C, o_p = o_e + sizeof(WfEntry) * cfg->n_weight_functions;
+    const size_t o_t = o_p + sizeof(double) * n_params, total = o_t + sizeof(uint64_t) * (size_t)cfg->n_tag_pairs;
+    std::vector<char> blob(total + 8);
+    memcpy(blob.data() + o_w, cfg->category_weights, sizeof(double) * C);
+    WfEntry* ent = reinterpret_cast<WfEntry*>(blob.data() + o_e);
+    double* prm = reinterpret_cast<double*>(blob.data() + o_p);
+    int off = 0;
+    for (int i = 0; i < cfg->n_weight_functions; ++i) {
+        const lchd_weight_function& w = cfg->weight_functions[i];
+        ent[i] = WfEntry{w.kind, w.n_params, off, 0};
+        memcpy(prm + off, w.params, sizeof(double) * w.n_params);
+        off += w.n_params;
+    }
+    uint64_t* tp = reinterpret_cast<uint64_t*>(blob.data() + o_t);
+    for (int64_t i = 0; i < cfg->n_tag_pairs; ++i)
+        tp[i] = ((uint64_t)(uint32_t)cfg->tag_pairs[2 * i] << 32) | (uint32_t)cfg->tag_pairs[2 * i + 1];
+    std::sort(tp, tp + cfg->n_tag_pairs);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (total + 8 > c->blob_cap) {
+        if (c->d_blob) HIP_TRY(hipFree(c->d_blob));
+        c->d_blob = nullptr;
+        HIP_TRY(hipMalloc(&c->d_blob, total + 4096));
+        c->blob_cap = total + 4096;
+    }
+    HIP_TRY(hipMemcpy(c->d_blob, blob.data(), total, hipMemcpyHostToDevice));
+    DevConfig h{};
+    h.n_categories = C;
+    h.n_wf = cfg->n_weight_functions;
+    h.sd_kind = cfg->sd_kind;
+    h.tag_mode = cfg->tag_mode;
+    h.tag_accept_same = cfg->tag_accept_same;
+    h.tag_accepted_pairs = cfg->tag_accepted_pairs;
+    h.tag_ordered = cfg->tag_ordered;
+    h.n_tag_pairs = (int32_t)cfg->n_tag_pairs;
+    h.sd_p0 = cfg->sd_n_params > 0 ? cfg->sd_params[0] : 0.0;
+    h.sd_p1 = cfg->sd_n_params > 1 ? cfg->sd_params[1] : 0.0;
+    h.cat_w = reinterpret_cast<const double*>(c->d_blob + o_w);
+    h.wf = reinterpret_cast<const WfEntry*>(c->d_blob + o_e);
+    h.wf_params = reinterpret_cast<const double*>(c->d_blob + o_p);
+    h.tag_pairs = reinterpret_cast<const uint64_t*>(c->d_blob + o_t);
+    HIP_TRY(hipMemcpy(c->d_cfg, &h, sizeof h, hipMemcpyHostToDevice));
+    c->h_cfg = h;
+    c->cfg_set = true;
+    return LCHD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// clouds
+// ------------------------------------------------------------------------------------------------
+static int upload_coords(lchd_ctx* c, lchd_cloud* cl, const double* xyz) {
+    const int64_t n = cl->n;
+    std::vector<double> soa((size_t)3 * n);
+    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) {
+            const double v = xyz[3 * i + k];
+            if (!std::isfinite(v)) return fail(LCHD_EVALUE, "non-finite coordinate at atom %lld", (long long)i);
+            soa[(size_t)k * n + i] = v;
+            mn[k] = std::min(mn[k], v);
+            mx[k] = std::max(mx[k], v);
+        }
+    for (int k = 0; k < 3; ++k) { cl->bbmin[k] = n ? mn[k] : 0.0; cl->bbmax[k] = n ? mx[k] : 0.0; }
+    if (n) {
+        HIP_TRY(hipMemcpyAsync(cl->x, soa.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(cl->y, soa.data() + n, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(cl->z, soa.data() + 2 * n, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return LCHD_OK;
+}
+
+static std::vector<uint8_t> cats_to_u8(const int32_t* cat, int64_t n) {
+    std::vector<uint8_t> v((size_t)n);
+    for (int64_t i = 0; i < n; ++i) v[(size_t)i] = (cat[i] >= 0 && cat[i] < 255) ? (uint8_t)cat[i] : (uint8_t)255;  // 255 = not in the map
+    return v;
+}
+
+extern "C" int lchd_cloud_create(lchd_ctx* c, const double* xyz, const int32_t* cat, const int32_t* tag, int64_t n, lchd_cloud** out) {
+    if (!c) return fail(LCHD_EVALUE, "null context");
+    if (n < 0 || n > (int64_t)1 << 30) return fail(LCHD_EUNSUPPORTED, "cloud size %lld out of range", (long long)n);
+    lchd_cloud* cl = new lchd_cloud();
+    cl->n = n;
+    const size_t m = (size_t)std::max<int64_t>(n, 1);
+    HIP_TRY(hipMalloc(&cl->x, sizeof(double) * m));
+    HIP_TRY(hipMalloc(&cl->y, sizeof(double) * m));
+    HIP_TRY(hipMalloc(&cl->z, sizeof(double) * m));
+    HIP_TRY(hipMalloc(&cl->cat, m));
+    HIP_TRY(hipMalloc(&cl->tag, sizeof(int32_t) * m));
+    if (xyz) {
+        if (int rc = upload_coords(c, cl, xyz)) { lchd_cloud_destroy(c, cl); return rc; }
+    } else {
+        HIP_TRY(hipMemsetAsync(cl->x, 0, sizeof(double) * m, c->stream));
+        HIP_TRY(hipMemsetAsync(cl->y, 0, sizeof(double) * m, c->stream));
+        HIP_TRY(hipMemsetAsync(cl->z, 0, sizeof(double) * m, c->stream));
+    }
+    if (n) {
+        std::vector<uint8_t> c8 = cats_to_u8(cat, n);
+        HIP_TRY(hipMemcpy(cl->cat, c8.data(), (size_t)n, hipMemcpyHostToDevice));
+        if (tag) HIP_TRY(hipMemcpy(cl->tag, tag, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+        else HIP_TRY(hipMemset(cl->tag, 0, sizeof(int32_t) * n));
+    }
+    *out = cl;
+    return LCHD_OK;
+}
+
+extern "C" int lchd_cloud_set_coords(lchd_ctx* c, lchd_cloud* cl, const double* xyz) {
+    if (!c || !cl || !xyz) return fail(LCHD_EVALUE, "null argument");
+    return upload_coords(c, cl, xyz);
+}
+
+extern "C" void lchd_cloud_destroy(lchd_ctx* c, lchd_cloud* cl) {
+    if (!cl) return;
+    if (c) (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(cl->x);
+    (void)hipFree(cl->y);
+    (void)hipFree(cl->z);
+    (void)hipFree(cl->cat);
+    (void)hipFree(cl->tag);
+    delete cl;
+}
+
+// ------------------------------------------------------------------------------------------------
+// status -> reference error classes
+// ------------------------------------------------------------------------------------------------
+enum Driver { DRV_ANCHORS, DRV_DMXS, DRV_PRIMS };
+
+static int status_to_rc(uint32_t f, Driver drv) {
+    if (f == 0) return LCHD_OK;
+    if (f & ST_BAD_ANCHOR) return fail(LCHD_EPANIC, "index out of bounds: an anchor index is outside its structure (src/locohd.rs:521)");
+    if (f & ST_EMPTY_ENV) return fail(LCHD_EPANIC, "index out of bounds: an environment is empty (src/locohd.rs:74)");
+    if (f & ST_BAD_WF) return fail(LCHD_EVALUE, "weight-function index out of range");
+    if (drv == DRV_ANCHORS) {
+        if (f & ST_FIRST_NOT_ZERO) return fail(LCHD_EVALUE, "The dists list must start with a distance of 0!");
+        if (f & ST_BAD_CATEGORY) return fail(LCHD_EVALUE, "Category not found!");
+        if (f & ST_ZERO_NORM) return fail(LCHD_EVALUE, "Zero norm error for PMF");
+    }
+    if (f & (ST_FIRST_NOT_ZERO | ST_BAD_CATEGORY | ST_ZERO_NORM | ST_BAD_DISTANCE))
+        return fail(LCHD_EVALUE, drv == DRV_PRIMS ? "The from_anchors function returned an error during the LoCoHD calculations!"
+                                                  : "The stat_dist_integral function returned an error during the LoCoHD calculations!");
+    return fail(LCHD_EDEVICE, "unexpected device status 0x%x", f);
+}
+
+static int read_status(lchd_ctx* c) {
+    HIP_TRY(hipMemcpyAsync(c->h_status, c->d_status, sizeof(DeviceStatus), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LCHD_OK;
+}
+
+static void mark(lchd_ctx* c, int i) {
+    if (c->timing) (void)hipEventRecord(c->ev[i], c->stream);
+}
+static void collect_times(lchd_ctx* c, int first, int last) {
+    for (int i = 0; i < PH_N; ++i) c->ms[i] = -1.f;
+    if (!c->timing) return;
+    for (int i = first; i < last; ++i) {
+        float t = -1.f;
+        if (hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1]) == hipSuccess) c->ms[i] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// from_primitives on device-resident clouds
+// ------------------------------------------------------------------------------------------------
+struct GridPlan {
+    double min[3], inv[3];
+    int dim[3];
+    int n_cells;
+};
+
+static GridPlan plan_grid(const lchd_cloud* cl, double thr) {
+    GridPlan g{};
+    // cells are at least (1 + 1e-9) * thr wide so that |dx| < thr can never skip a cell through rounding
+    const double cell0 = thr * (1.0 + 1e-9);
+    long long total = 1;
+    for (int k = 0; k < 3; ++k) {
+        const double ext = cl->bbmax[k] - cl->bbmin[k];
+        double nd = std::floor(ext / cell0);
+        if (!(nd >= 1.0)) nd = 1.0;
+        if (nd > 1024.0) nd = 1024.0;
+        g.dim[k] = (int)nd;
+        total *= g.dim[k];
+    }
+    while (total > (1ll << 18)) {  // keep the single-workgroup scan cheap: coarsen the largest axis
+        int k = (g.dim[0] >= g.dim[1] && g.dim[0] >= g.dim[2]) ? 0 : (g.dim[1] >= g.dim[2] ? 1 : 2);
+        total /= g.dim[k];
+        g.dim[k] = (g.dim[k] + 1) / 2;
+        total *= g.dim[k];
+    }
+    for (int k = 0; k < 3; ++k) {
+        const double ext = cl->bbmax[k] - cl->bbmin[k];
+        g.min[k] = cl->bbmin[k];
+        const double cell = ext > 0.0 ? ext / g.dim[k] : 1.0;
+        g.inv[k] = 1.0 / (cell * (1.0 + 1e-12));
+    }
+    g.n_cells = g.dim[0] * g.dim[1] * g.dim[2];
+    return g;
+}
+
+struct SideBufs {
+    uint32_t *cell_of, *cell_count, *cursor, *cell_start, *porig, *slot, *uniq;
+    double *px, *py, *pz;
+    uint8_t* pcat;
+    int32_t* ptag;
+    EnvStore env;
+};
+
+static void carve_side(Arena& a, int64_t n, int n_cells, int64_t max_envs, int cap, SideBufs& b) {
+    const size_t m = (size_t)std::max<int64_t>(n, 1);
+    b.cell_of = a.take<uint32_t>(m);
+    b.cell_count = a.take<uint32_t>((size_t)n_cells + 1);
+    b.cursor = a.take<uint32_t>((size_t)n_cells + 1);
+    b.cell_start = a.take<uint32_t>((size_t)n_cells + 1);
+    b.px = a.take<double>(m);
+    b.py = a.take<double>(m);
+    b.pz = a.take<double>(m);
+    b.pcat = a.take<uint8_t>(m);
+    b.ptag = a.take<int32_t>(m);
+    b.porig = a.take<uint32_t>(m);
+    b.slot = a.take<uint32_t>(m + 1);
+    b.uniq = a.take<uint32_t>(m);
+    const size_t ne = (size_t)std::max<int64_t>(max_envs, 1);
+    b.env.key = a.take<uint64_t>(ne * (size_t)cap);
+    b.env.cat = a.take<uint8_t>(ne * (size_t)cap);
+    b.env.len = a.take<int32_t>(ne);
+    b.env.stride = cap;
+}
+
+static int next_pow2_host(int64_t n) {
+    int p = 64;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+extern "C" int lchd_from_primitives_dev(lchd_ctx* c, lchd_cloud* a, lchd_cloud* b, const int64_t* d_anchors,
+                                        const int32_t* d_wf_index, int64_t n_pairs, double thr, double* d_out) {
+    if (!c || !a || !b) return fail(LCHD_EVALUE, "null argument");
+    if (!c->cfg_set) return fail(LCHD_EVALUE, "lchd_ctx_set_config has not been called");
+    c->last_valid = false;
+    if (n_pairs <= 0) return LCHD_OK;
+    if (!(thr > 0.0))  // within_radius returns nothing => dists[0] panics (src/locohd.rs:74)
+        return fail(LCHD_EPANIC, "index out of bounds: threshold_distance = %g leaves every environment empty", thr);
+    if (a->n == 0 || b->n == 0) return fail(LCHD_EPANIC, "index out of bounds: anchor pairs given for an empty structure");
+    if (!std::isfinite(thr)) thr = 1.7e308;
+
+    const GridPlan ga = plan_grid(a, thr), gb = plan_grid(b, thr);
+    const int64_t max_env_a = std::min<int64_t>(a->n, n_pairs), max_env_b = std::min<int64_t>(b->n, n_pairs);
+    int cap = c->cap_hint;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        SideBufs sa{}, sb{};
+        {
+            Arena dry(nullptr, 0, true);
+            carve_side(dry, a->n, ga.n_cells, max_env_a, cap, sa);
+            carve_side(dry, b->n, gb.n_cells, max_env_b, cap, sb);
+            if (int rc = ensure_ws(c, dry.off + 4096)) return rc;
+        }
+        Arena ar(c->ws, c->ws_cap, false);
+        carve_side(ar, a->n, ga.n_cells, max_env_a, cap, sa);
+        carve_side(ar, b->n, gb.n_cells, max_env_b, cap, sb);
+
+        auto grid_view = [](const GridPlan& g, const SideBufs& s) {
+            GridView v{};
+            for (int k = 0; k < 3; ++k) { v.min[k] = g.min[k]; v.inv[k] = g.inv[k]; v.dim[k] = g.dim[k]; }
+            v.n_cells = g.n_cells;
+            v.cell_start = s.cell_start;
+            v.px = s.px; v.py = s.py; v.pz = s.pz;
+            v.pcat = s.pcat; v.ptag = s.ptag; v.porig = s.porig;
+            return v;
+        };
+        const GridView gva = grid_view(ga, sa), gvb = grid_view(gb, sb);
+        const CloudView cva = a->view(), cvb = b->view();
+        hipStream_t s = c->stream;
+        HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(DeviceStatus), s));
+        mark(c, 0);
+        launch_cell_build(s, cva, gva, sa.cell_of, sa.cell_count, sa.cursor, sa.px, sa.py, sa.pz, sa.pcat, sa.ptag, sa.porig, sa.cell_start);
+        launch_cell_build(s, cvb, gvb, sb.cell_of, sb.cell_count, sb.cursor, sb.px, sb.py, sb.pz, sb.pcat, sb.ptag, sb.porig, sb.cell_start);
+        mark(c, 1);
+        launch_anchor_dedupe(s, d_anchors, n_pairs, 0, (int32_t)a->n, sa.slot, sa.uniq, c->d_status);
+        launch_anchor_dedupe(s, d_anchors, n_pairs, 1, (int32_t)b->n, sb.slot, sb.uniq, c->d_status);
+        mark(c, 2);
+        if (!launch_env_cells(s, cap, c->d_cfg, cva, gva, sa.uniq, 0, max_env_a, thr, sa.env, c->d_status) ||
+            !launch_env_cells(s, cap, c->d_cfg, cvb, gvb, sb.uniq, 1, max_env_b, thr, sb.env, c->d_status))
+            return fail(LCHD_EUNSUPPORTED, "no environment kernel variant with capacity %d", cap);
+        mark(c, 3);
+        SweepArgs sw{};
+        sw.cfg = c->d_cfg;
+        sw.env_a = sa.env;
+        sw.env_b = sb.env;
+        sw.anchors = d_anchors;
+        sw.slot_a = sa.slot;
+        sw.slot_b = sb.slot;
+        sw.n_slot_a = a->n;
+        sw.n_slot_b = b->n;
+        sw.wf_index = d_wf_index;
+        sw.n_pairs = n_pairs;
+        sw.out = d_out;
+        sw.st = c->d_status;
+        launch_sweep(s, c->h_cfg.n_categories, sw);
+        mark(c, 4);
+        HIP_TRY(hipGetLastError());
+        if (int rc = read_status(c)) return rc;
+        collect_times(c, 0, 4);
+        const uint32_t f = c->h_status->flags;
+        if (f & ST_BAD_ANCHOR) return status_to_rc(f, DRV_PRIMS);
+        if (f & ST_ENV_OVERFLOW) {
+            const int64_t need = c->h_status->max_env;
+            if (need > 4096)
+                return fail(LCHD_EUNSUPPORTED, "an environment holds %lld points; this build sorts at most 4096 per environment "
+                                               "in the thresholded path", (long long)need);
+            cap = next_pow2_host(need);
+            c->cap_hint = cap;
+            continue;
+        }
+        c->last = sw;
+        c->last_valid = true;
+        return status_to_rc(f, DRV_PRIMS);
+    }
+    return fail(LCHD_EDEVICE, "environment capacity retry did not converge");
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-pointer drivers
+// ------------------------------------------------------------------------------------------------
+static int check_wf_index(const lchd_config* cfg, const int32_t* wf_index, int64_t n) {
+    if (!wf_index) return LCHD_OK;
+    for (int64_t i = 0; i < n; ++i)
+        if (wf_index[i] < 0 || wf_index[i] >= cfg->n_weight_functions)
+            return fail(LCHD_EVALUE, "weight-function index %d out of range at position %lld", wf_index[i], (long long)i);
+    return LCHD_OK;
+}
+
+extern "C" int lchd_from_primitives(lchd_ctx* c, const lchd_config* cfg, const double* xyz_a, const int32_t* cat_a,
+                                    const int32_t* tag_a, int64_t n_a, const double* xyz_b, const int32_t* cat_b,
+                                    const int32_t* tag_b, int64_t n_b, const int64_t* anchors, const int32_t* wf_index,
+                                    int64_t n_pairs, double thr, double* out) {
+    if (!c) return fail(LCHD_EVALUE, "null context");
+    if (int rc = lchd_ctx_set_config(c, cfg)) return rc;
+    if (int rc = check_wf_index(cfg, wf_index, n_pairs)) return rc;
+    if (n_pairs == 0) return LCHD_OK;
+    lchd_cloud *a = nullptr, *b = nullptr;
+    int64_t* d_anchors = nullptr;
+    int32_t* d_wf = nullptr;
+    double* d_out = nullptr;
+    int rc = lchd_cloud_create(c, xyz_a, cat_a, tag_a, n_a, &a);
+    if (!rc) rc = lchd_cloud_create(c, xyz_b, cat_b, tag_b, n_b, &b);
+    auto hip_rc = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && !rc) rc = fail(LCHD_EDEVICE, "HIP error %d in %s", (int)e, what);
+    };
+    if (!rc) hip_rc(hipMalloc(&d_anchors, sizeof(int64_t) * 2 * n_pairs), "hipMalloc(anchors)");
+    if (!rc) hip_rc(hipMalloc(&d_out, sizeof(double) * n_pairs), "hipMalloc(out)");
+    if (!rc && wf_index) hip_rc(hipMalloc(&d_wf, sizeof(int32_t) * n_pairs), "hipMalloc(wf_index)");
+    if (!rc) hip_rc(hipMemcpy(d_anchors, anchors, sizeof(int64_t) * 2 * n_pairs, hipMemcpyHostToDevice), "H2D anchors");
+    if (!rc && wf_index) hip_rc(hipMemcpy(d_wf, wf_index, sizeof(int32_t) * n_pairs, hipMemcpyHostToDevice), "H2D wf_index");
+    if (!rc) rc = lchd_from_primitives_dev(c, a, b, d_anchors, d_wf, n_pairs, thr, d_out);
+    if (!rc) hip_rc(hipMemcpy(out, d_out, sizeof(double) * n_pairs, hipMemcpyDeviceToHost), "D2H scores");
+    (void)hipFree(d_anchors);
+    (void)hipFree(d_wf);
+    (void)hipFree(d_out);
+    c->last_valid = false;  // the per-call anchor buffer is gone: lchd_ctx_last_env_points must not touch it
+    lchd_cloud_destroy(c, a);
+    lchd_cloud_destroy(c, b);
+    return rc;
+}
+
+// Shared tail of from_anchors / from_dmxs / from_coords: environments are already sorted in `ea`/`eb`
+// (one per row), pair p = (row p, row p).
+static int sweep_rows(lchd_ctx* c, const EnvStore& ea, const EnvStore& eb, const int32_t* d_wf, int64_t rows, double* d_out,
+                      Driver drv) {
+    SweepArgs sw{};
+    sw.cfg = c->d_cfg;
+    sw.env_a = ea;
+    sw.env_b = eb;
+    sw.wf_index = d_wf;
+    sw.n_pairs = rows;
+    sw.out = d_out;
+    sw.st = c->d_status;
+    launch_sweep(c->stream, c->h_cfg.n_categories, sw);
+    mark(c, 4);
+    HIP_TRY(hipGetLastError());
+    if (int rc = read_status(c)) return rc;
+    collect_times(c, 2, 4);
+    return status_to_rc(c->h_status->flags, drv);
+}
+
+static int dense_driver(lchd_ctx* c, const lchd_config* cfg, const int32_t* seq_a, int64_t len_seq_a, const int32_t* seq_b,
+                        int64_t len_seq_b, const double* xyz_a, const double* xyz_b, const double* dmx_a, const double* dmx_b,
+                        int64_t rows, int64_t cols_a, int64_t cols_b, const int32_t* wf_index, double* out) {
+    if (int rc = lchd_ctx_set_config(c, cfg)) return rc;
+    if (int rc = check_wf_index(cfg, wf_index, rows)) return rc;
+    c->last_valid = false;
+    if (rows == 0) return LCHD_OK;
+    // utils.rs:25-39: the sort mask has row-length entries and indexes seq => a row longer than seq panics
+    if (cols_a > len_seq_a || cols_b > len_seq_b) return fail(LCHD_EPANIC, "index out of bounds: a distance row is longer than its seq");
+    if (cols_a == 0 || cols_b == 0) return fail(LCHD_EPANIC, "index out of bounds: empty distance row (src/locohd.rs:74)");
+    const int cap_a = next_pow2_host(cols_a), cap_b = next_pow2_host(cols_b);
+    if (cap_a > 16384 || cap_b > 16384)
+        return fail(LCHD_EUNSUPPORTED, "dense rows of more than 16384 points are not supported by this build (got %lld / %lld)",
+                    (long long)cols_a, (long long)cols_b);
+    lchd_cloud *a = nullptr, *b = nullptr;
+    int rc = lchd_cloud_create(c, xyz_a, seq_a, nullptr, cols_a, &a);
+    if (!rc) rc = lchd_cloud_create(c, xyz_b, seq_b, nullptr, cols_b, &b);
+    if (rc) { lchd_cloud_destroy(c, a); lchd_cloud_destroy(c, b); return rc; }
+    auto body = [&]() -> int {
+        EnvStore ea{}, eb{};
+        double *d_ma = nullptr, *d_mb = nullptr, *d_out = nullptr;
+        int32_t* d_wf = nullptr;
+        for (int dry = 1; dry >= 0; --dry) {
+            Arena ar(dry ? nullptr : c->ws, dry ? 0 : c->ws_cap, dry != 0);
+            ea.key = ar.take<uint64_t>((size_t)rows * cap_a);
+            ea.cat = ar.take<uint8_t>((size_t)rows * cap_a);
+            ea.len = ar.take<int32_t>((size_t)rows);
+            ea.stride = cap_a;
+            eb.key = ar.take<uint64_t>((size_t)rows * cap_b);
+            eb.cat = ar.take<uint8_t>((size_t)rows * cap_b);
+            eb.len = ar.take<int32_t>((size_t)rows);
+            eb.stride = cap_b;
+            d_out = ar.take<double>((size_t)rows);
+            d_wf = ar.take<int32_t>((size_t)rows);
+            if (dmx_a) {
+                d_ma = ar.take<double>((size_t)rows * cols_a);
+                d_mb = ar.take<double>((size_t)rows * cols_b);
+            }
+            if (dry) if (int rc2 = ensure_ws(c, ar.off + 4096)) return rc2;
+        }
+        hipStream_t s = c->stream;
+        HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(DeviceStatus), s));
+        if (dmx_a) {
+            HIP_TRY(hipMemcpyAsync(d_ma, dmx_a, sizeof(double) * rows * cols_a, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(d_mb, dmx_b, sizeof(double) * rows * cols_b, hipMemcpyHostToDevice, s));
+        }
+        if (wf_index) HIP_TRY(hipMemcpyAsync(d_wf, wf_index, sizeof(int32_t) * rows, hipMemcpyHostToDevice, s));
+        mark(c, 2);
+        if (!launch_env_rows(s, cap_a, c->d_cfg, a->view(), d_ma, cols_a, rows, cols_a, ea, c->d_status) ||
+            !launch_env_rows(s, cap_b, c->d_cfg, b->view(), d_mb, cols_b, rows, cols_b, eb, c->d_status))
+            return fail(LCHD_EUNSUPPORTED, "no dense environment kernel for this row length");
+        mark(c, 3);
+        if (int rc2 = sweep_rows(c, ea, eb, wf_index ? d_wf : nullptr, rows, d_out, DRV_DMXS)) return rc2;
+        HIP_TRY(hipMemcpy(out, d_out, sizeof(double) * rows, hipMemcpyDeviceToHost));
+        return LCHD_OK;
+    };
+    rc = body();
+    lchd_cloud_destroy(c, a);
+    lchd_cloud_destroy(c, b);
+    return rc;
+}
+
+extern "C" int lchd_from_coords(lchd_ctx* c, const lchd_config* cfg, const int32_t* seq_a, int64_t len_seq_a, const int32_t* seq_b,
+                                int64_t len_seq_b, const double* xyz_a, int64_t n_a, const double* xyz_b, int64_t n_b,
+                                const int32_t* wf_index, double* out) {
+    if (!c) return fail(LCHD_EVALUE, "null context");
+    if (n_a != n_b)  // src/locohd.rs:420-428 via :472-475
+        return fail(LCHD_EVALUE, "Expected matrices with the same length, got lengths %lld and %lld!", (long long)n_a, (long long)n_b);
+    return dense_driver(c, cfg, seq_a, len_seq_a, seq_b, len_seq_b, xyz_a, xyz_b, nullptr, nullptr, n_a, n_a, n_b, wf_index, out);
+}
+
+extern "C" int lchd_from_dmxs(lchd_ctx* c, const lchd_config* cfg, const int32_t* seq_a, int64_t len_seq_a, const int32_t* seq_b,
+                              int64_t len_seq_b, const double* dmx_a, int64_t rows_a, int64_t cols_a, const double* dmx_b,
+                              int64_t rows_b, int64_t cols_b, const int32_t* wf_index, double* out) {
+    if (!c) return fail(LCHD_EVALUE, "null context");
+    if (rows_a != rows_b)  // src/locohd.rs:420-428
+        return fail(LCHD_EVALUE, "Expected matrices with the same length, got lengths %lld and %lld!", (long long)rows_a, (long long)rows_b);
+    return dense_driver(c, cfg, seq_a, len_seq_a, seq_b, len_seq_b, nullptr, nullptr, dmx_a, dmx_b, rows_a, cols_a, cols_b, wf_index, out);
+}
+
+extern "C" int lchd_from_anchors(lchd_ctx* c, const lchd_config* cfg, const int32_t* seq_a, int64_t len_seq_a, const double* dists_a,
+                                 int64_t len_dists_a, const int32_t* seq_b, int64_t len_seq_b, const double* dists_b,
+                                 int64_t len_dists_b, int32_t wf_index, double* out) {
+    if (!c) return fail(LCHD_EVALUE, "null context");
+    if (int rc = lchd_ctx_set_config(c, cfg)) return rc;
+    if (wf_index < 0 || wf_index >= cfg->n_weight_functions) return fail(LCHD_EVALUE, "weight-function index out of range");
+    c->last_valid = false;
+    // src/locohd.rs:70-77
+    if (len_seq_a != len_dists_a || len_seq_b != len_dists_b) return fail(LCHD_EVALUE, "Lists seq and dists must have equal lengths!");
+    if (len_seq_a == 0 || len_seq_b == 0) return fail(LCHD_EPANIC, "index out of bounds: the len is 0 but the index is 0");
+    if (dists_a[0] != 0.0 || dists_b[0] != 0.0) return fail(LCHD_EVALUE, "The dists list must start with a distance of 0!");
+    if (len_seq_a > 65535 || len_seq_b > 65535) return fail(LCHD_EUNSUPPORTED, "environments of more than 65535 points are not supported");
+    for (int side = 0; side < 2; ++side) {
+        const double* d = side ? dists_b : dists_a;
+        const int64_t n = side ? len_dists_b : len_dists_a;
+        for (int64_t i = 0; i < n; ++i) {
+            if (std::isnan(d[i])) return fail(LCHD_EPANIC, "internal error: entered unreachable code (NaN distance)");
+            if (d[i] < 0.0) return fail(LCHD_EVALUE, "Invalid input value: %g. All values must be non-negative!", d[i]);
+            if (i && d[i] < d[i - 1])
+                return fail(LCHD_EUNSUPPORTED, "dists must be ascending (the reference does not check this and its result for "
+                                               "unsorted input is unspecified)");
+        }
+    }
+    EnvStore ea{}, eb{};
+    double* d_out = nullptr;
+    for (int dry = 1; dry >= 0; --dry) {
+        Arena ar(dry ? nullptr : c->ws, dry ? 0 : c->ws_cap, dry != 0);
+        ea.key = ar.take<uint64_t>((size_t)len_seq_a);
+        ea.cat = ar.take<uint8_t>((size_t)len_seq_a);
+        ea.len = ar.take<int32_t>(1);
+        ea.stride = len_seq_a;
+        eb.key = ar.take<uint64_t>((size_t)len_seq_b);
+        eb.cat = ar.take<uint8_t>((size_t)len_seq_b);
+        eb.len = ar.take<int32_t>(1);
+        eb.stride = len_seq_b;
+        d_out = ar.take<double>(1);
+        if (dry) if (int rc = ensure_ws(c, ar.off + 4096)) return rc;
+    }
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(DeviceStatus), s));
+    auto upload = [&](const EnvStore& e, const int32_t* seq, const double* d, int64_t n) -> int {
+        std::vector<uint64_t> k((size_t)n);
+        for (int64_t i = 0; i < n; ++i) { const double v = d[i] + 0.0; memcpy(&k[(size_t)i], &v, 8); }
+        std::vector<uint8_t> c8 = cats_to_u8(seq, n);
+        const int32_t len = (int32_t)n;
+        HIP_TRY(hipMemcpy(e.key, k.data(), sizeof(uint64_t) * n, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(e.cat, c8.data(), (size_t)n, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(e.len, &len, sizeof len, hipMemcpyHostToDevice));
+        return LCHD_OK;
+    };
+    if (int rc = upload(ea, seq_a, dists_a, len_seq_a)) return rc;
+    if (int rc = upload(eb, seq_b, dists_b, len_seq_b)) return rc;
+    int32_t* d_wf = nullptr;
+    // a single pair: its weight function index travels as a 1-element device array only when it is not 0
+    std::vector<int32_t> wfv(1, wf_index);
+    if (wf_index != 0) {
+        HIP_TRY(hipMalloc(&d_wf, sizeof(int32_t)));
+        HIP_TRY(hipMemcpy(d_wf, wfv.data(), sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    mark(c, 2);
+    mark(c, 3);
+    int rc = sweep_rows(c, ea, eb, d_wf, 1, d_out, DRV_ANCHORS);
+    if (!rc) {
+        hipError_t e = hipMemcpy(out, d_out, sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(LCHD_EDEVICE, "HIP error %d in D2H score", (int)e);
+    }
+    (void)hipFree(d_wf);
+    return rc;
+}

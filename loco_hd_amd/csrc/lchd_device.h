@@ -1,0 +1,109 @@
+// lchd_device.h -- internal interface between the C-ABI host layer (lchd_capi.hip) and the gfx950
+// kernels (lchd_kernels.hip).  Plain-old-data argument blocks + launcher prototypes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lchd {
+
+constexpr int kMaxCategories = 255;   // categories travel as u8 on the device
+constexpr int kSweepEPL = 8;          // merged events per lane per tile in the sweep kernel
+constexpr int kSweepTile = 64 * kSweepEPL;
+constexpr uint64_t kPadKey = ~0ull;   // sorts after every valid (non-negative, non-NaN) f64 bit pattern
+
+// status word written by kernels (device memory, zeroed per call)
+enum : uint32_t {
+    ST_BAD_ANCHOR = 1u << 0,      // anchor index outside the cloud            (reference: panic, :521)
+    ST_EMPTY_ENV = 1u << 1,       // environment without any point              (reference: panic, :74)
+    ST_FIRST_NOT_ZERO = 1u << 2,  // sorted dists[0] != 0                       (reference: ValueError, :74-77)
+    ST_BAD_CATEGORY = 1u << 3,    // category id outside [0, C)                 (reference: ValueError, pmf.rs:38-42)
+    ST_ENV_OVERFLOW = 1u << 4,    // environment larger than the kernel variant's LDS capacity (retry bigger)
+    ST_ZERO_NORM = 1u << 5,       // PMF norm 0                                 (reference: ValueError, pmf.rs:70-76)
+    ST_BAD_DISTANCE = 1u << 6,    // negative / NaN distance in a matrix row    (reference: ValueError / panic)
+    ST_BAD_WF = 1u << 7,          // weight-function index outside the table
+};
+struct DeviceStatus {
+    uint32_t flags;
+    uint32_t max_env;        // largest environment seen (for the overflow retry)
+    uint32_t n_unique[2];    // unique anchors per side
+    unsigned long long env_points;  // sum over pairs of n_A + n_B
+};
+
+struct WfEntry {
+    int32_t kind, n_params, offset, pad;
+};
+
+// Device-resident LoCoHD configuration (src/locohd.rs:42-55).
+struct DevConfig {
+    int32_t n_categories;
+    int32_t n_wf;
+    int32_t sd_kind;
+    int32_t tag_mode, tag_accept_same, tag_accepted_pairs, tag_ordered;
+    int32_t n_tag_pairs;
+    double sd_p0, sd_p1;
+    const double* cat_w;        // [n_categories]
+    const WfEntry* wf;          // [n_wf]
+    const double* wf_params;    // concatenated
+    const uint64_t* tag_pairs;  // sorted, (anchor_tag << 32) | neighbour_tag
+};
+
+// SoA structure in HBM.
+struct CloudView {
+    const double *x, *y, *z;
+    const uint8_t* cat;
+    const int32_t* tag;
+    int32_t n;
+};
+
+// Uniform grid over one cloud (replaces KdTree::build_by_ordered_float, src/locohd.rs:504-510).
+struct GridView {
+    double min[3], inv[3];   // cell index = clamp(floor((p - min) * inv), 0, dim-1)
+    int32_t dim[3];
+    int32_t n_cells;
+    const uint32_t* cell_start;  // [n_cells + 1]
+    // points permuted into cell order
+    const double *px, *py, *pz;
+    const uint8_t* pcat;
+    const int32_t* ptag;
+    const uint32_t* porig;
+};
+
+// Sorted environments: env e occupies [e*stride, e*stride + len[e]).
+struct EnvStore {
+    uint64_t* key;   // f64 distance bit patterns, ascending
+    uint8_t* cat;
+    int32_t* len;
+    int64_t stride;
+};
+
+void launch_cell_build(hipStream_t s, const CloudView& c, GridView g, uint32_t* cell_of, uint32_t* cell_count,
+                       uint32_t* cell_cursor, double* px, double* py, double* pz, uint8_t* pcat, int32_t* ptag,
+                       uint32_t* porig, uint32_t* cell_start);
+
+void launch_anchor_dedupe(hipStream_t s, const int64_t* anchors, int64_t n_pairs, int side, int32_t n_points,
+                          uint32_t* flag_then_slot, uint32_t* uniq, DeviceStatus* st);
+
+// returns false if `cap` is not an available variant
+bool launch_env_cells(hipStream_t s, int cap, const DevConfig* cfg, const CloudView& c, const GridView& g,
+                      const uint32_t* uniq, int side, int64_t max_envs, double thr, EnvStore env, DeviceStatus* st);
+
+// dense rows: either distances from coordinates (dmx == nullptr) or given rows (dmx != nullptr, leading dim ld)
+bool launch_env_rows(hipStream_t s, int cap, const DevConfig* cfg, const CloudView& c, const double* dmx, int64_t ld,
+                     int64_t n_rows, int64_t row_len, EnvStore env, DeviceStatus* st);
+
+struct SweepArgs {
+    const DevConfig* cfg;
+    EnvStore env_a, env_b;
+    const int64_t* anchors;   // [P][2] or nullptr => pair p uses env (p, p)
+    const uint32_t* slot_a;   // anchor index -> env slot (nullptr with anchors == nullptr)
+    const uint32_t* slot_b;
+    int64_t n_slot_a, n_slot_b;  // atoms per side (bounds for the anchor indices)
+    const int32_t* wf_index;  // [P] or nullptr => 0
+    int64_t n_pairs;
+    double* out;
+    DeviceStatus* st;
+};
+void launch_sweep(hipStream_t s, int n_categories, const SweepArgs& a);
+void launch_env_points(hipStream_t s, const SweepArgs& a, unsigned long long* out);
+
+}  // namespace lchd

@@ -1,0 +1,643 @@
+// lchd_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the LoCoHD scoring path.
+//
+// Pipeline for one from_primitives call (reference: /root/reference/src/locohd.rs:479-567):
+//
+//   K0  cell list           k_cell_count / k_exclusive_scan / k_cell_scatter
+//                           (replaces KdTree::build_by_ordered_float, :504-510)
+//   K0' anchor de-dup       k_mark_anchors / scan / k_compact_anchors
+//                           (an anchor that occurs in many pairs gets its environment built once)
+//   K1  environment build   k_env_cells<CAP>: radius search + tag filter + distances + LDS bitonic sort
+//                           (replaces env_from_idx :514-542, utils::sort_together utils.rs:25-39)
+//       dense variant       k_env_rows<NT>: whole cloud / given distance-matrix row (from_coords, from_dmxs)
+//   K2  sweep               k_sweep<CMAX>: merge-path partition of the two sorted environments, per-lane
+//                           sequential sweep with a wavefront prefix scan of packed category counts,
+//                           statistical distance per breakpoint, CDF differences, wave64 shuffle reduce
+//                           (replaces stat_dist_integral :61-226, pmf.rs, statistical_distances.rs, cdfs.rs)
+//
+// One wavefront (64 lanes, one 64-thread workgroup) owns one environment (K1) or one anchor pair (K2);
+// the launch has thousands of independent workgroups, so all 256 CUs / 8 XCDs are filled without any
+// inter-workgroup communication.  All arithmetic is f64 like the reference; no MFMA (there is no
+// contraction in this path).
+#include "lchd_device.h"
+#include "lchd_math.h"
+
+namespace lchd {
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int cell_coord(double p, double mn, double inv, int dim) {
+    int c = (int)floor((p - mn) * inv);
+    return min(max(c, 0), dim - 1);
+}
+__device__ __forceinline__ uint64_t d2u(double d) { return (uint64_t)__double_as_longlong(d); }
+__device__ __forceinline__ double u2d(uint64_t u) { return __longlong_as_double((long long)u); }
+
+__device__ __forceinline__ double shfl_f64(double v, int src) {
+    int lo = __shfl(__double2loint(v), src), hi = __shfl(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double shfl_up_f64(double v, int d) {
+    int lo = __shfl_up(__double2loint(v), d), hi = __shfl_up(__double2hiint(v), d);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double shfl_xor_f64(double v, int m) {
+    int lo = __shfl_xor(__double2loint(v), m), hi = __shfl_xor(__double2hiint(v), m);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) {
+    uint32_t lo = __shfl_up((uint32_t)v, d), hi = __shfl_up((uint32_t)(v >> 32), d);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
+    uint32_t lo = __shfl((uint32_t)v, src), hi = __shfl((uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0: uniform grid.  Points keep their f64 coordinates; only the bucketing uses the grid.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_cell_count(CloudView c, GridView g, uint32_t* cell_of, uint32_t* cell_count) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < c.n; i += gridDim.x * blockDim.x) {
+        const int cx = cell_coord(c.x[i], g.min[0], g.inv[0], g.dim[0]);
+        const int cy = cell_coord(c.y[i], g.min[1], g.inv[1], g.dim[1]);
+        const int cz = cell_coord(c.z[i], g.min[2], g.inv[2], g.dim[2]);
+        const uint32_t cell = (uint32_t)((cz * g.dim[1] + cy) * g.dim[0] + cx);
+        cell_of[i] = cell;
+        atomicAdd(&cell_count[cell], 1u);
+    }
+}
+
+// Exclusive scan of n u32 by ONE 1024-thread workgroup (n is a cell or atom count: small). out[n] = total.
+// In-place (out == in) is allowed.
+__global__ __launch_bounds__(1024) void k_exclusive_scan(const uint32_t* in, uint32_t* out, int n, uint32_t* total_out) {
+    __shared__ uint32_t wave_sum[16];
+    __shared__ uint32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const uint32_t v = (i < n) ? in[i] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) wave_sum[wave] = incl;
+        __syncthreads();
+        uint32_t wpre = 0;
+        for (int w = 0; w < wave; ++w) wpre += wave_sum[w];
+        const uint32_t carry = carry_s;
+        if (i < n) out[i] = carry + wpre + incl - v;
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + wpre + incl;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        out[n] = carry_s;
+        if (total_out) *total_out = carry_s;
+    }
+}
+
+__global__ void k_cell_scatter(CloudView c, const uint32_t* cell_of, const uint32_t* cell_start, uint32_t* cursor,
+                               double* px, double* py, double* pz, uint8_t* pcat, int32_t* ptag, uint32_t* porig) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < c.n; i += gridDim.x * blockDim.x) {
+        const uint32_t cell = cell_of[i];
+        const uint32_t pos = cell_start[cell] + atomicAdd(&cursor[cell], 1u);
+        px[pos] = c.x[i];
+        py[pos] = c.y[i];
+        pz[pos] = c.z[i];
+        pcat[pos] = c.cat[i];
+        ptag[pos] = c.tag[i];
+        porig[pos] = (uint32_t)i;
+    }
+}
+
+void launch_cell_build(hipStream_t s, const CloudView& c, GridView g, uint32_t* cell_of, uint32_t* cell_count,
+                       uint32_t* cell_cursor, double* px, double* py, double* pz, uint8_t* pcat, int32_t* ptag,
+                       uint32_t* porig, uint32_t* cell_start) {
+    (void)hipMemsetAsync(cell_count, 0, sizeof(uint32_t) * (size_t)(g.n_cells + 1), s);
+    (void)hipMemsetAsync(cell_cursor, 0, sizeof(uint32_t) * (size_t)(g.n_cells + 1), s);
+    const int nb = (c.n + 255) / 256 > 2048 ? 2048 : (c.n + 255) / 256;
+    if (c.n > 0) k_cell_count<<<nb, 256, 0, s>>>(c, g, cell_of, cell_count);
+    k_exclusive_scan<<<1, 1024, 0, s>>>(cell_count, cell_start, g.n_cells, nullptr);
+    if (c.n > 0) k_cell_scatter<<<nb, 256, 0, s>>>(c, cell_of, cell_start, cell_cursor, px, py, pz, pcat, ptag, porig);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0': anchor de-duplication.  flag[i] = 1 if atom i is an anchor of some pair; exclusive scan turns the
+// flags into environment slots; uniq[slot] = atom index.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_mark_anchors(const int64_t* anchors, int64_t n_pairs, int side, int32_t n_points, uint32_t* flag,
+                               DeviceStatus* st) {
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n_pairs; p += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t a = anchors[2 * p + side];
+        if (a < 0 || a >= n_points) atomicOr(&st->flags, ST_BAD_ANCHOR);
+        else flag[a] = 1u;
+    }
+}
+__global__ void k_compact_anchors(const uint32_t* slot, int32_t n_points, uint32_t* uniq) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_points; i += gridDim.x * blockDim.x)
+        if (slot[i + 1] != slot[i]) uniq[slot[i]] = (uint32_t)i;
+}
+
+void launch_anchor_dedupe(hipStream_t s, const int64_t* anchors, int64_t n_pairs, int side, int32_t n_points,
+                          uint32_t* flag_then_slot, uint32_t* uniq, DeviceStatus* st) {
+    (void)hipMemsetAsync(flag_then_slot, 0, sizeof(uint32_t) * (size_t)(n_points + 1), s);
+    if (n_pairs > 0) {
+        const int64_t nbp = (n_pairs + 255) / 256;
+        k_mark_anchors<<<(int)(nbp > 4096 ? 4096 : nbp), 256, 0, s>>>(anchors, n_pairs, side, n_points, flag_then_slot, st);
+    }
+    k_exclusive_scan<<<1, 1024, 0, s>>>(flag_then_slot, flag_then_slot, n_points, &st->n_unique[side]);
+    if (n_points > 0) {
+        const int nb = (n_points + 255) / 256;
+        k_compact_anchors<<<nb > 2048 ? 2048 : nb, 256, 0, s>>>(flag_then_slot, n_points, uniq);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bitonic sort of (u64 key, u8 value) pairs resident in LDS by a workgroup of NT threads.
+// Keys are f64 bit patterns of non-negative distances: unsigned integer order == numeric order.
+// Equal keys may come out in any order: ties only ever produce zero-width intervals in the sweep
+// (SURVEY.md section 0), so the score does not depend on it.
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void bitonic_sort_lds(uint64_t* key, uint8_t* val, int n2, int tid) {
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (n2 >> 1); t += NT) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const bool up = ((i & k) == 0);
+                const uint64_t a = key[i], b = key[l];
+                if (up ? (a > b) : (a < b)) {
+                    key[i] = b;
+                    key[l] = a;
+                    const uint8_t va = val[i];
+                    val[i] = val[l];
+                    val[l] = va;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__device__ __forceinline__ int next_pow2(int n) {
+    int p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+// tag_pairing_rule.rs:49-75 on interned tags
+__device__ __forceinline__ bool tag_pair_accepted(const DevConfig& cfg, int32_t t_anchor, int32_t t_other) {
+    if (cfg.tag_mode == 0) return (t_anchor == t_other) == (cfg.tag_accept_same != 0);
+    auto contains = [&](uint64_t k) {
+        int lo = 0, hi = cfg.n_tag_pairs;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            const uint64_t v = cfg.tag_pairs[mid];
+            if (v == k) return true;
+            if (v < k) lo = mid + 1; else hi = mid;
+        }
+        return false;
+    };
+    bool acc = contains(((uint64_t)(uint32_t)t_anchor << 32) | (uint32_t)t_other);
+    if (!cfg.tag_ordered) acc = acc || contains(((uint64_t)(uint32_t)t_other << 32) | (uint32_t)t_anchor);
+    return cfg.tag_accepted_pairs ? acc : !acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 (thresholded): one wavefront builds the sorted environment of one unique anchor.
+//   radius search   kd-tree crate within_radius semantics: keep p iff sum(diff^2) < thr^2   (:521)
+//   tag filter      p is the anchor itself, or pair_accepted(anchor.tag, p.tag)             (:524-528)
+//   distance        sqrt(sum(diff^2)), same summation order as utils.rs:1-8                 (:537)
+//   sort            ascending distance                                                       (:541)
+// ------------------------------------------------------------------------------------------------
+template <int CAP>
+__global__ __launch_bounds__(64) void k_env_cells(const DevConfig* __restrict__ cfgp, CloudView c, GridView g,
+                                                  const uint32_t* __restrict__ uniq, int side, double thr,
+                                                  EnvStore env, DeviceStatus* st) {
+    __shared__ uint64_t key[CAP];
+    __shared__ uint8_t val[CAP];
+    const int lane = threadIdx.x;
+    const int64_t e = blockIdx.x;
+    if (e >= (int64_t)st->n_unique[side]) return;
+    const DevConfig cfg = *cfgp;
+    const uint32_t anchor = uniq[e];
+    const double ax = c.x[anchor], ay = c.y[anchor], az = c.z[anchor];
+    const int32_t atag = c.tag[anchor];
+    const double thr2 = thr * thr;
+    const int cx = cell_coord(ax, g.min[0], g.inv[0], g.dim[0]);
+    const int cy = cell_coord(ay, g.min[1], g.inv[1], g.dim[1]);
+    const int cz = cell_coord(az, g.min[2], g.inv[2], g.dim[2]);
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
+
+    int count = 0;
+    for (int zz = max(cz - 1, 0); zz <= min(cz + 1, g.dim[2] - 1); ++zz) {
+        for (int yy = max(cy - 1, 0); yy <= min(cy + 1, g.dim[1] - 1); ++yy) {
+            // the (up to) three x-neighbour cells of one (y,z) row are contiguous in the cell-ordered arrays
+            const int row = (zz * g.dim[1] + yy) * g.dim[0];
+            const int beg = (int)g.cell_start[row + x0], end = (int)g.cell_start[row + x1 + 1];
+            for (int base = beg; base < end; base += 64) {
+                const int idx = base + lane;
+                bool ok = false;
+                double d2 = 0.0;
+                if (idx < end) {
+                    const double dx = g.px[idx] - ax, dy = g.py[idx] - ay, dz = g.pz[idx] - az;
+                    d2 = dx * dx;          // TU is built with -ffp-contract=off: same roundings as the
+                    d2 = d2 + dy * dy;     // reference's `distance += diff * diff`
+                    d2 = d2 + dz * dz;
+                    if (d2 < thr2) ok = (g.porig[idx] == anchor) || tag_pair_accepted(cfg, atag, g.ptag[idx]);
+                }
+                const unsigned long long m = __ballot(ok);
+                if (ok) {
+                    const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
+                    if (pos < CAP) {
+                        key[pos] = d2u(sqrt(d2));
+                        val[pos] = g.pcat[idx];
+                    }
+                }
+                count += __popcll(m);
+            }
+        }
+    }
+    if (count > CAP) {  // the host re-launches a larger variant
+        if (lane == 0) {
+            atomicOr(&st->flags, ST_ENV_OVERFLOW);
+            atomicMax(&st->max_env, (uint32_t)count);
+            env.len[e] = 0;
+        }
+        return;
+    }
+    if (count == 0) {
+        if (lane == 0) { atomicOr(&st->flags, ST_EMPTY_ENV); env.len[e] = 0; }
+        return;
+    }
+    const int n2 = next_pow2(count);
+    for (int i = count + lane; i < n2; i += 64) { key[i] = kPadKey; val[i] = 0; }
+    __syncthreads();
+    bitonic_sort_lds<64>(key, val, n2, lane);
+    uint64_t* ok_ = env.key + e * env.stride;
+    uint8_t* oc_ = env.cat + e * env.stride;
+    for (int i = lane; i < count; i += 64) { ok_[i] = key[i]; oc_[i] = val[i]; }
+    if (lane == 0) env.len[e] = count;
+}
+
+bool launch_env_cells(hipStream_t s, int cap, const DevConfig* cfg, const CloudView& c, const GridView& g,
+                      const uint32_t* uniq, int side, int64_t max_envs, double thr, EnvStore env, DeviceStatus* st) {
+    if (max_envs <= 0) return true;
+    const dim3 grid((unsigned)max_envs), block(64);
+    switch (cap) {
+        case 256: k_env_cells<256><<<grid, block, 0, s>>>(cfg, c, g, uniq, side, thr, env, st); return true;
+        case 512: k_env_cells<512><<<grid, block, 0, s>>>(cfg, c, g, uniq, side, thr, env, st); return true;
+        case 1024: k_env_cells<1024><<<grid, block, 0, s>>>(cfg, c, g, uniq, side, thr, env, st); return true;
+        case 2048: k_env_cells<2048><<<grid, block, 0, s>>>(cfg, c, g, uniq, side, thr, env, st); return true;
+        case 4096: k_env_cells<4096><<<grid, block, 0, s>>>(cfg, c, g, uniq, side, thr, env, st); return true;
+        default: return false;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 (dense): one workgroup sorts one full row -- from_coords (distances from anchor `row` to every atom,
+// utils.rs:10-22 + :25-39) or from_dmxs (a caller-supplied distance-matrix row, src/locohd.rs:439-440).
+// Dynamic LDS: n2 * 9 bytes.
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(NT) void k_env_rows(CloudView c, const double* __restrict__ dmx, int64_t ld,
+                                                 int64_t row_len, int n2, EnvStore env, DeviceStatus* st) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* key = reinterpret_cast<uint64_t*>(smem);
+    uint8_t* val = smem + (size_t)n2 * 8;
+    const int tid = threadIdx.x;
+    const int64_t r = blockIdx.x;
+    const int n = (int)row_len;
+    bool bad = false;
+    if (dmx) {
+        const double* row = dmx + r * ld;
+        for (int i = tid; i < n2; i += NT) {
+            uint64_t k = kPadKey;
+            uint8_t v = 0;
+            if (i < n) {
+                double d = row[i];
+                if (!(d >= 0.0)) { bad = true; d = 0.0; }  // negative or NaN
+                k = d2u(d + 0.0);                            // -0.0 -> +0.0
+                v = c.cat[i];
+            }
+            key[i] = k;
+            val[i] = v;
+        }
+    } else {
+        const double ax = c.x[r], ay = c.y[r], az = c.z[r];
+        for (int i = tid; i < n2; i += NT) {
+            uint64_t k = kPadKey;
+            uint8_t v = 0;
+            if (i < n) {
+                const double dx = ax - c.x[i], dy = ay - c.y[i], dz = az - c.z[i];
+                double d2 = dx * dx;
+                d2 = d2 + dy * dy;
+                d2 = d2 + dz * dz;
+                k = d2u(sqrt(d2));
+                v = c.cat[i];
+            }
+            key[i] = k;
+            val[i] = v;
+        }
+    }
+    if (bad) atomicOr(&st->flags, ST_BAD_DISTANCE);
+    __syncthreads();
+    bitonic_sort_lds<NT>(key, val, n2, tid);
+    uint64_t* ok_ = env.key + r * env.stride;
+    uint8_t* oc_ = env.cat + r * env.stride;
+    for (int i = tid; i < n; i += NT) { ok_[i] = key[i]; oc_[i] = val[i]; }
+    if (tid == 0) {
+        env.len[r] = n;
+        if (n > 0 && key[0] != 0ull) atomicOr(&st->flags, ST_FIRST_NOT_ZERO);
+    }
+}
+
+bool launch_env_rows(hipStream_t s, int cap, const DevConfig* cfg, const CloudView& c, const double* dmx, int64_t ld,
+                     int64_t n_rows, int64_t row_len, EnvStore env, DeviceStatus* st) {
+    (void)cfg;
+    if (n_rows <= 0) return true;
+    if (cap > 16384 || row_len > cap) return false;
+    const size_t lds = (size_t)cap * 9;
+    const dim3 grid((unsigned)n_rows);
+    if (cap <= 1024) {
+        k_env_rows<64><<<grid, 64, lds, s>>>(c, dmx, ld, row_len, cap, env, st);
+    } else if (cap <= 4096) {
+        k_env_rows<256><<<grid, 256, lds, s>>>(c, dmx, ld, row_len, cap, env, st);
+    } else {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_rows<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                16384 * 9);
+            attr_set = true;
+        }
+        k_env_rows<1024><<<grid, 1024, lds, s>>>(c, dmx, ld, row_len, cap, env, st);
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: the sweep.  One wavefront per anchor pair.
+//
+// S = sum_k [F(t_{k+1}) - F(t_k)] * H(state after k events), t_0 = 0, t_{M+1} = inf, where the events are
+// the merged non-anchor points of both environments (the reference's two-pointer
+// loop src/locohd.rs:97-223 evaluates exactly this sum; cross-list ties collapse because a zero-width
+// interval contributes exactly 0).
+//
+// Events are processed in tiles of 512: lane l owns merged events [8l, 8l+8) of the tile, found with a
+// merge-path binary search in LDS.  A packed (16-bit fields) wavefront prefix scan of the per-lane
+// category histograms gives every lane the exact integer category counts at its first event; it then
+// walks its 8 events sequentially, keeping the weighted counts in registers.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int merge_path(const uint64_t* A, int nA, const uint64_t* B, int nB, int d) {
+    int lo = max(0, d - nB), hi = min(d, nA);
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (A[mid] <= B[d - 1 - mid]) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// spread the four 4-bit fields of the low 16 bits of x into four 16-bit fields
+__device__ __forceinline__ uint64_t spread4(uint64_t x) {
+    x &= 0xFFFFull;
+    x = (x | (x << 24)) & 0x000000FF000000FFull;
+    x = (x | (x << 12)) & 0x000F000F000F000Full;
+    return x;
+}
+
+template <int CMAX>
+struct PmfState {
+    double a[CMAX], b[CMAX];  // weighted category counts of environment A / B (pmf.rs:16-17)
+};
+
+template <int CMAX>
+__device__ __forceinline__ double stat_distance(const DevConfig& cfg, const PmfState<CMAX>& s, int C, bool& zero_norm) {
+    // pmf.rs:65-88: normalise by the sums, then dispatch
+    double na = 0.0, nb = 0.0;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) if (c < C) na += s.a[c];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) if (c < C) nb += s.b[c];
+    if (na == 0.0 || nb == 0.0) zero_norm = true;
+    return sd_eval<CMAX>(cfg.sd_kind, cfg.sd_p0, cfg.sd_p1, [&](int c) { return s.a[c] / na; },
+                         [&](int c) { return s.b[c] / nb; }, C);
+}
+
+template <int CMAX>
+__global__ __launch_bounds__(64) void k_sweep(SweepArgs args) {
+    constexpr int EPL = kSweepEPL, TILE = kSweepTile;
+    constexpr int NW = CMAX / 4;  // u64 words of 16-bit fields per side
+    __shared__ uint64_t sA[TILE], sB[TILE];
+    __shared__ uint8_t cA[TILE], cB[TILE];
+    const int lane = threadIdx.x;
+    const DevConfig cfg = *args.cfg;
+    const int C = cfg.n_categories;
+    double w[CMAX];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) w[c] = (c < C) ? cfg.cat_w[c] : 0.0;
+
+    for (int64_t p = blockIdx.x; p < args.n_pairs; p += gridDim.x) {
+        int64_t ea = p, eb = p;
+        if (args.anchors) {
+            const int64_t ia_ = args.anchors[2 * p], ib_ = args.anchors[2 * p + 1];
+            // out-of-range anchors were flagged by k_mark_anchors; do not touch memory for them
+            if (ia_ < 0 || ib_ < 0 || ia_ >= args.n_slot_a || ib_ >= args.n_slot_b) {
+                if (lane == 0) args.out[p] = nan("");
+                continue;
+            }
+            ea = args.slot_a[ia_];
+            eb = args.slot_b[ib_];
+        }
+        const int nA = args.env_a.len[ea], nB = args.env_b.len[eb];
+        if (nA <= 0 || nB <= 0) {  // overflow / empty environment: already flagged by K1
+            if (lane == 0) args.out[p] = nan("");
+            continue;
+        }
+        const uint64_t* kA = args.env_a.key + ea * args.env_a.stride;
+        const uint64_t* kB = args.env_b.key + eb * args.env_b.stride;
+        const uint8_t* tA = args.env_a.cat + ea * args.env_a.stride;
+        const uint8_t* tB = args.env_b.cat + eb * args.env_b.stride;
+        const int wfi = args.wf_index ? args.wf_index[p] : 0;
+        if (wfi < 0 || wfi >= cfg.n_wf) {
+            if (lane == 0) { atomicOr(&args.st->flags, ST_BAD_WF); args.out[p] = nan(""); }
+            continue;
+        }
+        const WfEntry wf = cfg.wf[wfi];
+        const double* wp = cfg.wf_params + wf.offset;
+
+        bool bad_cat = false, zero_norm = false;
+        if (kA[0] != 0ull || kB[0] != 0ull) {  // src/locohd.rs:74-77
+            if (lane == 0) { atomicOr(&args.st->flags, ST_FIRST_NOT_ZERO); args.out[p] = nan(""); }
+            continue;
+        }
+        // packed integer category counts (16-bit fields), wave-uniform: seeded with the two anchors (:82-84)
+        uint64_t cntA[NW], cntB[NW];
+#pragma unroll
+        for (int k = 0; k < NW; ++k) cntA[k] = cntB[k] = 0;
+        {
+            const int c0a = tA[0], c0b = tB[0];
+            if (c0a >= C || c0b >= C) bad_cat = true;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) {
+                if ((c0a >> 2) == k) cntA[k] += 1ull << ((c0a & 3) * 16);
+                if ((c0b >> 2) == k) cntB[k] += 1ull << ((c0b & 3) * 16);
+            }
+        }
+        PmfState<CMAX> s;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
+            s.a[c] = w[c] * (double)((cntA[c >> 2] >> ((c & 3) * 16)) & 0xFFFFull);
+            s.b[c] = w[c] * (double)((cntB[c >> 2] >> ((c & 3) * 16)) & 0xFFFFull);
+        }
+        double F_carry = cdf_eval(wf.kind, wp, wf.n_params, 0.0);
+        double H_carry = bad_cat ? 0.0 : stat_distance<CMAX>(cfg, s, C, zero_norm);
+        double acc = 0.0;
+
+        const int mA = nA - 1, mB = nB - 1, M = mA + mB;  // non-anchor events
+        int ia = 0, ib = 0;
+        for (int k0 = 0; k0 < M; k0 += TILE) {
+            const int T = min(TILE, M - k0);
+            const int nAt = min(TILE, mA - ia), nBt = min(TILE, mB - ib);
+            __syncthreads();  // previous tile fully consumed
+            for (int t = lane; t < nAt; t += 64) { sA[t] = kA[1 + ia + t]; cA[t] = tA[1 + ia + t]; }
+            for (int t = lane; t < nBt; t += 64) { sB[t] = kB[1 + ib + t]; cB[t] = tB[1 + ib + t]; }
+            __syncthreads();
+            const int d0 = min(lane * EPL, T), d1 = min(d0 + EPL, T);
+            const int i0 = merge_path(sA, nAt, sB, nBt, d0);
+            const int iend = merge_path(sA, nAt, sB, nBt, T);
+            int i1 = __shfl_down(i0, 1);
+            if (lane == 63) i1 = iend;
+            const int j0 = d0 - i0, j1 = d1 - i1;
+
+            // pass 1: 4-bit-per-category histogram of this lane's chunk (at most 8 points per side)
+            uint64_t hA[CMAX / 16 > 0 ? CMAX / 16 : 1], hB[CMAX / 16 > 0 ? CMAX / 16 : 1];
+#pragma unroll
+            for (int k = 0; k < (CMAX / 16 > 0 ? CMAX / 16 : 1); ++k) hA[k] = hB[k] = 0;
+            for (int i = i0; i < i1; ++i) {
+                const int ct = cA[i];
+                if (ct >= C) bad_cat = true;
+                else {
+#pragma unroll
+                    for (int k = 0; k < (CMAX / 16 > 0 ? CMAX / 16 : 1); ++k)
+                        if ((ct >> 4) == k) hA[k] += 1ull << ((ct & 15) * 4);
+                }
+            }
+            for (int j = j0; j < j1; ++j) {
+                const int ct = cB[j];
+                if (ct >= C) bad_cat = true;
+                else {
+#pragma unroll
+                    for (int k = 0; k < (CMAX / 16 > 0 ? CMAX / 16 : 1); ++k)
+                        if ((ct >> 4) == k) hB[k] += 1ull << ((ct & 15) * 4);
+                }
+            }
+            // widen to 16-bit fields and exclusive-scan across the wavefront
+            uint64_t exA[NW], exB[NW];
+#pragma unroll
+            for (int k = 0; k < NW; ++k) {
+                uint64_t va = spread4(hA[(k * 4) / 16] >> (((k * 4) % 16) * 4));
+                uint64_t vb = spread4(hB[(k * 4) / 16] >> (((k * 4) % 16) * 4));
+                uint64_t ia_ = va, ib_ = vb;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint64_t ta = shfl_up_u64(ia_, d), tb = shfl_up_u64(ib_, d);
+                    if (lane >= d) { ia_ += ta; ib_ += tb; }
+                }
+                exA[k] = cntA[k] + ia_ - va;
+                exB[k] = cntB[k] + ib_ - vb;
+                cntA[k] += shfl_u64(ia_, 63);  // carry for the next tile
+                cntB[k] += shfl_u64(ib_, 63);
+            }
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) {
+                s.a[c] = w[c] * (double)((exA[c >> 2] >> ((c & 3) * 16)) & 0xFFFFull);
+                s.b[c] = w[c] * (double)((exB[c >> 2] >> ((c & 3) * 16)) & 0xFFFFull);
+            }
+
+            // pass 2: sequential sweep of this lane's events
+            int i = i0, j = j0;
+            double Fp = 0.0, Hp = 0.0, firstF = 0.0, local = 0.0;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                if (d0 + e < d1) {
+                    const bool takeA = (i < i1) && (j >= j1 || sA[i] <= sB[j]);
+                    const uint64_t kb = takeA ? sA[i] : sB[j];
+                    const int ct = takeA ? cA[i] : cB[j];
+                    i += takeA ? 1 : 0;
+                    j += takeA ? 0 : 1;
+                    const double F = cdf_eval(wf.kind, wp, wf.n_params, u2d(kb));
+                    if (e == 0) firstF = F; else local += (F - Fp) * Hp;
+                    // pmf.rs:47-63
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c) {
+                        if (takeA) s.a[c] += (c == ct) ? w[c] : 0.0;
+                        else s.b[c] += (c == ct) ? w[c] : 0.0;
+                    }
+                    Hp = stat_distance<CMAX>(cfg, s, C, zero_norm);
+                    Fp = F;
+                }
+            }
+            // stitch lane chunks: (F_first - F_last_of_previous_lane) * H_before_my_first_event
+            double prevF = shfl_up_f64(Fp, 1), prevH = shfl_up_f64(Hp, 1);
+            if (lane == 0) { prevF = F_carry; prevH = H_carry; }
+            if (d0 < d1) local += (firstF - prevF) * prevH;
+            acc += local;
+            const int last = (T - 1) / EPL;
+            F_carry = shfl_f64(Fp, last);
+            H_carry = shfl_f64(Hp, last);
+            ia += iend;
+            ib += T - iend;
+        }
+        // wave64 butterfly reduction + the last interval to +inf (:165-171,204-210,212-221)
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) acc += shfl_xor_f64(acc, m);
+        const double Finf = cdf_eval(wf.kind, wp, wf.n_params, (double)INFINITY);
+        acc += (Finf - F_carry) * H_carry;
+        const unsigned long long anybad = __ballot(bad_cat), anyzero = __ballot(zero_norm);
+        if (lane == 0) {
+            if (anybad) { atomicOr(&args.st->flags, ST_BAD_CATEGORY); acc = nan(""); }
+            if (anyzero) atomicOr(&args.st->flags, ST_ZERO_NORM);
+            args.out[p] = acc;
+        }
+    }
+}
+
+void launch_sweep(hipStream_t s, int n_categories, const SweepArgs& a) {
+    if (a.n_pairs <= 0) return;
+    const unsigned grid = (unsigned)(a.n_pairs < 262144 ? a.n_pairs : 262144);
+    if (n_categories <= 8) k_sweep<8><<<grid, 64, 0, s>>>(a);
+    else if (n_categories <= 16) k_sweep<16><<<grid, 64, 0, s>>>(a);
+    else k_sweep<32><<<grid, 64, 0, s>>>(a);
+}
+
+// sum over pairs of n_A + n_B (algorithmic-bytes accounting for bench.py; not part of the scoring path)
+__global__ void k_env_points(SweepArgs args, unsigned long long* out) {
+    unsigned long long local = 0;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < args.n_pairs; p += (int64_t)gridDim.x * blockDim.x) {
+        int64_t ea = p, eb = p;
+        if (args.anchors) {
+            const int64_t ia_ = args.anchors[2 * p], ib_ = args.anchors[2 * p + 1];
+            if (ia_ < 0 || ib_ < 0 || ia_ >= args.n_slot_a || ib_ >= args.n_slot_b) continue;
+            ea = args.slot_a[ia_];
+            eb = args.slot_b[ib_];
+        }
+        local += (unsigned long long)max(args.env_a.len[ea], 0) + (unsigned long long)max(args.env_b.len[eb], 0);
+    }
+    for (int m = 32; m > 0; m >>= 1) {
+        const uint32_t lo = __shfl_xor((uint32_t)local, m), hi = __shfl_xor((uint32_t)(local >> 32), m);
+        local += ((unsigned long long)hi << 32) | lo;
+    }
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, local);
+}
+void launch_env_points(hipStream_t s, const SweepArgs& a, unsigned long long* out) {
+    (void)hipMemsetAsync(out, 0, sizeof(unsigned long long), s);
+    if (a.n_pairs > 0) k_env_points<<<1024, 256, 0, s>>>(a, out);
+}
+
+}  // namespace lchd

@@ -1,0 +1,265 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the reference's known answers.
+
+Bar (BASELINE.json north_star): anchor indexing bit-exact (output i belongs to anchor pair i), scores
+within 1e-6 absolute.  In practice the two paths agree to ~1e-14; TOL below is the contractual bound,
+TIGHT the regression bound.
+"""
+import itertools
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-6
+TIGHT = 1e-11
+
+CATS = ["A", "B", "C", "D", "E"]
+
+
+@pytest.fixture(scope="module")
+def lh():
+    import loco_hd_amd
+
+    return loco_hd_amd
+
+
+def both(lh, oracle, build):
+    """build(mod) -> value; returns (hip, oracle) results"""
+    return build(lh), build(oracle)
+
+
+def cloud(rng, n, box=50.0, cats=CATS):
+    return rng.choice(cats, n).tolist(), rng.uniform(-box, box, (n, 3))
+
+
+def prims(mod, seq, xyz, tags=None):
+    tags = [""] * len(seq) if tags is None else tags
+    return [mod.PrimitiveAtom(s, t, c) for s, t, c in zip(seq, tags, xyz)]
+
+
+# ---- the reference's own known answers, through the GPU ------------------------------------------------
+def test_small_locohd(lh):  # /root/reference/tests/test_locohd.py:27-52
+    lchd = lh.LoCoHD(["O", "A", "B", "C"], lh.WeightFunction("uniform", [0.0, 4.0]))
+    seq = ["O", "A", "B", "C"]
+    assert lchd.from_anchors(seq, seq, [0.0, 1.0, 2.0, 3.0], [0.0, 1.0, 1.0, 1.0]) == pytest.approx(0.2268, abs=5e-5)
+    assert lchd.from_anchors(seq, seq, [0.0, 1.0, 1.0, 1.0], [0.0, 1.0, 2.0, 3.0]) == pytest.approx(0.2268, abs=5e-5)
+    lchd = lh.LoCoHD(["A", "B", "C"], lh.WeightFunction("kumaraswamy", [3.0, 10.0, 2.0, 5.0]))
+    v = lchd.from_anchors(["A", "B", "A", "C"], ["A", "C"], [0.0, 1.0, 5.0, 9.0], [0.0, 7.0])
+    assert v == pytest.approx(0.4979, abs=5e-5)
+    assert v == pytest.approx(0.4978635773685092, abs=TIGHT)
+
+
+def test_tag_rule_in_locohd(lh):  # /root/reference/tests/test_tag_pairing_rule.py:100-157
+    from test_oracle_kat import PLANAR_ANCHORS, planar_structure
+
+    s = planar_structure(lh)
+    wf = lh.WeightFunction("uniform", [1.0, 1.001])
+    lchd = lh.LoCoHD(["A", "B", "C"], wf, lh.TagPairingRule({"accept_same": True}))
+    got = lchd.from_primitives(s, s, PLANAR_ANCHORS, 1.002)
+    for g, w in zip(got, [0.0, 0.0, 1.0, 1.0, 1.0]):
+        assert abs(g - w) < 5e-16
+    lchd = lh.LoCoHD(["A", "B", "C"], wf, lh.TagPairingRule({"accept_same": False}))
+    got = lchd.from_primitives(s, s, PLANAR_ANCHORS, 1.002)
+    for g, w in zip(got, [0.7071, 0.5412, 0.5412, 0.4284, 0.6501]):
+        assert g == pytest.approx(w, abs=5e-5)
+
+
+# ---- random clouds vs the oracle ------------------------------------------------------------------------
+WFS = [("uniform", [3.0, 10.0]), ("hyper_exp", [1.0, 0.1]), ("hyper_exp", [0.49, 0.86, 0.55, 0.13, 0.096, 0.157]),
+       ("dagum", [1.7, 2.5, 9.0]), ("kumaraswamy", [2.0, 11.0, 3.3, 4.4])]
+SDS = [("Hellinger", [2.0]), ("Hellinger", [3.4277149325231795]), ("Kolmogorov-Smirnov", []), ("Kullback-Leibler", [0.514]),
+       ("Renyi", [2.428, 0.73]), ("Renyi", [0.0404, 3.566]), ("Renyi", [1.0, 0.5])]
+
+
+@pytest.mark.parametrize("wf", WFS)
+def test_from_primitives_weight_functions(lh, oracle, wf):
+    rng = np.random.default_rng(11)
+    sa, xa = cloud(rng, 257)
+    sb, xb = cloud(rng, 199)
+    anchors = [(i, i) for i in range(199)] + [(256, 0), (0, 198), (5, 5)]
+
+    def run(mod):
+        lchd = mod.LoCoHD(CATS, mod.WeightFunction(*wf))
+        return np.asarray(lchd.from_primitives(prims(mod, sa, xa), prims(mod, sb, xb), anchors, 50.0))
+
+    got, want = both(lh, oracle, run)
+    assert got.shape == want.shape
+    assert np.max(np.abs(got - want)) < TIGHT
+
+
+@pytest.mark.parametrize("sd", SDS)
+def test_from_primitives_statistical_distances(lh, oracle, sd):
+    rng = np.random.default_rng(12)
+    sa, xa = cloud(rng, 180)
+    sb, xb = cloud(rng, 230)
+    anchors = [(int(i), int(j)) for i, j in zip(rng.integers(0, 180, 150), rng.integers(0, 230, 150))]
+
+    def run(mod):
+        lchd = mod.LoCoHD(CATS, mod.WeightFunction("hyper_exp", [1.0, 0.08]), statistical_distance=mod.StatisticalDistance(*sd))
+        return np.asarray(lchd.from_primitives(prims(mod, sa, xa), prims(mod, sb, xb), anchors, 45.0))
+
+    got, want = both(lh, oracle, run)
+    assert np.max(np.abs(got - want)) < 1e-10
+
+
+def test_tags_weights_and_multi_wf(lh, oracle):
+    rng = np.random.default_rng(13)
+    n = 240
+    sa, xa = cloud(rng, n, box=12.0)
+    sb, xb = cloud(rng, n, box=12.0)
+    tags = [f"A/{i // 3}-RES" for i in range(n)]
+    keys = ["near", "far"]
+    anchors = [(i, (7 * i) % n, keys[i % 2]) for i in range(n)]
+    for rule in ({"accept_same": False}, {"accept_same": True},
+                 {"tag_pairs": {(tags[0], tags[3]), (tags[6], tags[9]), (tags[30], tags[30])}, "accepted_pairs": False, "ordered": True},
+                 {"tag_pairs": {(tags[i], tags[j]) for i in range(0, n, 3) for j in range(0, n, 9)}, "accepted_pairs": True, "ordered": False}):
+
+        def run(mod):
+            wfd = {"near": mod.WeightFunction("uniform", [3.0, 10.0]), "far": mod.WeightFunction("dagum", [2.0, 5.0, 1.0])}
+            lchd = mod.LoCoHD(CATS, wfd, mod.TagPairingRule(rule), category_weights=[1.0, 0.5, 2.25, 3.0, 0.1])
+            return np.asarray(lchd.from_primitives(prims(mod, sa, xa, tags), prims(mod, sb, xb, tags), anchors, 9.5))
+
+        got, want = both(lh, oracle, run)
+        assert np.max(np.abs(got - want)) < TIGHT, rule
+
+
+def test_from_coords_and_dmxs(lh, oracle):
+    rng = np.random.default_rng(14)
+    for n in (1, 2, 63, 64, 65, 100, 700, 1500):
+        sa, xa = cloud(rng, n, box=20.0)
+        sb, xb = cloud(rng, n, box=20.0)
+
+        def run(mod):
+            lchd = mod.LoCoHD(CATS, mod.WeightFunction("hyper_exp", [1.0, 1.0 / 7.0]))
+            return np.asarray(lchd.from_coords(sa, sb, xa, xb))
+
+        got, want = both(lh, oracle, run)
+        assert np.max(np.abs(got - want)) < TIGHT, n
+    # from_dmxs with +inf entries (python_codes/ensembles/compare_ensembles.py:261-263) and unequal widths
+    n, m = 90, 70
+    sa, xa = cloud(rng, n, box=15.0)
+    sb, xb = cloud(rng, m, box=15.0)
+    da = np.sqrt(((xa[:60, None, :] - xa[None, :, :]) ** 2).sum(-1))
+    db = np.sqrt(((xb[:60, None, :] - xb[None, :, :]) ** 2).sum(-1))
+    da[rng.integers(0, 60, 40), rng.integers(0, n, 40)] = np.inf
+    for i in range(60):
+        da[i, i] = 0.0
+
+    def run2(mod):
+        lchd = mod.LoCoHD(CATS, mod.WeightFunction("uniform", [3.0, 10.0]))
+        return np.asarray(lchd.from_dmxs(sa, sb, da, db))
+
+    got, want = both(lh, oracle, run2)
+    assert np.max(np.abs(got - want)) < TIGHT
+
+
+def test_ties_and_coincident_points(lh, oracle):
+    """Lattice coordinates: many exactly equal distances inside and across the two environments."""
+    rng = np.random.default_rng(15)
+    grid = np.array(list(itertools.product(range(6), repeat=3)), dtype=float)
+    xa = np.concatenate([grid, grid[:20]])  # duplicates => distance-0 neighbours
+    xb = grid[rng.permutation(len(grid))]
+    sa, sb = rng.choice(CATS, len(xa)).tolist(), rng.choice(CATS, len(xb)).tolist()
+    anchors = [(int(i), int(j)) for i, j in zip(rng.integers(0, len(xa), 200), rng.integers(0, len(xb), 200))]
+    for wf in (("uniform", [1.0, 3.0]), ("kumaraswamy", [0.0, 4.0, 2.0, 2.0])):
+
+        def run(mod):
+            lchd = mod.LoCoHD(CATS, mod.WeightFunction(*wf))
+            return np.asarray(lchd.from_primitives(prims(mod, sa, xa), prims(mod, sb, xb), anchors, 3.0000001))
+
+        got, want = both(lh, oracle, run)
+        assert np.max(np.abs(got - want)) < TIGHT
+
+
+def test_self_comparison_is_zero_and_symmetry(lh):
+    rng = np.random.default_rng(16)
+    s, x = cloud(rng, 400, box=20.0)
+    s2, x2 = cloud(rng, 400, box=20.0)
+    lchd = lh.LoCoHD(CATS, lh.WeightFunction("hyper_exp", [1.0, 0.2]))
+    p, q = prims(lh, s, x), prims(lh, s2, x2)
+    anchors = [(i, i) for i in range(400)]
+    assert max(abs(v) for v in lchd.from_primitives(p, p, anchors, 12.0)) == 0.0
+    ab = np.asarray(lchd.from_primitives(p, q, anchors, 12.0))
+    ba = np.asarray(lchd.from_primitives(q, p, anchors, 12.0))
+    assert np.max(np.abs(ab - ba)) < 1e-13
+    assert ab.min() >= 0.0 and ab.max() <= 1.0 + 1e-12
+
+
+def test_anchor_order_and_reuse(lh, oracle):
+    """Output i must belong to anchor pair i, whatever the order / repetition of anchors."""
+    rng = np.random.default_rng(17)
+    sa, xa = cloud(rng, 150, box=15.0)
+    sb, xb = cloud(rng, 150, box=15.0)
+    anchors = [(int(i), int(j)) for i, j in zip(rng.integers(0, 150, 3000), rng.integers(0, 150, 3000))]
+    anchors += [(0, 0)] * 5 + [(149, 149), (0, 149), (149, 0)]
+
+    def run(mod):
+        lchd = mod.LoCoHD(CATS, mod.WeightFunction("uniform", [3.0, 10.0]))
+        return np.asarray(lchd.from_primitives(prims(mod, sa, xa), prims(mod, sb, xb), anchors, 10.0))
+
+    got, want = both(lh, oracle, run)
+    assert np.array_equal(np.argsort(got, kind="stable"), np.argsort(want, kind="stable")) or np.max(np.abs(got - want)) < TIGHT
+    assert np.max(np.abs(got - want)) < TIGHT
+
+
+def test_large_environments_retry(lh, oracle):
+    """Dense cloud: environments of ~1500 points overflow the default LDS capacity and trigger the retry."""
+    rng = np.random.default_rng(18)
+    sa, xa = cloud(rng, 3000, box=10.0)
+    sb, xb = cloud(rng, 2500, box=10.0)
+    anchors = [(int(i), int(j)) for i, j in zip(rng.integers(0, 3000, 64), rng.integers(0, 2500, 64))]
+
+    def run(mod):
+        lchd = mod.LoCoHD(CATS, mod.WeightFunction("hyper_exp", [1.0, 0.15]))
+        return np.asarray(lchd.from_primitives(prims(mod, sa, xa), prims(mod, sb, xb), anchors, 9.0))
+
+    got, want = both(lh, oracle, run)
+    assert np.max(np.abs(got - want)) < TIGHT
+
+
+def test_many_categories(lh, oracle):
+    rng = np.random.default_rng(19)
+    for ncat in (1, 8, 9, 16, 17, 25, 32):
+        cats = [f"c{i}" for i in range(ncat)]
+        sa, xa = cloud(rng, 300, box=12.0, cats=cats)
+        sb, xb = cloud(rng, 300, box=12.0, cats=cats)
+        anchors = [(i, i) for i in range(300)]
+
+        def run(mod):
+            lchd = mod.LoCoHD(cats, mod.WeightFunction("hyper_exp", [1.0, 0.1]))
+            return np.asarray(lchd.from_primitives(prims(mod, sa, xa), prims(mod, sb, xb), anchors, 10.0))
+
+        got, want = both(lh, oracle, run)
+        assert np.max(np.abs(got - want)) < TIGHT, ncat
+
+
+def test_error_behaviour(lh):
+    lchd = lh.LoCoHD(["A", "B"], lh.WeightFunction("uniform", [0.0, 4.0]))
+    with pytest.raises(ValueError):  # src/locohd.rs:70-73
+        lchd.from_anchors(["A", "B"], ["A"], [0.0], [0.0])
+    with pytest.raises(ValueError):  # :74-77
+        lchd.from_anchors(["A", "B"], ["A"], [0.5, 1.0], [0.0])
+    with pytest.raises(ValueError):  # pmf.rs:38-42 unknown category
+        lchd.from_anchors(["A", "Z"], ["A"], [0.0, 1.0], [0.0])
+    with pytest.raises(ValueError):  # :276-281 key given for a single weight function
+        lchd.from_anchors(["A"], ["A"], [0.0], [0.0], "k")
+    with pytest.raises(ValueError):  # empty anchor list is the 3-tuple variant (:34-40)
+        lchd.from_primitives([], [], [], 5.0)
+    p = [lh.PrimitiveAtom("A", "", [0.0, 0.0, 0.0]), lh.PrimitiveAtom("Z", "", [1.0, 0.0, 0.0])]
+    with pytest.raises(ValueError):  # unknown category inside an environment
+        lchd.from_primitives(p, p, [(0, 0)], 5.0)
+    assert lchd.from_primitives(p, p, [(0, 0)], 0.5) == [0.0]  # ...but not when it is outside every environment
+    with pytest.raises(lh.PanicException):  # anchor out of range (:521)
+        lchd.from_primitives(p, p, [(0, 2)], 5.0)
+    with pytest.raises(lh.PanicException):  # non-positive threshold => empty environments (:74)
+        lchd.from_primitives(p, p, [(0, 0)], 0.0)
+    with pytest.raises(ValueError):  # :420-428
+        lchd.from_dmxs(["A"], ["A"], [[0.0]], [[0.0], [0.0]])
+    with pytest.raises(ValueError):  # row without a zero: dists[0] != 0 (collapsed message, :448-452)
+        lchd.from_dmxs(["A", "B"], ["A", "B"], [[1.0, 2.0]], [[0.0, 1.0]])
+    multi = lh.LoCoHD(["A", "B"], {"x": lh.WeightFunction("uniform", [0.0, 4.0])})
+    assert multi.from_primitives(p[:1], p[:1], [], 5.0) == []
+    with pytest.raises(ValueError):
+        multi.from_primitives(p[:1], p[:1], [(0, 0, "nope")], 5.0)
+    assert multi.from_primitives(p[:1], p[:1], [(0, 0, "x")], 5.0) == [0.0]
