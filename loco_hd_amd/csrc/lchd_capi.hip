@@ -139,6 +139,7 @@ struct lchd_ctx {
     hipStream_t stream = nullptr;
     // configuration
     bool cfg_set = false;
+    bool hellinger2 = false, unit_weights = false;  // which sweep kernel variant applies
     DevConfig h_cfg{};
     DevConfig* d_cfg = nullptr;
     char* d_blob = nullptr;
@@ -149,6 +150,7 @@ struct lchd_ctx {
     DeviceStatus* d_status = nullptr;
     DeviceStatus* h_status = nullptr;  // pinned
     unsigned long long* d_points = nullptr;
+    double* d_tabs = nullptr;  // sqrt(k) | 1/sqrt(k), 65536 entries each
     int cap_hint = 512;
     // timing
     bool timing = false;
@@ -199,6 +201,9 @@ extern "C" int lchd_ctx_create(int32_t device, lchd_ctx** out) {
     HIP_TRY(hipMalloc(&c->d_status, sizeof(DeviceStatus)));
     HIP_TRY(hipMalloc(&c->d_points, sizeof(unsigned long long)));
     HIP_TRY(hipHostMalloc(&c->h_status, sizeof(DeviceStatus)));
+    HIP_TRY(hipMalloc(&c->d_tabs, sizeof(double) * 2 * 65536));
+    launch_fill_sqrt_tables(c->stream, c->d_tabs, c->d_tabs + 65536);
+    HIP_TRY(hipStreamSynchronize(c->stream));
     for (auto& ev : c->ev) HIP_TRY(hipEventCreate(&ev));
     *out = c;
     return LCHD_OK;
@@ -212,6 +217,7 @@ extern "C" void lchd_ctx_destroy(lchd_ctx* c) {
     (void)hipFree(c->d_cfg);
     (void)hipFree(c->d_status);
     (void)hipFree(c->d_points);
+    (void)hipFree(c->d_tabs);
     (void)hipHostFree(c->h_status);
     for (auto& ev : c->ev) (void)hipEventDestroy(ev);
     delete c;
@@ -301,6 +307,8 @@ extern "C" int lchd_ctx_set_config(lchd_ctx* c, const lchd_config* cfg) {
     h.tag_pairs = reinterpret_cast<const uint64_t*>(c->d_blob + o_t);
     HIP_TRY(hipMemcpy(c->d_cfg, &h, sizeof h, hipMemcpyHostToDevice));
     c->h_cfg = h;
+    c->hellinger2 = (cfg->sd_kind == LCHD_SD_HELLINGER && cfg->sd_params[0] == 2.0);
+    c->unit_weights = std::all_of(cfg->category_weights, cfg->category_weights + C, [](double v) { return v == 1.0; });
     c->cfg_set = true;
     return LCHD_OK;
 }
@@ -555,7 +563,9 @@ extern "C" int lchd_from_primitives_dev(lchd_ctx* c, lchd_cloud* a, lchd_cloud* 
         sw.n_pairs = n_pairs;
         sw.out = d_out;
         sw.st = c->d_status;
-        launch_sweep(s, c->h_cfg.n_categories, sw);
+        sw.sqrt_tab = c->d_tabs;
+        sw.rsqrt_tab = c->d_tabs + 65536;
+        launch_sweep(s, c->h_cfg.n_categories, c->hellinger2, c->unit_weights, sw);
         mark(c, 4);
         HIP_TRY(hipGetLastError());
         if (int rc = read_status(c)) return rc;
@@ -634,7 +644,9 @@ static int sweep_rows(lchd_ctx* c, const EnvStore& ea, const EnvStore& eb, const
     sw.n_pairs = rows;
     sw.out = d_out;
     sw.st = c->d_status;
-    launch_sweep(c->stream, c->h_cfg.n_categories, sw);
+    sw.sqrt_tab = c->d_tabs;
+    sw.rsqrt_tab = c->d_tabs + 65536;
+    launch_sweep(c->stream, c->h_cfg.n_categories, c->hellinger2, c->unit_weights, sw);
     mark(c, 4);
     HIP_TRY(hipGetLastError());
     if (int rc = read_status(c)) return rc;
