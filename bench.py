@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- anchor-pair LoCoHD scores/s on MI355X (BASELINE.json metric), one JSON line on rank 0.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+Workload (SURVEY.md section 8d, config C2a = BASELINE.json configs[1]): two 10 000-atom random clouds at
+protein-like density 0.05 atoms/A^3 (box side 58.5 A), 10 primitive categories, hyper_exp[1.0, 0.1] weight
+function, Hellinger-2, from_primitives semantics with threshold 10 A, P = 10^6 anchor pairs per GPU:
+pair k = (k mod N, perm_r(k mod N)) with r = k div N and perm_r a seeded permutation (round 0 = identity), so
+every one of the 10^4 atoms of each cloud is an anchor ~100 times.  Coordinates, categories and anchor pairs
+are resident in HBM before the timed region; ONE STEP = one full pass of the hot path over that batch:
+cell lists for both clouds, anchor de-duplication, environment build (radius search + f64 distances + sort),
+merge sweep (Hellinger + CDF + reduction), status read-back.  Nothing is cached across steps.
+
+Multi-GPU (weak scaling): every rank holds both clouds and its own 10^6 pairs (different permutation
+rounds); the per-rank score vectors are gathered to rank 0 over RCCL inside the timed step.
+
+The JSON line also carries:
+  roofline      dominant kernel's ALGORITHMIC bytes per launch (B_pair = (n_A+n_B)*28 + 16)
+                / its average launch duration (HIP events on the launch stream, recorded by the C library)
+                against the 8 TB/s HBM peak.
+  cpu_baseline  the CPU oracle (C restatement of the reference algorithm, kind "port": the Rust reference
+                cannot be built here) timed on this host's cores on a bounded sample of the same pairs;
+                the same sample is the parity gate (max |gpu - cpu| must be <= 1e-6).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def make_workload(name: str, rank: int, n_pairs: int):
+    """Synthetic inputs of SURVEY.md 8(d).  Returns dict(xyz_a, xyz_b, cat_a, cat_b, pairs, thr, C, wf, label)."""
+    if name == "c2a":
+        n, c, seed, thr = 10_000, 10, 2, 10.0
+        rounds = max(1, n_pairs // n)
+    elif name == "c5":  # stress: two 200k-point clouds, 25 categories, random anchor pairs
+        n, c, seed, thr = 200_000, 25, 5, 10.0
+        rounds = 0
+    else:
+        raise SystemExit(f"unknown workload {name}")
+    rng = np.random.default_rng(seed)
+    side = (n / 0.05) ** (1.0 / 3.0)
+    xyz_a, xyz_b = rng.uniform(0.0, side, (n, 3)), rng.uniform(0.0, side, (n, 3))
+    cat_a, cat_b = rng.integers(0, c, n).astype(np.int32), rng.integers(0, c, n).astype(np.int32)
+    prng = np.random.default_rng(1000 * seed + rank)  # every rank scores different pairs of the same clouds
+    if rounds:
+        idx = np.arange(n, dtype=np.int64)
+        cols = []
+        for r in range(rounds):
+            perm = idx if (r == 0 and rank == 0) else prng.permutation(n)
+            cols.append(np.stack([idx, perm], 1))
+        pairs = np.concatenate(cols, 0)[:n_pairs]
+        label = (f"C2a: 2x{n}-atom random clouds (0.05 atoms/A^3), {c} categories, hyper_exp[1,0.1], Hellinger-2, "
+                 f"from_primitives thr {thr:g} A, {len(pairs)} anchor pairs/GPU = {rounds} permutation rounds over all atoms")
+    else:
+        pairs = np.stack([prng.integers(0, n, n_pairs), prng.integers(0, n, n_pairs)], 1).astype(np.int64)
+        label = f"C5: 2x{n}-point clouds, {c} categories, hyper_exp[1,0.1], {n_pairs} random anchor pairs/GPU, thr {thr:g} A"
+    return dict(xyz_a=xyz_a, xyz_b=xyz_b, cat_a=cat_a, cat_b=cat_b, pairs=np.ascontiguousarray(pairs), thr=thr, C=c,
+                wf=("hyper_exp", [1.0, 0.1]), label=label, n=n)
+
+
+def cpu_baseline(w, gpu_scores: np.ndarray, budget_s: float = 12.0):
+    """Time the CPU oracle on a bounded prefix of the same pairs (all host cores) and use it as the parity gate."""
+    from oracle import oracle as orc  # checker / baseline only
+
+    cores = os.cpu_count() or 1
+    lchd = orc.LoCoHD([f"c{i}" for i in range(w["C"])], orc.WeightFunction(*w["wf"]), n_of_threads=cores)
+    tag = np.zeros(w["n"], dtype=np.int32)
+
+    def run(m):
+        t0 = time.perf_counter()
+        out = lchd.from_arrays(w["xyz_a"], w["cat_a"], tag, w["xyz_b"], w["cat_b"], tag, w["pairs"][:m], w["thr"])
+        return np.asarray(out), time.perf_counter() - t0
+
+    probe = min(len(w["pairs"]), 500 * cores)
+    _, dt = run(probe)
+    rate = probe / max(dt, 1e-9)
+    m = int(min(len(w["pairs"]), max(10_000, rate * budget_s)))
+    ref, dt = run(m)
+    err = float(np.max(np.abs(ref - gpu_scores[:m])))
+    return {"value": m / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"first {m} anchor pairs of the same workload, {dt:.1f} s, C oracle (oracle/locohd_oracle.c) with "
+                      f"{cores} pthreads over anchor pairs; reference Rust core not buildable in this image"}, err, m
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c2a", choices=["c2a", "c5"])
+    ap.add_argument("--pairs", type=int, default=1_000_000, help="anchor pairs per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import loco_hd_amd as lh
+    from loco_hd_amd.device import DeviceSession
+    from loco_hd_amd.dist import gather_scores
+
+    w = make_workload(args.workload, rank, args.pairs)
+    lchd = lh.LoCoHD([f"c{i}" for i in range(w["C"])], lh.WeightFunction(*w["wf"]))
+    sess = DeviceSession(lchd, device=local_rank)
+    cloud_a = sess.upload(w["xyz_a"], w["cat_a"])
+    cloud_b = sess.upload(w["xyz_b"], w["cat_b"])
+    anchors = torch.from_numpy(w["pairs"]).to(dev)
+    p = anchors.shape[0]
+    out = torch.empty(p, dtype=torch.float64, device=dev)
+    gathered = torch.empty(p * world, dtype=torch.float64, device=dev) if (world > 1 and rank == 0) else None
+    sess.enable_timing(True)
+
+    def step():
+        sess.from_primitives(cloud_a, cloud_b, anchors, w["thr"], out=out)
+        if world > 1:
+            gather_scores(out, gathered, world, rank)
+
+    phase_ms = {"cells": 0.0, "anchors": 0.0, "env": 0.0, "sweep": 0.0}
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        for k, v in sess.last_ms().items():
+            phase_ms[k] += v
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    phase_ms = {k: v / max(args.steps, 1) for k, v in phase_ms.items()}
+    env_points = sess.last_env_points()  # sum over this rank's pairs of n_A + n_B
+    scores = out.cpu().numpy()
+
+    if rank == 0:
+        algo_bytes = env_points * 28 + 16 * p  # B_pair = (n_A + n_B) * 28 B + 8 B + 8 B
+        dom = max(("env", "sweep"), key=lambda k: phase_ms[k])
+        dom_name = {"env": "k_env_cells (2 launches: side A + side B)", "sweep": "k_sweep"}[dom]
+        achieved = algo_bytes / (phase_ms[dom] * 1e-3) / 1e9
+        result = {
+            "metric": "anchor-pair LoCoHD scores/sec",
+            "value": p * world * args.steps / elapsed,
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": w["label"], "pairs_per_gpu": p, "mean_env_points_per_pair": env_points / p},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": dom_name,
+                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": phase_ms[dom]},
+            "kernel_ms": phase_ms,
+        }
+        if not args.no_cpu_baseline:
+            base, err, m = cpu_baseline(w, scores)
+            result["cpu_baseline"] = base
+            result["max_abs_err_vs_cpu"] = err
+            result["parity_sample_pairs"] = m
+            if not (err <= 1e-6):
+                result["parity_failed"] = True
+        print(json.dumps(result), flush=True)
+        if result.get("parity_failed"):
+            sys.exit(3)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    sess.close()
+
+
+if __name__ == "__main__":
+    main()
