@@ -139,7 +139,7 @@ struct lchd_ctx {
     hipStream_t stream = nullptr;
     // configuration
     bool cfg_set = false;
-    bool hellinger2 = false, unit_weights = false;  // which sweep kernel variant applies
+    bool hellinger2 = false, unit_weights = false, wf_pow = false;  // which sweep kernel variant applies
     DevConfig h_cfg{};
     DevConfig* d_cfg = nullptr;
     char* d_blob = nullptr;
@@ -309,6 +309,10 @@ extern "C" int lchd_ctx_set_config(lchd_ctx* c, const lchd_config* cfg) {
     c->h_cfg = h;
     c->hellinger2 = (cfg->sd_kind == LCHD_SD_HELLINGER && cfg->sd_params[0] == 2.0);
     c->unit_weights = std::all_of(cfg->category_weights, cfg->category_weights + C, [](double v) { return v == 1.0; });
+    c->wf_pow = false;
+    for (int i = 0; i < cfg->n_weight_functions; ++i)
+        c->wf_pow = c->wf_pow || cfg->weight_functions[i].kind == LCHD_WF_DAGUM || cfg->weight_functions[i].kind == LCHD_WF_KUMARASWAMY ||
+                    (cfg->weight_functions[i].kind == LCHD_WF_HYPER_EXP && cfg->weight_functions[i].n_params > 8);  // not register-resident
     c->cfg_set = true;
     return LCHD_OK;
 }
@@ -565,7 +569,7 @@ extern "C" int lchd_from_primitives_dev(lchd_ctx* c, lchd_cloud* a, lchd_cloud* 
         sw.st = c->d_status;
         sw.sqrt_tab = c->d_tabs;
         sw.rsqrt_tab = c->d_tabs + 65536;
-        launch_sweep(s, c->h_cfg.n_categories, c->hellinger2, c->unit_weights, sw);
+        launch_sweep(s, c->h_cfg.n_categories, c->hellinger2, c->unit_weights, c->wf_pow, sw);
         mark(c, 4);
         HIP_TRY(hipGetLastError());
         if (int rc = read_status(c)) return rc;
@@ -646,7 +650,7 @@ static int sweep_rows(lchd_ctx* c, const EnvStore& ea, const EnvStore& eb, const
     sw.st = c->d_status;
     sw.sqrt_tab = c->d_tabs;
     sw.rsqrt_tab = c->d_tabs + 65536;
-    launch_sweep(c->stream, c->h_cfg.n_categories, c->hellinger2, c->unit_weights, sw);
+    launch_sweep(c->stream, c->h_cfg.n_categories, c->hellinger2, c->unit_weights, c->wf_pow, sw);
     mark(c, 4);
     HIP_TRY(hipGetLastError());
     if (int rc = read_status(c)) return rc;

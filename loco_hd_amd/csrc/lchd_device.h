@@ -105,7 +105,7 @@ struct SweepArgs {
     const double* sqrt_tab;   // [65536] sqrt(k), context-owned
     const double* rsqrt_tab;  // [65536] 1/sqrt(k)
 };
-void launch_sweep(hipStream_t s, int n_categories, bool hellinger2, bool unit_weights, const SweepArgs& a);
+void launch_sweep(hipStream_t s, int n_categories, bool hellinger2, bool unit_weights, bool wf_pow, const SweepArgs& a);
 void launch_fill_sqrt_tables(hipStream_t s, double* sqrt_tab, double* rsqrt_tab);  // 65536 entries each
 void launch_env_points(hipStream_t s, const SweepArgs& a, unsigned long long* out);
 

@@ -435,10 +435,49 @@ __device__ __forceinline__ uint64_t spread4(uint64_t x) {
 
 // hyper_exp and uniform are the common weight functions and stay inline; the pow-based CDFs are called.
 __device__ __noinline__ double cdf_pow_based(int kind, const double* p, int np, double x) { return cdf_eval(kind, p, np, x); }
-__device__ __forceinline__ double cdf_dev(int kind, const double* p, int np, double x) {
-    if (kind == WF_HYPER_EXP) return cdf_hyper_exp(p, np, x);
-    if (kind == WF_UNIFORM) return cdf_uniform(p, x);
-    return cdf_pow_based(kind, p, np, x);
+// One pair's weight function.  hyper_exp with <= 4 terms and uniform keep their parameters in (scalar)
+// registers; everything else goes through the out-of-line evaluator with the parameter pointer.
+struct WfRegs {
+    int kind, np, nterm;
+    bool fast;
+    double a[4], b[4];
+    const double* p;
+};
+__device__ __forceinline__ WfRegs wf_load(const WfEntry& e, const double* p) {
+    WfRegs w;
+    w.kind = e.kind;
+    w.np = e.n_params;
+    w.nterm = e.n_params / 2;
+    w.p = p;
+    w.fast = (e.kind == WF_UNIFORM) || (e.kind == WF_HYPER_EXP && w.nterm <= 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { w.a[i] = 0.0; w.b[i] = 0.0; }
+    if (e.kind == WF_UNIFORM) { w.a[0] = p[0]; w.a[1] = p[1]; }
+    else if (w.fast) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (i < w.nterm) { w.a[i] = p[i]; w.b[i] = p[w.nterm + i]; }
+    }
+    return w;
+}
+template <bool WFANY>
+__device__ __forceinline__ double cdf_dev(const WfRegs& w, double x) {
+    if (w.kind == WF_UNIFORM) {  // cdfs.rs:39-45
+        if (x < w.a[0]) return 0.0;
+        if (x > w.a[1]) return 1.0;
+        return (x - w.a[0]) / (w.a[1] - w.a[0]);
+    }
+    if (w.fast) {  // cdfs.rs:5-21, same accumulation order
+        double norm = 0.0, sum = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < w.nterm) {
+                sum += w.a[i] * exp(-w.b[i] * x);
+                norm += w.a[i];
+            }
+        return 1.0 - sum / norm;
+    }
+    if constexpr (WFANY) return cdf_pow_based(w.kind, w.p, w.np, x);
+    else return 0.0;  // unreachable: the host routes tables with other weight functions to the WFANY build
 }
 
 // StatisticalDistance::run for the non-default distances; out of line so that the sweep kernel stays small.
@@ -446,7 +485,7 @@ __device__ __noinline__ double sd_generic(int kind, double p0, double p1, const 
     return sd_eval<0>(kind, p0, p1, [&](int c) { return p[c]; }, [&](int c) { return q[c]; }, C);
 }
 
-template <int CMAX, int MODE>
+template <int CMAX, int MODE, bool WFANY>
 __global__ __launch_bounds__(256) void k_sweep(SweepArgs args) {
     constexpr int EPL = kSweepEPL, TILE = kSweepTile;
     constexpr int NW = CMAX / 4;          // u64 words of 16-bit count fields per side
@@ -456,7 +495,8 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs args) {
     __shared__ double w_s[32], sw_s[32];
     __shared__ uint64_t sA_[4][TILE], sB_[4][TILE];
     __shared__ uint8_t cA_[4][TILE], cB_[4][TILE];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform => everything derived from it stays scalar
     const DevConfig cfg = *args.cfg;
     const int C = cfg.n_categories;
     const double* __restrict__ g_sqrt_in = args.sqrt_tab;
@@ -513,8 +553,8 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs args) {
             if (lane == 0) { atomicOr(&args.st->flags, ST_BAD_WF); args.out[p] = nan(""); }
             continue;
         }
-        const WfEntry wf = cfg.wf[wfi];
-        const double* wp = cfg.wf_params + wf.offset;
+        const WfEntry wfe = cfg.wf[wfi];
+        const WfRegs wf = wf_load(wfe, cfg.wf_params + wfe.offset);
         if (kA[0] != 0ull || kB[0] != 0ull) {  // src/locohd.rs:74-77
             if (lane == 0) { atomicOr(&args.st->flags, ST_FIRST_NOT_ZERO); args.out[p] = nan(""); }
             continue;
@@ -588,7 +628,7 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs args) {
         for (int k = 0; k < NW; ++k) { exA[k] = cntA[k]; exB[k] = cntB[k]; }
         totA = totB = 1;
         load_state();
-        double F_carry = cdf_dev(wf.kind, wp, wf.n_params, 0.0);
+        double F_carry = cdf_dev<WFANY>(wf, 0.0);
         double H_carry = bad_cat ? 0.0 : distance();
         double acc = 0.0;
 
@@ -602,7 +642,8 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs args) {
             for (int t = lane; t < nBt; t += 64) { sB[t] = kB[1 + ib + t]; cB[t] = tB[1 + ib + t]; }
             wave_sync_lds();
             // lane l owns merged events [d0, d1); each lane searches the END of its chunk
-            const int d0 = min(lane * EPL, T), d1 = min(d0 + EPL, T);
+            const int epl = (T + 63) >> 6;  // <= EPL (= 8): the 4-bit histogram fields hold up to 15
+            const int d0 = min(lane * epl, T), d1 = min(d0 + epl, T);
             const int i1 = merge_path(sA, nAt, sB, nBt, d1);
             int i0 = __shfl_up(i1, 1);
             if (lane == 0) i0 = 0;
@@ -648,14 +689,14 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs args) {
             // pass 2: sequential sweep of this lane's events
             int i = i0, j = j0;
             double Fp = 0.0, Hp = 0.0, firstF = 0.0, local = 0.0;
-            for (int e = 0; e < EPL; ++e) {
+            for (int e = 0; e < epl; ++e) {
                 if (d0 + e < d1) {
                     const bool takeA = (i < i1) && (j >= j1 || sA[i] <= sB[j]);
                     const uint64_t kb = takeA ? sA[i] : sB[j];
                     const int ct = takeA ? cA[i] : cB[j];
                     i += takeA ? 1 : 0;
                     j += takeA ? 0 : 1;
-                    const double F = cdf_dev(wf.kind, wp, wf.n_params, u2d(kb));
+                    const double F = cdf_dev<WFANY>(wf, u2d(kb));
                     if (e == 0) firstF = F; else local += (F - Fp) * Hp;
                     // pmf.rs:47-63: one more point of category ct on one side
                     const uint64_t inc = 1ull << ((ct & 3) * 16);
@@ -698,7 +739,7 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs args) {
             if (lane == 0) { prevF = F_carry; prevH = H_carry; }
             if (d0 < d1) local += (firstF - prevF) * prevH;
             acc += local;
-            const int last = (T - 1) / EPL;
+            const int last = (T - 1) / epl;
             F_carry = shfl_f64(Fp, last);
             H_carry = shfl_f64(Hp, last);
             ia += iend;
@@ -707,7 +748,7 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs args) {
         // wave64 butterfly reduction + the last interval to +inf (:165-171,204-210,212-221)
 #pragma unroll
         for (int m = 32; m > 0; m >>= 1) acc += shfl_xor_f64(acc, m);
-        const double Finf = cdf_dev(wf.kind, wp, wf.n_params, (double)INFINITY);
+        const double Finf = cdf_dev<WFANY>(wf, (double)INFINITY);
         acc += (Finf - F_carry) * H_carry;
         const unsigned long long anybad = __ballot(bad_cat), anyzero = __ballot(zero_norm);
         if (lane == 0) {
@@ -718,23 +759,26 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs args) {
     }
 }
 
-template <int MODE>
+template <int MODE, bool WFANY>
 static void launch_sweep_mode(hipStream_t s, int cmax, unsigned grid, const SweepArgs& a) {
-    if (cmax <= 8) k_sweep<8, MODE><<<grid, 256, 0, s>>>(a);
-    else if (cmax <= 16) k_sweep<16, MODE><<<grid, 256, 0, s>>>(a);
-    else k_sweep<32, MODE><<<grid, 256, 0, s>>>(a);
+    if (cmax <= 8) k_sweep<8, MODE, WFANY><<<grid, 256, 0, s>>>(a);
+    else if (cmax <= 12) k_sweep<12, MODE, WFANY><<<grid, 256, 0, s>>>(a);
+    else if (cmax <= 16) k_sweep<16, MODE, WFANY><<<grid, 256, 0, s>>>(a);
+    else if (cmax <= 24) k_sweep<24, MODE, WFANY><<<grid, 256, 0, s>>>(a);
+    else k_sweep<32, MODE, WFANY><<<grid, 256, 0, s>>>(a);
 }
 
-void launch_sweep(hipStream_t s, int n_categories, bool hellinger2, bool unit_weights, const SweepArgs& a) {
+void launch_sweep(hipStream_t s, int n_categories, bool hellinger2, bool unit_weights, bool wf_pow, const SweepArgs& a) {
     if (a.n_pairs <= 0) return;
     const int64_t blocks = (a.n_pairs + 3) / 4;
     const unsigned grid = (unsigned)(blocks < 4096 ? blocks : 4096);  // grid-stride: LDS tables are built once per block
     int cmax = n_categories;
     if (const char* f = getenv("LCHD_FORCE_CMAX")) cmax = atoi(f) > cmax ? atoi(f) : cmax;  // test hook
     if (const char* f = getenv("LCHD_FORCE_GENERIC")) hellinger2 = hellinger2 && atoi(f) == 0;  // test hook
-    if (!hellinger2) launch_sweep_mode<MODE_GEN>(s, cmax, grid, a);
-    else if (unit_weights) launch_sweep_mode<MODE_H2U>(s, cmax, grid, a);
-    else launch_sweep_mode<MODE_H2W>(s, cmax, grid, a);
+    if (!hellinger2) launch_sweep_mode<MODE_GEN, true>(s, cmax, grid, a);
+    else if (unit_weights && !wf_pow) launch_sweep_mode<MODE_H2U, false>(s, cmax, grid, a);
+    else if (unit_weights) launch_sweep_mode<MODE_H2U, true>(s, cmax, grid, a);
+    else launch_sweep_mode<MODE_H2W, true>(s, cmax, grid, a);
 }
 
 
