@@ -8,10 +8,11 @@ entry point fails loudly -- there is no Python/CPU fallback for the scoring path
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "libloco_hd_hip.so"
+LIB_PATH = Path(os.environ["LCHD_LIB"]) if os.environ.get("LCHD_LIB") else _PKG / "libloco_hd_hip.so"  # LCHD_LIB: tuning builds
 
 OK, EVALUE, EPANIC, EDEVICE, EUNSUPPORTED = 0, 1, 2, 3, 4
 

@@ -7,7 +7,7 @@
 namespace lchd {
 
 constexpr int kMaxCategories = 255;   // categories travel as u8 on the device
-constexpr int kSweepEPL = 8;          // merged events per lane per tile in the sweep kernel
+constexpr int kSweepEPL = 6;          // merged events per lane per tile in the sweep kernel
 constexpr int kSweepTile = 64 * kSweepEPL;
 constexpr uint64_t kPadKey = ~0ull;   // sorts after every valid (non-negative, non-NaN) f64 bit pattern
 

@@ -384,7 +384,7 @@ bool launch_env_rows(hipStream_t s, int cap, const DevConfig* cfg, const CloudVi
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2: the sweep.  One wavefront per anchor pair, four pairs per 256-thread workgroup.
+// K2: the sweep.  One wavefront per anchor pair, eight pairs per 512-thread workgroup.
 //
 // S = sum_k [F(t_{k+1}) - F(t_k)] * H(state after k events), t_0 = 0, t_{M+1} = inf, where the events are
 // the merged non-anchor points of both environments (the reference's two-pointer
@@ -397,15 +397,23 @@ bool launch_env_rows(hipStream_t s, int cap, const DevConfig* cfg, const CloudVi
 // walks its 8 events sequentially with the per-category state in registers.
 //
 // MODE_H2U / MODE_H2W: Hellinger distance with exponent 2 (the default, src/locohd.rs:365-370), unit /
-//   arbitrary category weights.  H = sqrt(1/2 sum_c (sqrt(a_c/N_a) - sqrt(b_c/N_b))^2) is evaluated as
-//   sqrt(a_c) * (1/sqrt(N_a)) with sqrt(a_c) cached per category (only the changed category is refreshed,
-//   from an LDS table of sqrt(k)); the literal difference-of-roots form is kept so that identical
-//   environments give exactly 0 (the cancellation form 1 - BC does not).
+//   arbitrary category weights.  The per-lane state is just the packed integer category counts plus the
+//   running Bhattacharyya numerator D = sum_c sqrt(a_c b_c); an event touches one category, so D is updated
+//   in O(1) from an LDS table of sqrt(k) and H^2 = 1 - D / sqrt(N_a N_b).  Where that cancellation form would
+//   lose accuracy (H^2 < 1e-3) the literal sum_c (sqrt(a_c/N_a) - sqrt(b_c/N_b))^2 / 2 is evaluated instead,
+//   which also gives exactly 0 for identical environments.
 // MODE_GEN: every other StatisticalDistance (statistical_distances.rs:4-78): weighted counts in registers,
 //   normalised like pmf.rs:65-83, distance through one out-of-line call.
 // ------------------------------------------------------------------------------------------------
 enum { MODE_H2U = 0, MODE_H2W = 1, MODE_GEN = 2 };
-constexpr int kSqrtTab = 1024;
+#ifndef LCHD_SWEEP_WAVES
+#define LCHD_SWEEP_WAVES 4
+#endif
+#ifndef LCHD_SWEEP_MINW
+#define LCHD_SWEEP_MINW 2
+#endif
+constexpr int kSqrtTab = 512;  // LDSTAB kernels: environments of at most 512 points, sqrt tables entirely in LDS
+constexpr int kSweepWaves = LCHD_SWEEP_WAVES;  // anchor pairs (wavefronts) per workgroup
 
 __device__ __forceinline__ void wave_sync_lds() {
     // LDS operations of one wavefront execute in issue order; this only stops the compiler from moving
@@ -423,6 +431,28 @@ __device__ __forceinline__ int merge_path(const uint64_t* A, int nA, const uint6
         if (A[mid] <= B[d - 1 - mid]) lo = mid + 1; else hi = mid;
     }
     return lo;
+}
+
+// Inclusive prefix sum across the 64 lanes with DPP adds (row_shr 1/2/4/8 inside each row of 16 lanes, then the
+// two row broadcasts): 6 VALU instructions, no LDS crossbar traffic.  Lanes without a source add the identity 0.
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x) {
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return (uint32_t)v;
+}
+// 16-bit count fields never carry into each other (every count < 65536), so a u64 of four fields scans as two u32
+__device__ __forceinline__ uint64_t wave_incl_scan_fields(uint64_t x) {
+    const uint32_t lo = wave_incl_scan_u32((uint32_t)x), hi = wave_incl_scan_u32((uint32_t)(x >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
+    const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, l), hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
 }
 
 // spread the four 4-bit fields of the low 16 bits of x into four 16-bit fields
@@ -485,28 +515,31 @@ __device__ __noinline__ double sd_generic(int kind, double p0, double p1, const 
     return sd_eval<0>(kind, p0, p1, [&](int c) { return p[c]; }, [&](int c) { return q[c]; }, C);
 }
 
-template <int CMAX, int MODE, bool WFANY>
-__global__ __launch_bounds__(256) void k_sweep(SweepArgs args) {
-    constexpr int EPL = kSweepEPL, TILE = kSweepTile;
+template <int CMAX, int MODE, bool WFANY, bool LDSTAB>
+__global__ __launch_bounds__(64 * kSweepWaves, LCHD_SWEEP_MINW) void k_sweep(SweepArgs args) {
+    constexpr int EPL = kSweepEPL, TILE = kSweepTile, WPB = kSweepWaves;
     constexpr int NW = CMAX / 4;          // u64 words of 16-bit count fields per side
     constexpr int NH = (CMAX + 15) / 16;  // u64 words of 4-bit histogram fields per side
     constexpr bool H2 = (MODE != MODE_GEN);
-    __shared__ double t_sqrt[kSqrtTab], t_rsqrt[kSqrtTab];
+    constexpr int NV = H2 ? 1 : CMAX;     // only the generic path keeps per-category values in registers
+    constexpr int NT = LDSTAB ? kSqrtTab + 8 : 1;  // sqrt(k), 1/sqrt(k) for k <= 512 in LDS; otherwise read from the global tables
+    __shared__ double t_sqrt[NT], t_rsqrt[NT];
     __shared__ double w_s[32], sw_s[32];
-    __shared__ uint64_t sA_[4][TILE], sB_[4][TILE];
-    __shared__ uint8_t cA_[4][TILE], cB_[4][TILE];
+    __shared__ uint64_t sA_[WPB][TILE], sB_[WPB][TILE];
+    __shared__ uint8_t cA_[WPB][TILE], cB_[WPB][TILE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform => everything derived from it stays scalar
-    const DevConfig cfg = *args.cfg;
-    const int C = cfg.n_categories;
-    const double* __restrict__ g_sqrt_in = args.sqrt_tab;
-    const double* __restrict__ g_rsqrt_in = args.rsqrt_tab;
-    for (int k = tid; k < kSqrtTab; k += 256) {
-        t_sqrt[k] = g_sqrt_in[k];
-        t_rsqrt[k] = g_rsqrt_in[k];
-    }
+    const DevConfig* __restrict__ cfgp = args.cfg;
+    const int C = cfgp->n_categories;
+    const double* __restrict__ g_sqrt = args.sqrt_tab;    // [65536] sqrt(k)
+    const double* __restrict__ g_rsqrt = args.rsqrt_tab;  // [65536] 1/sqrt(k)
+    if constexpr (LDSTAB)
+        for (int k = tid; k < NT; k += 64 * WPB) {
+            t_sqrt[k] = g_sqrt[k];
+            t_rsqrt[k] = g_rsqrt[k];
+        }
     if (tid < 32) {
-        const double wv_ = tid < C ? cfg.cat_w[tid] : 0.0;
+        const double wv_ = tid < C ? cfgp->cat_w[tid] : 0.0;
         w_s[tid] = wv_;
         sw_s[tid] = sqrt(wv_);
     }
@@ -516,18 +549,15 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs args) {
     uint8_t* cA = cA_[wv];
     uint8_t* cB = cB_[wv];
 
-    const double* __restrict__ g_sqrt = args.sqrt_tab;    // [65536] sqrt(k)
-    const double* __restrict__ g_rsqrt = args.rsqrt_tab;  // [65536] 1/sqrt(k)
-    auto sqrt_cnt = [&](int cnt) { return cnt < kSqrtTab ? t_sqrt[cnt] : g_sqrt[cnt]; };
-    auto rsqrt_cnt = [&](int cnt) { return cnt < kSqrtTab ? t_rsqrt[cnt] : g_rsqrt[cnt]; };
-    // per-category register value for an integer count: sqrt(weighted count) (H2) or weighted count (GEN)
-    auto val_of = [&](int c, int cnt) -> double {
-        if constexpr (MODE == MODE_H2U) return sqrt_cnt(cnt);
-        else if constexpr (MODE == MODE_H2W) return sqrt_cnt(cnt) * sw_s[c & 31];
-        else return w_s[c & 31] * (double)cnt;
+    auto sqrt_cnt = [&](int cnt) -> double { if constexpr (LDSTAB) return t_sqrt[cnt]; else return g_sqrt[cnt]; };
+    auto rsqrt_cnt = [&](int cnt) -> double { if constexpr (LDSTAB) return t_rsqrt[cnt]; else return g_rsqrt[cnt]; };
+    // sqrt of the weighted count of category c (c may be dynamic)
+    auto root_of = [&](int c, int cnt) -> double {
+        if constexpr (MODE == MODE_H2W) return sqrt_cnt(cnt) * sw_s[c & 31];
+        else return sqrt_cnt(cnt);
     };
 
-    for (int64_t p = (int64_t)blockIdx.x * 4 + wv; p < args.n_pairs; p += (int64_t)gridDim.x * 4) {
+    for (int64_t p = (int64_t)blockIdx.x * WPB + wv; p < args.n_pairs; p += (int64_t)gridDim.x * WPB) {
         int64_t ea = p, eb = p;
         if (args.anchors) {
             const int64_t ia_ = args.anchors[2 * p], ib_ = args.anchors[2 * p + 1];
@@ -544,17 +574,17 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs args) {
             if (lane == 0) args.out[p] = nan("");
             continue;
         }
-        const uint64_t* kA = args.env_a.key + ea * args.env_a.stride;
-        const uint64_t* kB = args.env_b.key + eb * args.env_b.stride;
-        const uint8_t* tA = args.env_a.cat + ea * args.env_a.stride;
-        const uint8_t* tB = args.env_b.cat + eb * args.env_b.stride;
+        const uint64_t* __restrict__ kA = args.env_a.key + ea * args.env_a.stride;
+        const uint64_t* __restrict__ kB = args.env_b.key + eb * args.env_b.stride;
+        const uint8_t* __restrict__ tA = args.env_a.cat + ea * args.env_a.stride;
+        const uint8_t* __restrict__ tB = args.env_b.cat + eb * args.env_b.stride;
         const int wfi = args.wf_index ? args.wf_index[p] : 0;
-        if (wfi < 0 || wfi >= cfg.n_wf) {
+        if (wfi < 0 || wfi >= cfgp->n_wf) {
             if (lane == 0) { atomicOr(&args.st->flags, ST_BAD_WF); args.out[p] = nan(""); }
             continue;
         }
-        const WfEntry wfe = cfg.wf[wfi];
-        const WfRegs wf = wf_load(wfe, cfg.wf_params + wfe.offset);
+        const WfEntry wfe = cfgp->wf[wfi];
+        const WfRegs wf = wf_load(wfe, cfgp->wf_params + wfe.offset);
         if (kA[0] != 0ull || kB[0] != 0ull) {  // src/locohd.rs:74-77
             if (lane == 0) { atomicOr(&args.st->flags, ST_FIRST_NOT_ZERO); args.out[p] = nan(""); }
             continue;
@@ -563,53 +593,80 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs args) {
         bool bad_cat = false, zero_norm = false;
         // wave-uniform packed integer category counts (16-bit fields), seeded with the two anchors (:82-84)
         uint64_t cntA[NW], cntB[NW];
-#pragma unroll
-        for (int k = 0; k < NW; ++k) cntA[k] = cntB[k] = 0;
         {
             const int c0a = tA[0], c0b = tB[0];
             if (c0a >= C || c0b >= C) bad_cat = true;
 #pragma unroll
             for (int k = 0; k < NW; ++k) {
-                cntA[k] += ((c0a >> 2) == k) ? (1ull << ((c0a & 3) * 16)) : 0ull;
-                cntB[k] += ((c0b >> 2) == k) ? (1ull << ((c0b & 3) * 16)) : 0ull;
+                cntA[k] = ((c0a >> 2) == k) ? (1ull << ((c0a & 3) * 16)) : 0ull;
+                cntB[k] = ((c0b >> 2) == k) ? (1ull << ((c0b & 3) * 16)) : 0ull;
             }
         }
 
-        // per-lane state
-        double va[CMAX], vb[CMAX];   // val_of(category count) for A / B
-        uint64_t exA[NW], exB[NW];   // this lane's packed counts
-        double na = 0.0, nb = 0.0;   // H2U: unused; H2W/GEN: weighted totals
-        int totA = 0, totB = 0;      // points seen (incl. anchor)
+        // ---- per-lane state -------------------------------------------------------------------------
+        uint64_t exA[NW], exB[NW];   // packed category counts at this lane's position
+        int totA = 1, totB = 1;      // points seen per side (incl. anchor)
         double ra = 0.0, rb = 0.0;   // H2: 1/sqrt(total weight)
+        double na = 0.0, nb = 0.0;   // H2W: total weights
+        double D = 0.0;              // H2: sum_c sqrt(a_c * b_c)  (Bhattacharyya numerator)
+        double va[NV], vb[NV];       // GEN: weighted category counts (pmf.rs:16-17)
 
-        auto load_state = [&]() {    // registers <- packed counts exA/exB, totals totA/totB
+        auto field = [&](const uint64_t (&ex)[NW], int c) -> int {  // static c
+            return (int)((ex[c >> 2] >> ((c & 3) * 16)) & 0xFFFFull);
+        };
+        auto load_state = [&]() {  // registers <- packed counts exA/exB and totals totA/totB
+            if constexpr (H2) {
+                D = 0.0;
+                if constexpr (MODE == MODE_H2W) na = nb = 0.0;
 #pragma unroll
-            for (int c = 0; c < CMAX; ++c) {  // padded categories: count 0, weight 0 -> value 0
-                va[c] = val_of(c, (int)((exA[c >> 2] >> ((c & 3) * 16)) & 0xFFFFull));
-                vb[c] = val_of(c, (int)((exB[c >> 2] >> ((c & 3) * 16)) & 0xFFFFull));
-            }
-            if constexpr (MODE == MODE_H2U) {
-                ra = rsqrt_cnt(totA);
-                rb = rsqrt_cnt(totB);
-            } else {
-                na = nb = 0.0;
+                for (int k = 0; k < NW; ++k) {  // padded categories have count 0 on both sides: contribute 0
 #pragma unroll
-                for (int c = 0; c < CMAX; ++c) {
-                    na += w_s[c] * (double)((exA[c >> 2] >> ((c & 3) * 16)) & 0xFFFFull);
-                    nb += w_s[c] * (double)((exB[c >> 2] >> ((c & 3) * 16)) & 0xFFFFull);
+                    for (int f = 0; f < 4; ++f) {
+                        const int c = 4 * k + f;
+                        const int ca = field(exA, c), cb = field(exB, c);
+                        if constexpr (MODE == MODE_H2W) {
+                            D += w_s[c] * (sqrt_cnt(ca) * sqrt_cnt(cb));
+                            na += w_s[c] * (double)ca;
+                            nb += w_s[c] * (double)cb;
+                        } else {
+                            D += sqrt_cnt(ca) * sqrt_cnt(cb);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);  // keep only one word's table look-ups in flight (register pressure)
                 }
                 if constexpr (MODE == MODE_H2W) { ra = 1.0 / sqrt(na); rb = 1.0 / sqrt(nb); }
+                else { ra = rsqrt_cnt(totA); rb = rsqrt_cnt(totB); }
+            } else {
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) {
+                    va[c] = w_s[c] * (double)field(exA, c);
+                    vb[c] = w_s[c] * (double)field(exB, c);
+                }
             }
+        };
+        // exact squared Hellinger distance in the literal difference-of-roots form (statistical_distances.rs:4-10)
+        auto exact_h2 = [&]() -> double {
+            double acc2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) {
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    const int c = 4 * k + f;
+                    const double d = root_of(c, field(exA, c)) * ra - root_of(c, field(exB, c)) * rb;  // equal inputs cancel exactly
+                    acc2 = fma(d, d, acc2);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return 0.5 * acc2;
         };
         auto distance = [&]() -> double {  // pmf.rs:85-88
             if constexpr (H2) {
-                double acc2 = 0.0;
-#pragma unroll
-                for (int c = 0; c < CMAX; ++c) {
-                    const double d = va[c] * ra - vb[c] * rb;  // two roundings that cancel exactly for equal inputs
-                    acc2 = fma(d, d, acc2);
-                }
-                return sqrt(0.5 * acc2);
+                // H^2 = 1 - sum_c sqrt(p_c q_c): O(1) per event from the running D.  Its rounding error (~1e-16
+                // absolute) only matters when H^2 itself is tiny, so small values are recomputed in the exact form
+                // (which also returns exactly 0 for identical environments).
+                double h2 = 1.0 - (ra * rb) * D;
+                if (h2 < 1e-3) h2 = exact_h2();
+                return sqrt(h2);
             } else {
                 double pn[CMAX], qn[CMAX];
                 double sa_ = 0.0, sb_ = 0.0;  // pmf.rs:67-68: fresh sums
@@ -620,13 +677,12 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs args) {
                 if (sa_ == 0.0 || sb_ == 0.0) zero_norm = true;
 #pragma unroll
                 for (int c = 0; c < CMAX; ++c) { pn[c] = va[c] / sa_; qn[c] = vb[c] / sb_; }
-                return sd_generic(cfg.sd_kind, cfg.sd_p0, cfg.sd_p1, pn, qn, C);
+                return sd_generic(cfgp->sd_kind, cfgp->sd_p0, cfgp->sd_p1, pn, qn, C);
             }
         };
 
 #pragma unroll
         for (int k = 0; k < NW; ++k) { exA[k] = cntA[k]; exB[k] = cntB[k]; }
-        totA = totB = 1;
         load_state();
         double F_carry = cdf_dev<WFANY>(wf, 0.0);
         double H_carry = bad_cat ? 0.0 : distance();
@@ -671,16 +727,11 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs args) {
             for (int k = 0; k < NW; ++k) {
                 const uint64_t va_ = spread4(hA[(k * 4) / 16] >> (((k * 4) % 16) * 4));
                 const uint64_t vb_ = spread4(hB[(k * 4) / 16] >> (((k * 4) % 16) * 4));
-                uint64_t sa_ = va_, sb_ = vb_;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint64_t ta = shfl_up_u64(sa_, d), tb = shfl_up_u64(sb_, d);
-                    if (lane >= d) { sa_ += ta; sb_ += tb; }
-                }
+                const uint64_t sa_ = wave_incl_scan_fields(va_), sb_ = wave_incl_scan_fields(vb_);
                 exA[k] = cntA[k] + sa_ - va_;
                 exB[k] = cntB[k] + sb_ - vb_;
-                cntA[k] += shfl_u64(sa_, 63);  // carry for the next tile
-                cntB[k] += shfl_u64(sb_, 63);
+                cntA[k] += readlane_u64(sa_, 63);  // carry for the next tile (scalar)
+                cntB[k] += readlane_u64(sb_, 63);
             }
             totA = 1 + ia + i0;
             totB = 1 + ib + j0;
@@ -699,36 +750,45 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs args) {
                     const double F = cdf_dev<WFANY>(wf, u2d(kb));
                     if (e == 0) firstF = F; else local += (F - Fp) * Hp;
                     // pmf.rs:47-63: one more point of category ct on one side
-                    const uint64_t inc = 1ull << ((ct & 3) * 16);
-                    uint64_t word = 0;
+                    const int sh = (ct & 3) * 16;
+                    const uint64_t inc = 1ull << sh;
+                    uint64_t wA = 0, wB = 0;
 #pragma unroll
                     for (int k = 0; k < NW; ++k) {
                         const bool hit = ((ct >> 2) == k);
+                        wA = hit ? exA[k] : wA;
+                        wB = hit ? exB[k] : wB;
                         exA[k] += (hit && takeA) ? inc : 0ull;
                         exB[k] += (hit && !takeA) ? inc : 0ull;
-                        word = hit ? (takeA ? exA[k] : exB[k]) : word;
                     }
-                    const int cnt = (int)((word >> ((ct & 3) * 16)) & 0xFFFFull);
-                    const double nv = val_of(ct, cnt);
-#pragma unroll
-                    for (int c = 0; c < CMAX; ++c) {
-                        const bool hit = (c == ct);
-                        va[c] = (hit && takeA) ? nv : va[c];
-                        vb[c] = (hit && !takeA) ? nv : vb[c];
-                    }
+                    const int cntA_ = (int)((wA >> sh) & 0xFFFFull), cntB_ = (int)((wB >> sh) & 0xFFFFull);  // before the update
                     totA += takeA ? 1 : 0;
                     totB += takeA ? 0 : 1;
-                    if constexpr (MODE == MODE_H2U) {
-                        const double r = rsqrt_cnt(takeA ? totA : totB);
-                        ra = takeA ? r : ra;
-                        rb = takeA ? rb : r;
-                    } else if constexpr (MODE == MODE_H2W) {
+                    if constexpr (H2) {
+                        const int mine = takeA ? cntA_ : cntB_, other = takeA ? cntB_ : cntA_;
+                        double delta = (sqrt_cnt(mine + 1) - sqrt_cnt(mine)) * sqrt_cnt(other);
+                        if constexpr (MODE == MODE_H2W) {
+                            const double wv_ = w_s[ct & 31];
+                            delta *= wv_;
+                            na += takeA ? wv_ : 0.0;
+                            nb += takeA ? 0.0 : wv_;
+                            const double r = 1.0 / sqrt(takeA ? na : nb);
+                            ra = takeA ? r : ra;
+                            rb = takeA ? rb : r;
+                        } else {
+                            const double r = rsqrt_cnt(takeA ? totA : totB);
+                            ra = takeA ? r : ra;
+                            rb = takeA ? rb : r;
+                        }
+                        D += delta;
+                    } else {
                         const double wv_ = w_s[ct & 31];
-                        na += takeA ? wv_ : 0.0;
-                        nb += takeA ? 0.0 : wv_;
-                        const double r = 1.0 / sqrt(takeA ? na : nb);
-                        ra = takeA ? r : ra;
-                        rb = takeA ? rb : r;
+#pragma unroll
+                        for (int c = 0; c < CMAX; ++c) {
+                            const bool hit = (c == ct);
+                            va[c] += (hit && takeA) ? wv_ : 0.0;
+                            vb[c] += (hit && !takeA) ? wv_ : 0.0;
+                        }
                     }
                     Hp = distance();
                     Fp = F;
@@ -759,28 +819,37 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs args) {
     }
 }
 
-template <int MODE, bool WFANY>
+template <int MODE, bool WFANY, bool LDSTAB>
 static void launch_sweep_mode(hipStream_t s, int cmax, unsigned grid, const SweepArgs& a) {
-    if (cmax <= 8) k_sweep<8, MODE, WFANY><<<grid, 256, 0, s>>>(a);
-    else if (cmax <= 12) k_sweep<12, MODE, WFANY><<<grid, 256, 0, s>>>(a);
-    else if (cmax <= 16) k_sweep<16, MODE, WFANY><<<grid, 256, 0, s>>>(a);
-    else if (cmax <= 24) k_sweep<24, MODE, WFANY><<<grid, 256, 0, s>>>(a);
-    else k_sweep<32, MODE, WFANY><<<grid, 256, 0, s>>>(a);
+    constexpr int NTH = 64 * kSweepWaves;
+    if (cmax <= 8) k_sweep<8, MODE, WFANY, LDSTAB><<<grid, NTH, 0, s>>>(a);
+    else if (cmax <= 12) k_sweep<12, MODE, WFANY, LDSTAB><<<grid, NTH, 0, s>>>(a);
+    else if (cmax <= 16) k_sweep<16, MODE, WFANY, LDSTAB><<<grid, NTH, 0, s>>>(a);
+    else if (cmax <= 24) k_sweep<24, MODE, WFANY, LDSTAB><<<grid, NTH, 0, s>>>(a);
+    else k_sweep<32, MODE, WFANY, LDSTAB><<<grid, NTH, 0, s>>>(a);
 }
 
 void launch_sweep(hipStream_t s, int n_categories, bool hellinger2, bool unit_weights, bool wf_pow, const SweepArgs& a) {
     if (a.n_pairs <= 0) return;
-    const int64_t blocks = (a.n_pairs + 3) / 4;
+    const int64_t blocks = (a.n_pairs + kSweepWaves - 1) / kSweepWaves;
     const unsigned grid = (unsigned)(blocks < 4096 ? blocks : 4096);  // grid-stride: LDS tables are built once per block
     int cmax = n_categories;
     if (const char* f = getenv("LCHD_FORCE_CMAX")) cmax = atoi(f) > cmax ? atoi(f) : cmax;  // test hook
     if (const char* f = getenv("LCHD_FORCE_GENERIC")) hellinger2 = hellinger2 && atoi(f) == 0;  // test hook
-    if (!hellinger2) launch_sweep_mode<MODE_GEN, true>(s, cmax, grid, a);
-    else if (unit_weights && !wf_pow) launch_sweep_mode<MODE_H2U, false>(s, cmax, grid, a);
-    else if (unit_weights) launch_sweep_mode<MODE_H2U, true>(s, cmax, grid, a);
-    else launch_sweep_mode<MODE_H2W, true>(s, cmax, grid, a);
+    bool small = a.env_a.stride <= kSqrtTab && a.env_b.stride <= kSqrtTab;  // every count fits the LDS tables
+    if (const char* f = getenv("LCHD_FORCE_BIGENV")) small = small && atoi(f) == 0;  // test hook
+    if (!hellinger2) launch_sweep_mode<MODE_GEN, true, false>(s, cmax, grid, a);
+    else if (unit_weights && !wf_pow) {
+        if (small) launch_sweep_mode<MODE_H2U, false, true>(s, cmax, grid, a);
+        else launch_sweep_mode<MODE_H2U, false, false>(s, cmax, grid, a);
+    } else if (unit_weights) {
+        if (small) launch_sweep_mode<MODE_H2U, true, true>(s, cmax, grid, a);
+        else launch_sweep_mode<MODE_H2U, true, false>(s, cmax, grid, a);
+    } else {
+        if (small) launch_sweep_mode<MODE_H2W, true, true>(s, cmax, grid, a);
+        else launch_sweep_mode<MODE_H2W, true, false>(s, cmax, grid, a);
+    }
 }
-
 
 // sum over pairs of n_A + n_B (algorithmic-bytes accounting for bench.py; not part of the scoring path)
 __global__ void k_env_points(SweepArgs args, unsigned long long* out) {

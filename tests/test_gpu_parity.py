@@ -263,3 +263,44 @@ def test_error_behaviour(lh):
     with pytest.raises(ValueError):
         multi.from_primitives(p[:1], p[:1], [(0, 0, "nope")], 5.0)
     assert multi.from_primitives(p[:1], p[:1], [(0, 0, "x")], 5.0) == [0.0]
+
+
+@pytest.mark.parametrize("hook", [{"LCHD_FORCE_CMAX": "8"}, {"LCHD_FORCE_CMAX": "12"}, {"LCHD_FORCE_CMAX": "16"},
+                                  {"LCHD_FORCE_CMAX": "24"}, {"LCHD_FORCE_CMAX": "32"}, {"LCHD_FORCE_GENERIC": "1"},
+                                  {"LCHD_FORCE_BIGENV": "1"}, {"LCHD_FORCE_GENERIC": "1", "LCHD_FORCE_CMAX": "16"}])
+def test_every_sweep_kernel_variant(lh, oracle, hook, monkeypatch):
+    """The sweep kernel is instantiated per category-slot count / distance family / table placement; the launcher's
+    test hooks force each instantiation onto the same inputs (an -O3 miscompile of one variant was caught this way)."""
+    rng = np.random.default_rng(23)
+    sa, xa = cloud(rng, 500, box=13.0)
+    sb, xb = cloud(rng, 450, box=13.0)
+    anchors = [(int(i), int(j)) for i, j in zip(rng.integers(0, 500, 400), rng.integers(0, 450, 400))]
+    for k, v in hook.items():
+        monkeypatch.setenv(k, v)
+    for wf, w in ((("hyper_exp", [1.0, 0.1]), None), (("kumaraswamy", [2.0, 11.0, 3.3, 4.4]), [1.0, 0.5, 2.25, 3.0, 0.1])):
+
+        def run(mod):
+            lchd = mod.LoCoHD(CATS, mod.WeightFunction(*wf), category_weights=w)
+            return np.asarray(lchd.from_primitives(prims(mod, sa, xa), prims(mod, sb, xb), anchors, 9.0))
+
+        got, want = both(lh, oracle, run)
+        assert np.max(np.abs(got - want)) < TIGHT, (hook, wf)
+
+
+def test_near_identical_environments(lh, oracle):
+    """Small Hellinger distances exercise the exact difference-of-roots branch of the fast path."""
+    rng = np.random.default_rng(29)
+    s, x = cloud(rng, 600, box=14.0)
+    x2 = x + rng.normal(0.0, 0.02, x.shape)  # slightly jittered copy, same categories
+    s3 = list(s)
+    for i in rng.integers(0, 600, 12):
+        s3[i] = CATS[(CATS.index(s3[i]) + 1) % len(CATS)]  # a few relabelled atoms
+    anchors = [(i, i) for i in range(600)]
+    for sb_, xb_ in ((s, x2), (s3, x), (s3, x2)):
+
+        def run(mod):
+            lchd = mod.LoCoHD(CATS, mod.WeightFunction("uniform", [3.0, 10.0]))
+            return np.asarray(lchd.from_primitives(prims(mod, s, x), prims(mod, sb_, xb_), anchors, 10.0))
+
+        got, want = both(lh, oracle, run)
+        assert np.max(np.abs(got - want)) < TIGHT
