@@ -1,0 +1,127 @@
+"""Host logic of the product package on a CPU-only machine: validation, error classes, string interning, the
+host-side leaves of the C ABI (CDFs, statistical distances).  Mirrors the reference's own unit tests
+(/root/reference/tests/test_wfs.py, test_tag_pairing_rule.py:8-98, test_locohd.py:54-73) against loco_hd_amd."""
+import itertools
+
+import numpy as np
+import pytest
+
+import loco_hd_amd as lh
+from test_oracle_kat import WF_ERRS, WF_KATS
+
+
+@pytest.mark.parametrize("name,params,cases", WF_KATS)
+def test_weight_function_kats(name, params, cases):  # tests/test_wfs.py:8-138
+    wf = lh.WeightFunction(name, params)
+    for a, b, want in cases:
+        assert wf.integral_range(float(a), float(b)) == pytest.approx(want, abs=5e-5)
+    assert wf.function_name == name and wf.parameters == [float(p) for p in params]
+
+
+@pytest.mark.parametrize("name,params", WF_ERRS)
+def test_weight_function_errors(name, params):  # tests/test_wfs.py:29-156
+    with pytest.raises(ValueError):
+        lh.WeightFunction(name, params)
+
+
+def test_weight_function_misc(oracle):
+    with pytest.raises(ValueError):
+        lh.WeightFunction("gauss", [1.0])
+    wf = lh.WeightFunction("dagum", [1.7, 2.5, 9.0])
+    with pytest.raises(ValueError):  # weight_function.rs:97-100
+        wf.integral_point(-1e-9)
+    xs = np.linspace(0.0, 40.0, 201)
+    ref = oracle.WeightFunction("dagum", [1.7, 2.5, 9.0])
+    assert np.allclose(wf.integral_vec(xs), ref.integral_vec(xs), rtol=0, atol=1e-15)
+    assert wf.integral_point(float("inf")) == 1.0 and wf.integral_point(0.0) == 0.0
+
+
+def test_statistical_distance_leaves(oracle):
+    rng = np.random.default_rng(3)
+    for name, prm in (("Hellinger", [2.0]), ("Hellinger", [3.3]), ("Kolmogorov-Smirnov", []), ("Kullback-Leibler", [0.5]),
+                      ("Renyi", [2.4, 0.7]), ("Renyi", [1.0, 0.5]), ("Renyi", [0.0, 0.1]), ("Renyi", [float("inf"), 0.2])):
+        a, b = lh.StatisticalDistance(name, prm), oracle.StatisticalDistance(name, prm)
+        for _ in range(20):
+            p, q = rng.dirichlet(np.ones(7)), rng.dirichlet(np.ones(7))
+            assert a.run(p, q) == pytest.approx(b.run(p, q), abs=1e-15)
+    for bad in (("Hellinger", []), ("Hellinger", [1.0, 2.0]), ("Kolmogorov-Smirnov", [1.0]), ("Renyi", [1.0]), ("Wasserstein", [])):
+        with pytest.raises(ValueError):
+            lh.StatisticalDistance(*bad)
+
+
+def test_tag_pairing_truth_table():  # tests/test_tag_pairing_rule.py:8-98
+    tpr = lh.TagPairingRule({"accept_same": True})
+    assert tpr.pair_accepted(("A", "A")) and not tpr.pair_accepted(("A", "B"))
+    tpr = lh.TagPairingRule({"accept_same": False})
+    assert not tpr.pair_accepted(("A", "A")) and tpr.pair_accepted(("A", "B"))
+    listed = {("A", "B"), ("A", "C"), ("B", "C")}
+    for accepted_pairs, ordered in itertools.product([True, False], [True, False]):
+        tpr = lh.TagPairingRule({"tag_pairs": listed, "accepted_pairs": accepted_pairs, "ordered": ordered})
+        for pair in itertools.product("ABC", repeat=2):
+            hit = pair in listed or (not ordered and pair[::-1] in listed)
+            assert tpr.pair_accepted(pair) == (hit if accepted_pairs else not hit)
+        assert "WithList" in tpr.get_dbg_str()
+    with pytest.raises(TypeError):
+        lh.TagPairingRule({"something": 1})
+
+
+def test_locohd_constructor():  # tests/test_locohd.py:54-73, src/locohd.rs:289-389
+    wf = lh.WeightFunction("uniform", [0.0, 4.0])
+    types = ["O", "A", "B", "C"]
+    with pytest.raises(ValueError):
+        lh.LoCoHD([], wf)
+    for bad in ([1.0, 1.0, 1.0], [1.0] * 5, [1.0, -1.0, 1.0, 1.0], [1.0, 0.0, 1.0, 1.0]):
+        with pytest.raises(ValueError):
+            lh.LoCoHD(types, wf, category_weights=bad)
+    lchd = lh.LoCoHD(types, wf, lh.TagPairingRule({"accept_same": False}), 4)  # positional use, README.md:373-378
+    assert lchd.categories == {"O": 0, "A": 1, "B": 2, "C": 3}
+    assert lchd.category_weights == [1.0] * 4 and lchd.w_func is wf
+    dflt = lh.LoCoHD(types)  # defaults :349-370
+    assert dflt.w_func.function_name == "uniform" and dflt.w_func.parameters == [3.0, 10.0]
+    assert dflt.tag_pairing_rule.pair_accepted(("x", "x"))
+    assert lh.LoCoHD(["A", "B", "A"]).categories == {"A": 2, "B": 1}  # HashMap collect keeps the last index (:312-316)
+
+
+def test_weight_function_key_rules():  # src/locohd.rs:230-283
+    single = lh.LoCoHD(["A"], lh.WeightFunction("uniform", [0.0, 4.0]))
+    multi = lh.LoCoHD(["A"], {"x": lh.WeightFunction("uniform", [0.0, 4.0]), "y": lh.WeightFunction("uniform", [1.0, 2.0])})
+    assert single._wf_indices(None, 5) is None
+    assert multi._wf_indices(["y", "x", "y"], 3).tolist() == [1, 0, 1]
+    for lchd, keys, n in ((single, ["x"], 1), (multi, None, 1), (multi, ["x"], 2), (multi, ["x", "nope"], 2)):
+        with pytest.raises(ValueError):
+            lchd._wf_indices(keys, n)
+
+
+def test_anchor_pair_parsing():  # AnchorPairSpecifier, src/locohd.rs:34-40
+    split = lh.LoCoHD._split_anchor_pairs
+    assert split([(0, 1), (2, 3)]) == ([(0, 1), (2, 3)], None)
+    assert split([(0, 1, "k")]) == ([(0, 1)], ["k"])
+    assert split([]) == ([], [])  # the empty list is the with-key variant
+    with pytest.raises(TypeError):
+        split([(0, 1), (1, 2, "k")])
+    with pytest.raises(OverflowError):
+        split([(0, -1)])
+
+
+def test_packing_interns_like_the_reference():
+    lchd = lh.LoCoHD(["A", "B"])
+    prims = [lh.PrimitiveAtom("A", "r1", [0, 0, 0]), lh.PrimitiveAtom("Z", "r2", (1, 2, 3)), lh.PrimitiveAtom("B", "r1", np.ones(3))]
+    interner = {}
+    p = lchd.pack(prims, interner)
+    assert p.cat.tolist() == [0, -1, 1] and p.tag.tolist() == [0, 1, 0] and p.xyz[1].tolist() == [1.0, 2.0, 3.0]
+    prims[0].coordinates = [9, 9, 9]
+    assert prims[0].coordinates == [9.0, 9.0, 9.0]
+    with pytest.raises(ValueError):
+        lh.PrimitiveAtom("A", "", [1.0, 2.0])
+
+
+def test_scoring_fails_loudly_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lchd = lh.LoCoHD(["A"])
+    with pytest.raises(lh.DeviceError):
+        lchd.from_anchors(["A"], ["A"], [0.0], [0.0])
+    with pytest.raises(lh.DeviceError):
+        lchd.from_coords(["A"], ["A"], [[0.0, 0.0, 0.0]], [[0.0, 0.0, 0.0]])
