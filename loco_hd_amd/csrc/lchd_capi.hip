@@ -264,18 +264,21 @@ extern "C" int lchd_ctx_set_config(lchd_ctx* c, const lchd_config* cfg) {
         if (int rc = lchd_wf_validate(w.kind, w.params, w.n_params)) return rc;
         n_params += (size_t)w.n_params;
     }
-    // blob: [cat_w][wf entries][wf params][tag pairs]
+    // blob: [cat_w][wf entries][wf params][F(+inf) per wf][tag pairs]
     const size_t o_w = 0, o_e = o_w + sizeof(double) * C, o_p = o_e + sizeof(WfEntry) * cfg->n_weight_functions;
-    const size_t o_t = o_p + sizeof(double) * n_params, total = o_t + sizeof(uint64_t) * (size_t)cfg->n_tag_pairs;
+    const size_t o_f = o_p + sizeof(double) * n_params, o_t = o_f + sizeof(double) * cfg->n_weight_functions;
+    const size_t total = o_t + sizeof(uint64_t) * (size_t)cfg->n_tag_pairs;
     std::vector<char> blob(total + 8);
     memcpy(blob.data() + o_w, cfg->category_weights, sizeof(double) * C);
     WfEntry* ent = reinterpret_cast<WfEntry*>(blob.data() + o_e);
     double* prm = reinterpret_cast<double*>(blob.data() + o_p);
+    double* finf = reinterpret_cast<double*>(blob.data() + o_f);
     int off = 0;
     for (int i = 0; i < cfg->n_weight_functions; ++i) {
         const lchd_weight_function& w = cfg->weight_functions[i];
         ent[i] = WfEntry{w.kind, w.n_params, off, 0};
         memcpy(prm + off, w.params, sizeof(double) * w.n_params);
+        finf[i] = cdf_eval(w.kind, w.params, w.n_params, (double)INFINITY);
         off += w.n_params;
     }
     uint64_t* tp = reinterpret_cast<uint64_t*>(blob.data() + o_t);
@@ -304,6 +307,7 @@ extern "C" int lchd_ctx_set_config(lchd_ctx* c, const lchd_config* cfg) {
     h.cat_w = reinterpret_cast<const double*>(c->d_blob + o_w);
     h.wf = reinterpret_cast<const WfEntry*>(c->d_blob + o_e);
     h.wf_params = reinterpret_cast<const double*>(c->d_blob + o_p);
+    h.wf_finf = reinterpret_cast<const double*>(c->d_blob + o_f);
     h.tag_pairs = reinterpret_cast<const uint64_t*>(c->d_blob + o_t);
     HIP_TRY(hipMemcpy(c->d_cfg, &h, sizeof h, hipMemcpyHostToDevice));
     c->h_cfg = h;
@@ -496,6 +500,7 @@ static void carve_side(Arena& a, int64_t n, int n_cells, int64_t max_envs, int c
     b.env.cat = a.take<uint8_t>(ne * (size_t)cap);
     b.env.len = a.take<int32_t>(ne);
     b.env.stride = cap;
+    b.env.cdf_keys = 0;
 }
 
 static int next_pow2_host(int64_t n) {
@@ -529,6 +534,7 @@ extern "C" int lchd_from_primitives_dev(lchd_ctx* c, lchd_cloud* a, lchd_cloud* 
         Arena ar(c->ws, c->ws_cap, false);
         carve_side(ar, a->n, ga.n_cells, max_env_a, cap, sa);
         carve_side(ar, b->n, gb.n_cells, max_env_b, cap, sb);
+        sa.env.cdf_keys = sb.env.cdf_keys = (c->h_cfg.n_wf == 1 && !getenv("LCHD_NO_CDF_KEYS")) ? 1 : 0;
 
         auto grid_view = [](const GridPlan& g, const SideBufs& s) {
             GridView v{};
@@ -690,6 +696,7 @@ static int dense_driver(lchd_ctx* c, const lchd_config* cfg, const int32_t* seq_
             eb.cat = ar.take<uint8_t>((size_t)rows * cap_b);
             eb.len = ar.take<int32_t>((size_t)rows);
             eb.stride = cap_b;
+            ea.cdf_keys = eb.cdf_keys = (c->h_cfg.n_wf == 1 && !getenv("LCHD_NO_CDF_KEYS")) ? 1 : 0;
             d_out = ar.take<double>((size_t)rows);
             d_wf = ar.take<int32_t>((size_t)rows);
             if (dmx_a) {

@@ -44,6 +44,7 @@ struct DevConfig {
     const double* cat_w;        // [n_categories]
     const WfEntry* wf;          // [n_wf]
     const double* wf_params;    // concatenated
+    const double* wf_finf;      // [n_wf] F(+inf) per weight function (host-evaluated; 1.0 except for degenerate dagum)
     const uint64_t* tag_pairs;  // sorted, (anchor_tag << 32) | neighbour_tag
 };
 
@@ -74,6 +75,7 @@ struct EnvStore {
     uint8_t* cat;
     int32_t* len;
     int64_t stride;
+    int32_t cdf_keys;  // 1: key = bits of F(distance) for the configuration's single weight function (sweep needs no CDF evaluation)
 };
 
 void launch_cell_build(hipStream_t s, const CloudView& c, GridView g, uint32_t* cell_of, uint32_t* cell_count,

@@ -187,6 +187,40 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t* key, uint8_t* val, in
     }
 }
 
+// Single-weight-function configurations: replace the sorted distances by F(distance) so that the sweep kernel never
+// evaluates a CDF (every pair that re-uses this environment would recompute the same values).  F is non-decreasing,
+// so the order is unchanged; a running maximum removes last-bit inversions of the floating-point CDF (the merge in
+// the sweep kernel needs sorted keys; equal F values are zero-width intervals and contribute exactly 0).
+template <int NT>
+__device__ __forceinline__ void keys_to_cdf_lds(uint64_t* key, int n, int tid, const DevConfig* __restrict__ cfg) {
+    const WfEntry wf = cfg->wf[0];
+    const double* __restrict__ prm = cfg->wf_params + wf.offset;
+    const int chunk = (n + NT - 1) / NT, lo = min(tid * chunk, n), hi = min(lo + chunk, n);
+    uint64_t m = 0;
+    for (int i = lo; i < hi; ++i) {
+        const uint64_t f = d2u(cdf_eval(wf.kind, prm, wf.n_params, u2d(key[i])) + 0.0);
+        m = f > m ? f : m;
+        key[i] = m;
+    }
+    // exclusive prefix maximum of the per-thread maxima
+    uint64_t incl = m;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t t = shfl_up_u64(incl, d);
+        if ((tid & 63) >= d) incl = t > incl ? t : incl;
+    }
+    uint64_t excl = shfl_up_u64(incl, 1);
+    if ((tid & 63) == 0) excl = 0;
+    if constexpr (NT > 64) {
+        __shared__ uint64_t wave_max[NT / 64];
+        if ((tid & 63) == 63) wave_max[tid >> 6] = incl;
+        __syncthreads();
+        for (int w = 0; w < (tid >> 6); ++w) excl = wave_max[w] > excl ? wave_max[w] : excl;
+    }
+    for (int i = lo; i < hi; ++i) key[i] = key[i] > excl ? key[i] : excl;
+    __syncthreads();
+}
+
 __device__ __forceinline__ int next_pow2(int n) {
     int p = 1;
     while (p < n) p <<= 1;
@@ -282,6 +316,7 @@ __global__ __launch_bounds__(64) void k_env_cells(const DevConfig* __restrict__ 
     for (int i = count + lane; i < n2; i += 64) { key[i] = kPadKey; val[i] = 0; }
     __syncthreads();
     bitonic_sort_lds<64>(key, val, n2, lane);
+    if (env.cdf_keys) keys_to_cdf_lds<64>(key, count, lane, cfgp);
     uint64_t* ok_ = env.key + e * env.stride;
     uint8_t* oc_ = env.cat + e * env.stride;
     for (int i = lane; i < count; i += 64) { ok_[i] = key[i]; oc_[i] = val[i]; }
@@ -308,8 +343,8 @@ bool launch_env_cells(hipStream_t s, int cap, const DevConfig* cfg, const CloudV
 // Dynamic LDS: n2 * 9 bytes.
 // ------------------------------------------------------------------------------------------------
 template <int NT>
-__global__ __launch_bounds__(NT) void k_env_rows(CloudView c, const double* __restrict__ dmx, int64_t ld,
-                                                 int64_t row_len, int n2, EnvStore env, DeviceStatus* st) {
+__global__ __launch_bounds__(NT) void k_env_rows(const DevConfig* __restrict__ cfgp, CloudView c, const double* __restrict__ dmx,
+                                                 int64_t ld, int64_t row_len, int n2, EnvStore env, DeviceStatus* st) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* key = reinterpret_cast<uint64_t*>(smem);
     uint8_t* val = smem + (size_t)n2 * 8;
@@ -351,26 +386,27 @@ __global__ __launch_bounds__(NT) void k_env_rows(CloudView c, const double* __re
     if (bad) atomicOr(&st->flags, ST_BAD_DISTANCE);
     __syncthreads();
     bitonic_sort_lds<NT>(key, val, n2, tid);
+    if (tid == 0) {
+        env.len[r] = n;
+        if (n > 0 && key[0] != 0ull) atomicOr(&st->flags, ST_FIRST_NOT_ZERO);  // src/locohd.rs:74-77, on the distance
+    }
+    __syncthreads();
+    if (env.cdf_keys) keys_to_cdf_lds<NT>(key, n, tid, cfgp);
     uint64_t* ok_ = env.key + r * env.stride;
     uint8_t* oc_ = env.cat + r * env.stride;
     for (int i = tid; i < n; i += NT) { ok_[i] = key[i]; oc_[i] = val[i]; }
-    if (tid == 0) {
-        env.len[r] = n;
-        if (n > 0 && key[0] != 0ull) atomicOr(&st->flags, ST_FIRST_NOT_ZERO);
-    }
 }
 
 bool launch_env_rows(hipStream_t s, int cap, const DevConfig* cfg, const CloudView& c, const double* dmx, int64_t ld,
                      int64_t n_rows, int64_t row_len, EnvStore env, DeviceStatus* st) {
-    (void)cfg;
     if (n_rows <= 0) return true;
     if (cap > 16384 || row_len > cap) return false;
     const size_t lds = (size_t)cap * 9;
     const dim3 grid((unsigned)n_rows);
     if (cap <= 1024) {
-        k_env_rows<64><<<grid, 64, lds, s>>>(c, dmx, ld, row_len, cap, env, st);
+        k_env_rows<64><<<grid, 64, lds, s>>>(cfg, c, dmx, ld, row_len, cap, env, st);
     } else if (cap <= 4096) {
-        k_env_rows<256><<<grid, 256, lds, s>>>(c, dmx, ld, row_len, cap, env, st);
+        k_env_rows<256><<<grid, 256, lds, s>>>(cfg, c, dmx, ld, row_len, cap, env, st);
     } else {
         static bool attr_set = false;
         if (!attr_set) {
@@ -378,7 +414,7 @@ bool launch_env_rows(hipStream_t s, int cap, const DevConfig* cfg, const CloudVi
                                 16384 * 9);
             attr_set = true;
         }
-        k_env_rows<1024><<<grid, 1024, lds, s>>>(c, dmx, ld, row_len, cap, env, st);
+        k_env_rows<1024><<<grid, 1024, lds, s>>>(cfg, c, dmx, ld, row_len, cap, env, st);
     }
     return true;
 }
@@ -406,6 +442,8 @@ bool launch_env_rows(hipStream_t s, int cap, const DevConfig* cfg, const CloudVi
 //   normalised like pmf.rs:65-83, distance through one out-of-line call.
 // ------------------------------------------------------------------------------------------------
 enum { MODE_H2U = 0, MODE_H2W = 1, MODE_GEN = 2 };
+// where F(t) comes from: the environment keys already are F values / inline CDFs only / any CDF
+enum { F_KEY = 0, F_FAST = 1, F_ANY = 2 };
 #ifndef LCHD_SWEEP_WAVES
 #define LCHD_SWEEP_WAVES 4
 #endif
@@ -515,7 +553,7 @@ __device__ __noinline__ double sd_generic(int kind, double p0, double p1, const 
     return sd_eval<0>(kind, p0, p1, [&](int c) { return p[c]; }, [&](int c) { return q[c]; }, C);
 }
 
-template <int CMAX, int MODE, bool WFANY, bool LDSTAB>
+template <int CMAX, int MODE, int FMODE, bool LDSTAB>
 __global__ __launch_bounds__(64 * kSweepWaves, LCHD_SWEEP_MINW) void k_sweep(SweepArgs args) {
     constexpr int EPL = kSweepEPL, TILE = kSweepTile, WPB = kSweepWaves;
     constexpr int NW = CMAX / 4;          // u64 words of 16-bit count fields per side
@@ -583,12 +621,20 @@ __global__ __launch_bounds__(64 * kSweepWaves, LCHD_SWEEP_MINW) void k_sweep(Swe
             if (lane == 0) { atomicOr(&args.st->flags, ST_BAD_WF); args.out[p] = nan(""); }
             continue;
         }
-        const WfEntry wfe = cfgp->wf[wfi];
-        const WfRegs wf = wf_load(wfe, cfgp->wf_params + wfe.offset);
-        if (kA[0] != 0ull || kB[0] != 0ull) {  // src/locohd.rs:74-77
-            if (lane == 0) { atomicOr(&args.st->flags, ST_FIRST_NOT_ZERO); args.out[p] = nan(""); }
-            continue;
+        constexpr bool WFANY = (FMODE == F_ANY);
+        WfRegs wf{};
+        if constexpr (FMODE != F_KEY) {
+            const WfEntry wfe = cfgp->wf[wfi];
+            wf = wf_load(wfe, cfgp->wf_params + wfe.offset);
+            if (kA[0] != 0ull || kB[0] != 0ull) {  // src/locohd.rs:74-77 (F_KEY: checked by the environment kernels)
+                if (lane == 0) { atomicOr(&args.st->flags, ST_FIRST_NOT_ZERO); args.out[p] = nan(""); }
+                continue;
+            }
         }
+        auto cdf_of_key = [&](uint64_t k) -> double {
+            if constexpr (FMODE == F_KEY) return u2d(k);
+            else return cdf_dev<WFANY>(wf, u2d(k));
+        };
 
         bool bad_cat = false, zero_norm = false;
         // wave-uniform packed integer category counts (16-bit fields), seeded with the two anchors (:82-84)
@@ -684,7 +730,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, LCHD_SWEEP_MINW) void k_sweep(Swe
 #pragma unroll
         for (int k = 0; k < NW; ++k) { exA[k] = cntA[k]; exB[k] = cntB[k]; }
         load_state();
-        double F_carry = cdf_dev<WFANY>(wf, 0.0);
+        double F_carry = cdf_of_key(kA[0]);  // F(0): both anchors sit at distance 0
         double H_carry = bad_cat ? 0.0 : distance();
         double acc = 0.0;
 
@@ -747,7 +793,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, LCHD_SWEEP_MINW) void k_sweep(Swe
                     const int ct = takeA ? cA[i] : cB[j];
                     i += takeA ? 1 : 0;
                     j += takeA ? 0 : 1;
-                    const double F = cdf_dev<WFANY>(wf, u2d(kb));
+                    const double F = cdf_of_key(kb);
                     if (e == 0) firstF = F; else local += (F - Fp) * Hp;
                     // pmf.rs:47-63: one more point of category ct on one side
                     const int sh = (ct & 3) * 16;
@@ -808,7 +854,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, LCHD_SWEEP_MINW) void k_sweep(Swe
         // wave64 butterfly reduction + the last interval to +inf (:165-171,204-210,212-221)
 #pragma unroll
         for (int m = 32; m > 0; m >>= 1) acc += shfl_xor_f64(acc, m);
-        const double Finf = cdf_dev<WFANY>(wf, (double)INFINITY);
+        const double Finf = cfgp->wf_finf[wfi];
         acc += (Finf - F_carry) * H_carry;
         const unsigned long long anybad = __ballot(bad_cat), anyzero = __ballot(zero_norm);
         if (lane == 0) {
@@ -819,14 +865,20 @@ __global__ __launch_bounds__(64 * kSweepWaves, LCHD_SWEEP_MINW) void k_sweep(Swe
     }
 }
 
-template <int MODE, bool WFANY, bool LDSTAB>
+template <int MODE, int FMODE, bool LDSTAB>
 static void launch_sweep_mode(hipStream_t s, int cmax, unsigned grid, const SweepArgs& a) {
     constexpr int NTH = 64 * kSweepWaves;
-    if (cmax <= 8) k_sweep<8, MODE, WFANY, LDSTAB><<<grid, NTH, 0, s>>>(a);
-    else if (cmax <= 12) k_sweep<12, MODE, WFANY, LDSTAB><<<grid, NTH, 0, s>>>(a);
-    else if (cmax <= 16) k_sweep<16, MODE, WFANY, LDSTAB><<<grid, NTH, 0, s>>>(a);
-    else if (cmax <= 24) k_sweep<24, MODE, WFANY, LDSTAB><<<grid, NTH, 0, s>>>(a);
-    else k_sweep<32, MODE, WFANY, LDSTAB><<<grid, NTH, 0, s>>>(a);
+    if (cmax <= 8) k_sweep<8, MODE, FMODE, LDSTAB><<<grid, NTH, 0, s>>>(a);
+    else if (cmax <= 12) k_sweep<12, MODE, FMODE, LDSTAB><<<grid, NTH, 0, s>>>(a);
+    else if (cmax <= 16) k_sweep<16, MODE, FMODE, LDSTAB><<<grid, NTH, 0, s>>>(a);
+    else if (cmax <= 24) k_sweep<24, MODE, FMODE, LDSTAB><<<grid, NTH, 0, s>>>(a);
+    else k_sweep<32, MODE, FMODE, LDSTAB><<<grid, NTH, 0, s>>>(a);
+}
+template <int MODE, bool LDSTAB>
+static void launch_sweep_f(hipStream_t s, int cmax, unsigned grid, int fmode, const SweepArgs& a) {
+    if (fmode == F_KEY) launch_sweep_mode<MODE, F_KEY, LDSTAB>(s, cmax, grid, a);
+    else if (fmode == F_FAST && MODE == MODE_H2U) launch_sweep_mode<MODE_H2U, F_FAST, LDSTAB>(s, cmax, grid, a);
+    else launch_sweep_mode<MODE, F_ANY, LDSTAB>(s, cmax, grid, a);
 }
 
 void launch_sweep(hipStream_t s, int n_categories, bool hellinger2, bool unit_weights, bool wf_pow, const SweepArgs& a) {
@@ -838,16 +890,14 @@ void launch_sweep(hipStream_t s, int n_categories, bool hellinger2, bool unit_we
     if (const char* f = getenv("LCHD_FORCE_GENERIC")) hellinger2 = hellinger2 && atoi(f) == 0;  // test hook
     bool small = a.env_a.stride <= kSqrtTab && a.env_b.stride <= kSqrtTab;  // every count fits the LDS tables
     if (const char* f = getenv("LCHD_FORCE_BIGENV")) small = small && atoi(f) == 0;  // test hook
-    if (!hellinger2) launch_sweep_mode<MODE_GEN, true, false>(s, cmax, grid, a);
-    else if (unit_weights && !wf_pow) {
-        if (small) launch_sweep_mode<MODE_H2U, false, true>(s, cmax, grid, a);
-        else launch_sweep_mode<MODE_H2U, false, false>(s, cmax, grid, a);
-    } else if (unit_weights) {
-        if (small) launch_sweep_mode<MODE_H2U, true, true>(s, cmax, grid, a);
-        else launch_sweep_mode<MODE_H2U, true, false>(s, cmax, grid, a);
+    const int fmode = (a.env_a.cdf_keys && a.env_b.cdf_keys) ? F_KEY : (wf_pow ? F_ANY : F_FAST);
+    if (!hellinger2) launch_sweep_f<MODE_GEN, false>(s, cmax, grid, fmode, a);
+    else if (unit_weights) {
+        if (small) launch_sweep_f<MODE_H2U, true>(s, cmax, grid, fmode, a);
+        else launch_sweep_f<MODE_H2U, false>(s, cmax, grid, fmode, a);
     } else {
-        if (small) launch_sweep_mode<MODE_H2W, true, true>(s, cmax, grid, a);
-        else launch_sweep_mode<MODE_H2W, true, false>(s, cmax, grid, a);
+        if (small) launch_sweep_f<MODE_H2W, true>(s, cmax, grid, fmode, a);
+        else launch_sweep_f<MODE_H2W, false>(s, cmax, grid, fmode, a);
     }
 }
 
