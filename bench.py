@@ -73,11 +73,27 @@ def make_workload(name: str, rank: int, n_pairs: int):
                 wf=("hyper_exp", [1.0, 0.1]), label=label, n=n)
 
 
+def usable_cores() -> int:
+    """CPU threads this process may really use: affinity mask and cgroup quota, not just os.cpu_count()."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(w, gpu_scores: np.ndarray, budget_s: float = 12.0):
     """Time the CPU oracle on a bounded prefix of the same pairs (all host cores) and use it as the parity gate."""
     from oracle import oracle as orc  # checker / baseline only
 
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     lchd = orc.LoCoHD([f"c{i}" for i in range(w["C"])], orc.WeightFunction(*w["wf"]), n_of_threads=cores)
     tag = np.zeros(w["n"], dtype=np.int32)
 

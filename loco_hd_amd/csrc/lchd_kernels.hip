@@ -749,7 +749,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, LCHD_SWEEP_MINW) void k_sweep(Swe
             const int i1 = merge_path(sA, nAt, sB, nBt, d1);
             int i0 = __shfl_up(i1, 1);
             if (lane == 0) i0 = 0;
-            const int iend = __shfl(i1, 63);
+            const int iend = __builtin_amdgcn_readlane(i1, 63);
             const int j0 = d0 - i0, j1 = d1 - i1;
 
             // pass 1: 4-bit-per-category histogram of this lane's chunk (at most 8 points per side)
@@ -785,15 +785,15 @@ __global__ __launch_bounds__(64 * kSweepWaves, LCHD_SWEEP_MINW) void k_sweep(Swe
 
             // pass 2: sequential sweep of this lane's events
             int i = i0, j = j0;
+            uint64_t ka = (i < i1) ? sA[i] : kPadKey, kb = (j < j1) ? sB[j] : kPadKey;  // list heads stay in registers
             double Fp = 0.0, Hp = 0.0, firstF = 0.0, local = 0.0;
             for (int e = 0; e < epl; ++e) {
                 if (d0 + e < d1) {
-                    const bool takeA = (i < i1) && (j >= j1 || sA[i] <= sB[j]);
-                    const uint64_t kb = takeA ? sA[i] : sB[j];
+                    const bool takeA = (ka <= kb);  // an exhausted list shows the pad key (> every real key)
+                    const uint64_t key = takeA ? ka : kb;
                     const int ct = takeA ? cA[i] : cB[j];
-                    i += takeA ? 1 : 0;
-                    j += takeA ? 0 : 1;
-                    const double F = cdf_of_key(kb);
+                    if (takeA) { ++i; ka = (i < i1) ? sA[i] : kPadKey; } else { ++j; kb = (j < j1) ? sB[j] : kPadKey; }
+                    const double F = cdf_of_key(key);
                     if (e == 0) firstF = F; else local += (F - Fp) * Hp;
                     // pmf.rs:47-63: one more point of category ct on one side
                     const int sh = (ct & 3) * 16;

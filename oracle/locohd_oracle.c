@@ -450,26 +450,21 @@ typedef struct {
     row_fn fn;
     void *ctx;
     int64_t n;
-    int64_t *next;
-    int *err;
-    pthread_mutex_t *mu;
+    int64_t next; /* claimed with an atomic add (work stealing in chunks, like rayon's splitting) */
+    int err;
 } pf_shared;
 
 static void *pf_worker(void *arg) {
     pf_shared *s = (pf_shared *)arg;
     for (;;) {
-        pthread_mutex_lock(s->mu);
-        int64_t lo = *s->next;
-        *s->next = lo + 16;
-        pthread_mutex_unlock(s->mu);
+        int64_t lo = __atomic_fetch_add(&s->next, 64, __ATOMIC_RELAXED);
         if (lo >= s->n) break;
-        int64_t hi = lo + 16 < s->n ? lo + 16 : s->n;
+        int64_t hi = lo + 64 < s->n ? lo + 64 : s->n;
         for (int64_t i = lo; i < hi; ++i) {
             int rc = s->fn(s->ctx, i);
             if (rc) {
-                pthread_mutex_lock(s->mu);
-                if (*s->err == 0 || rc > *s->err) *s->err = rc;
-                pthread_mutex_unlock(s->mu);
+                int cur = __atomic_load_n(&s->err, __ATOMIC_RELAXED);
+                while ((cur == 0 || rc > cur) && !__atomic_compare_exchange_n(&s->err, &cur, rc, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
             }
         }
     }
@@ -477,22 +472,20 @@ static void *pf_worker(void *arg) {
 }
 
 static int parallel_for(row_fn fn, void *ctx, int64_t n, int n_threads) {
-    int err = 0;
     if (n_threads <= 1) {
+        int err = 0;
         for (int64_t i = 0; i < n; ++i) {
             int rc = fn(ctx, i);
             if (rc && (err == 0 || rc > err)) err = rc;
         }
         return err;
     }
-    int64_t next = 0;
-    pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
-    pf_shared sh = {fn, ctx, n, &next, &err, &mu};
+    pf_shared sh = {fn, ctx, n, 0, 0};
     pthread_t *th = (pthread_t *)malloc((size_t)n_threads * sizeof(pthread_t));
     for (int t = 0; t < n_threads; ++t) pthread_create(&th[t], NULL, pf_worker, &sh);
     for (int t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
     free(th);
-    return err;
+    return sh.err;
 }
 
 /* ------------------------------------------------------------------------------------------------
