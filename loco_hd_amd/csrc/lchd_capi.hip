@@ -253,8 +253,7 @@ extern "C" int lchd_ctx_set_config(lchd_ctx* c, const lchd_config* cfg) {
     if (!c || !cfg) return fail(LCHD_EVALUE, "null context/config");
     const int C = cfg->n_categories;
     if (C <= 0) return fail(LCHD_EVALUE, "The number of possible categories (primitive types) cannot be zero!");
-    if (C > 32)
-        return fail(LCHD_EUNSUPPORTED, "this build supports at most 32 categories (got %d)", C);
+    if (C > 255) return fail(LCHD_EUNSUPPORTED, "at most 255 categories are supported (categories travel as u8; got %d)", C);
     if (int rc = lchd_config_validate(C, C, cfg->category_weights, C)) return rc;
     if (cfg->n_weight_functions <= 0) return fail(LCHD_EVALUE, "at least one weight function is required");
     if (int rc = lchd_sd_validate(cfg->sd_kind, cfg->sd_n_params)) return rc;

@@ -865,6 +865,276 @@ __global__ __launch_bounds__(64 * kSweepWaves, LCHD_SWEEP_MINW) void k_sweep(Swe
     }
 }
 
+constexpr int kWideMaxCat = 256;
+
+// Many-categories variant (32 < C <= 255): the per-lane category counts live in LDS columns instead of registers, all
+// category loops are runtime loops, and the sqrt tables are read from global memory.  Slower per pair than k_sweep,
+// but independent of the category count in registers.  WPB = anchor pairs (wavefronts) per workgroup.
+template <int MODE, int FMODE, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
+    constexpr int TILE = kSweepTile;
+    constexpr bool LDSTAB = false;
+    constexpr bool H2 = (MODE != MODE_GEN);
+    constexpr int NT = LDSTAB ? kSqrtTab + 8 : 1;  // sqrt(k), 1/sqrt(k) for k <= 512 in LDS; otherwise read from the global tables
+    // Dynamic LDS: per-lane category counts, cnt[wave][category][lane] = count_A | count_B << 16.  A lane only
+    // ever touches its own column, and column-major placement makes every access conflict-free.
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+    __shared__ double t_sqrt[NT], t_rsqrt[NT];
+    __shared__ double w_s[kWideMaxCat], sw_s[kWideMaxCat];
+    __shared__ uint32_t carry_[WPB][kWideMaxCat];  // per category: counts before the current tile (A | B << 16)
+    __shared__ uint64_t sA_[WPB][TILE], sB_[WPB][TILE];
+    __shared__ uint8_t cA_[WPB][TILE], cB_[WPB][TILE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform => everything derived from it stays scalar
+    const DevConfig* __restrict__ cfgp = args.cfg;
+    const int C = cfgp->n_categories;
+    const double* __restrict__ g_sqrt = args.sqrt_tab;    // [65536] sqrt(k)
+    const double* __restrict__ g_rsqrt = args.rsqrt_tab;  // [65536] 1/sqrt(k)
+    if constexpr (LDSTAB)
+        for (int k = tid; k < NT; k += 64 * WPB) {
+            t_sqrt[k] = g_sqrt[k];
+            t_rsqrt[k] = g_rsqrt[k];
+        }
+    for (int c = tid; c < kWideMaxCat; c += 64 * WPB) {
+        const double wv_ = c < C ? cfgp->cat_w[c] : 0.0;
+        w_s[c] = wv_;
+        sw_s[c] = sqrt(wv_);
+    }
+    __syncthreads();
+    uint64_t* sA = sA_[wv];
+    uint64_t* sB = sB_[wv];
+    uint8_t* cA = cA_[wv];
+    uint8_t* cB = cB_[wv];
+    uint32_t* carry = carry_[wv];
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(smem_dyn) + (size_t)wv * C * 64 + lane;  // this lane's column: cnt[c * 64]
+
+    auto sqrt_cnt = [&](int k) -> double { if constexpr (LDSTAB) return t_sqrt[k]; else return g_sqrt[k]; };
+    auto rsqrt_cnt = [&](int k) -> double { if constexpr (LDSTAB) return t_rsqrt[k]; else return g_rsqrt[k]; };
+
+    for (int64_t p = (int64_t)blockIdx.x * WPB + wv; p < args.n_pairs; p += (int64_t)gridDim.x * WPB) {
+        int64_t ea = p, eb = p;
+        if (args.anchors) {
+            const int64_t ia_ = args.anchors[2 * p], ib_ = args.anchors[2 * p + 1];
+            // out-of-range anchors were flagged by k_mark_anchors; do not touch memory for them
+            if (ia_ < 0 || ib_ < 0 || ia_ >= args.n_slot_a || ib_ >= args.n_slot_b) {
+                if (lane == 0) args.out[p] = nan("");
+                continue;
+            }
+            ea = args.slot_a[ia_];
+            eb = args.slot_b[ib_];
+        }
+        const int nA = args.env_a.len[ea], nB = args.env_b.len[eb];
+        if (nA <= 0 || nB <= 0) {  // overflow / empty environment: already flagged by K1
+            if (lane == 0) args.out[p] = nan("");
+            continue;
+        }
+        const uint64_t* __restrict__ kA = args.env_a.key + ea * args.env_a.stride;
+        const uint64_t* __restrict__ kB = args.env_b.key + eb * args.env_b.stride;
+        const uint8_t* __restrict__ tA = args.env_a.cat + ea * args.env_a.stride;
+        const uint8_t* __restrict__ tB = args.env_b.cat + eb * args.env_b.stride;
+        const int wfi = args.wf_index ? args.wf_index[p] : 0;
+        if (wfi < 0 || wfi >= cfgp->n_wf) {
+            if (lane == 0) { atomicOr(&args.st->flags, ST_BAD_WF); args.out[p] = nan(""); }
+            continue;
+        }
+        constexpr bool WFANY = (FMODE == F_ANY);
+        WfRegs wf{};
+        if constexpr (FMODE != F_KEY) {
+            const WfEntry wfe = cfgp->wf[wfi];
+            wf = wf_load(wfe, cfgp->wf_params + wfe.offset);
+            if (kA[0] != 0ull || kB[0] != 0ull) {  // src/locohd.rs:74-77 (F_KEY: checked by the environment kernels)
+                if (lane == 0) { atomicOr(&args.st->flags, ST_FIRST_NOT_ZERO); args.out[p] = nan(""); }
+                continue;
+            }
+        }
+        auto cdf_of_key = [&](uint64_t k) -> double {
+            if constexpr (FMODE == F_KEY) return u2d(k);
+            else return cdf_dev<WFANY>(wf, u2d(k));
+        };
+
+        bool bad_cat = false, zero_norm = false;
+        // ---- per-lane state (category counts live in LDS) ------------------------------------------------
+        int totA = 1, totB = 1;      // points seen per side (incl. anchor)
+        double ra = 1.0, rb = 1.0;   // H2: 1/sqrt(total weight)
+        double na = 0.0, nb = 0.0;   // H2W: total weights
+        double D = 0.0;              // H2: sum_c sqrt(a_c * b_c)  (Bhattacharyya numerator)
+
+        // exact squared Hellinger distance in the literal difference-of-roots form (statistical_distances.rs:4-10)
+        auto exact_h2 = [&]() -> double {
+            double acc2 = 0.0;
+            for (int c = 0; c < C; ++c) {
+                const uint32_t v = cnt[c * 64];
+                double xa = sqrt_cnt((int)(v & 0xFFFFu)), xb = sqrt_cnt((int)(v >> 16));
+                if constexpr (MODE == MODE_H2W) { xa *= sw_s[c]; xb *= sw_s[c]; }
+                const double d = xa * ra - xb * rb;  // equal inputs cancel exactly
+                acc2 = fma(d, d, acc2);
+            }
+            return 0.5 * acc2;
+        };
+        auto distance = [&]() -> double {  // pmf.rs:85-88
+            if constexpr (H2) {
+                // H^2 = 1 - sum_c sqrt(p_c q_c): O(1) per event from the running D.  Its rounding error (~1e-16
+                // absolute) only matters when H^2 itself is tiny, so small values are recomputed in the exact form
+                // (which also returns exactly 0 for identical environments).
+                double h2 = 1.0 - (ra * rb) * D;
+                if (h2 < 1e-3) h2 = exact_h2();
+                return sqrt(h2);
+            } else {
+                double pn[kWideMaxCat], qn[kWideMaxCat];
+                double sa_ = 0.0, sb_ = 0.0;  // pmf.rs:67-68: fresh sums
+                for (int c = 0; c < C; ++c) {
+                    const uint32_t v = cnt[c * 64];
+                    pn[c] = w_s[c] * (double)(v & 0xFFFFu);
+                    qn[c] = w_s[c] * (double)(v >> 16);
+                    sa_ += pn[c];
+                    sb_ += qn[c];
+                }
+                if (sa_ == 0.0 || sb_ == 0.0) zero_norm = true;
+                for (int c = 0; c < C; ++c) { pn[c] /= sa_; qn[c] /= sb_; }
+                return sd_generic(cfgp->sd_kind, cfgp->sd_p0, cfgp->sd_p1, pn, qn, C);
+            }
+        };
+
+        // seed with the two anchors (:82-84): carry row and every lane's column
+        const int c0a = tA[0], c0b = tB[0];
+        if (c0a >= C || c0b >= C) bad_cat = true;
+        wave_sync_lds();
+        for (int c = lane; c < C; c += 64) carry[c] = (c == c0a ? 1u : 0u) | (c == c0b ? 0x10000u : 0u);
+        for (int c = 0; c < C; ++c) cnt[c * 64] = (c == c0a ? 1u : 0u) | (c == c0b ? 0x10000u : 0u);
+        if constexpr (H2) {
+            if (c0a == c0b && !bad_cat) D = (MODE == MODE_H2W) ? w_s[c0a & (kWideMaxCat - 1)] : 1.0;
+            if constexpr (MODE == MODE_H2W) {
+                na = w_s[c0a & (kWideMaxCat - 1)];
+                nb = w_s[c0b & (kWideMaxCat - 1)];
+                ra = 1.0 / sqrt(na);
+                rb = 1.0 / sqrt(nb);
+            }
+        }
+        wave_sync_lds();
+        double F_carry = cdf_of_key(kA[0]);  // F(0): both anchors sit at distance 0
+        double H_carry = bad_cat ? 0.0 : distance();
+        double acc = 0.0;
+
+        const int mA = nA - 1, mB = nB - 1, M = mA + mB;  // non-anchor events
+        int ia = 0, ib = 0;
+        for (int k0 = 0; k0 < M; k0 += TILE) {
+            const int T = min(TILE, M - k0);
+            const int nAt = min(TILE, mA - ia), nBt = min(TILE, mB - ib);
+            wave_sync_lds();  // previous tile fully consumed
+            for (int t = lane; t < nAt; t += 64) { sA[t] = kA[1 + ia + t]; cA[t] = tA[1 + ia + t]; }
+            for (int t = lane; t < nBt; t += 64) { sB[t] = kB[1 + ib + t]; cB[t] = tB[1 + ib + t]; }
+            wave_sync_lds();
+            // lane l owns merged events [d0, d1); each lane searches the END of its chunk
+            const int epl = (T + 63) >> 6;
+            const int d0 = min(lane * epl, T), d1 = min(d0 + epl, T);
+            const int i1 = merge_path(sA, nAt, sB, nBt, d1);
+            int i0 = __shfl_up(i1, 1);
+            if (lane == 0) i0 = 0;
+            const int iend = __builtin_amdgcn_readlane(i1, 63);
+            const int j0 = d0 - i0, j1 = d1 - i1;
+
+            // pass 1: histogram of this lane's chunk into its LDS column
+            for (int c = 0; c < C; ++c) cnt[c * 64] = 0u;
+            for (int i = i0; i < i1; ++i) {
+                const int ct = cA[i];
+                if (ct >= C) bad_cat = true; else cnt[ct * 64] += 1u;
+            }
+            for (int j = j0; j < j1; ++j) {
+                const int ct = cB[j];
+                if (ct >= C) bad_cat = true; else cnt[ct * 64] += 0x10000u;
+            }
+            // per category: wave64 inclusive scan (the carry of earlier tiles enters through lane 0); the exclusive
+            // prefix = counts at this lane's first event.  Both 16-bit halves scan at once (every count < 65536).
+            totA = 1 + ia + i0;
+            totB = 1 + ib + j0;
+            if constexpr (H2) D = 0.0;
+            if constexpr (MODE == MODE_H2W) na = nb = 0.0;
+            for (int c = 0; c < C; ++c) {
+                const uint32_t own = cnt[c * 64];
+                const uint32_t incl = wave_incl_scan_u32(own + (lane == 0 ? carry[c] : 0u));
+                const uint32_t excl = incl - own;
+                cnt[c * 64] = excl;
+                if (lane == 63) carry[c] = incl;
+                if constexpr (H2) {
+                    const int ca = (int)(excl & 0xFFFFu), cb = (int)(excl >> 16);
+                    if constexpr (MODE == MODE_H2W) {
+                        D += w_s[c] * (sqrt_cnt(ca) * sqrt_cnt(cb));
+                        na += w_s[c] * (double)ca;
+                        nb += w_s[c] * (double)cb;
+                    } else {
+                        D += sqrt_cnt(ca) * sqrt_cnt(cb);
+                    }
+                }
+            }
+            if constexpr (MODE == MODE_H2W) { ra = 1.0 / sqrt(na); rb = 1.0 / sqrt(nb); }
+            else if constexpr (MODE == MODE_H2U) { ra = rsqrt_cnt(totA); rb = rsqrt_cnt(totB); }
+
+            // pass 2: sequential sweep of this lane's events (the two list heads stay in registers)
+            int i = i0, j = j0;
+            uint64_t ka = (i < i1) ? sA[i] : kPadKey, kb = (j < j1) ? sB[j] : kPadKey;
+            double Fp = 0.0, Hp = 0.0, firstF = 0.0, local = 0.0;
+            for (int e = d0; e < d1; ++e) {
+                const bool takeA = (ka <= kb);  // an exhausted list shows the pad key (> every real key)
+                const uint64_t key = takeA ? ka : kb;
+                const int ct = takeA ? cA[i] : cB[j];
+                if (takeA) { ++i; ka = (i < i1) ? sA[i] : kPadKey; } else { ++j; kb = (j < j1) ? sB[j] : kPadKey; }
+                const double F = cdf_of_key(key);
+                if (e == d0) firstF = F; else local += (F - Fp) * Hp;
+                // pmf.rs:47-63: one more point of category ct on one side
+                const bool okc = ct < C;
+                const int cs = okc ? ct : 0;
+                const uint32_t old = cnt[cs * 64];
+                cnt[cs * 64] = old + (okc ? (takeA ? 1u : 0x10000u) : 0u);
+                totA += takeA ? 1 : 0;
+                totB += takeA ? 0 : 1;
+                if constexpr (H2) {
+                    const int cntA_ = (int)(old & 0xFFFFu), cntB_ = (int)(old >> 16);
+                    const int mine = takeA ? cntA_ : cntB_, other = takeA ? cntB_ : cntA_;
+                    double delta = (sqrt_cnt(mine + 1) - sqrt_cnt(mine)) * sqrt_cnt(other);
+                    if constexpr (MODE == MODE_H2W) {
+                        const double wv_ = w_s[cs];
+                        delta *= wv_;
+                        na += takeA ? wv_ : 0.0;
+                        nb += takeA ? 0.0 : wv_;
+                        const double r = 1.0 / sqrt(takeA ? na : nb);
+                        ra = takeA ? r : ra;
+                        rb = takeA ? rb : r;
+                    } else {
+                        const double r = rsqrt_cnt(takeA ? totA : totB);
+                        ra = takeA ? r : ra;
+                        rb = takeA ? rb : r;
+                    }
+                    D += okc ? delta : 0.0;
+                }
+                Hp = distance();
+                Fp = F;
+            }
+            // stitch lane chunks: (F_first - F_last_of_previous_lane) * H_before_my_first_event
+            double prevF = shfl_up_f64(Fp, 1), prevH = shfl_up_f64(Hp, 1);
+            if (lane == 0) { prevF = F_carry; prevH = H_carry; }
+            if (d0 < d1) local += (firstF - prevF) * prevH;
+            acc += local;
+            const int last = (T - 1) / epl;
+            F_carry = shfl_f64(Fp, last);
+            H_carry = shfl_f64(Hp, last);
+            ia += iend;
+            ib += T - iend;
+        }
+        // wave64 butterfly reduction + the last interval to +inf (:165-171,204-210,212-221)
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) acc += shfl_xor_f64(acc, m);
+        const double Finf = cfgp->wf_finf[wfi];
+        acc += (Finf - F_carry) * H_carry;
+        const unsigned long long anybad = __ballot(bad_cat), anyzero = __ballot(zero_norm);
+        if (lane == 0) {
+            if (anybad) { atomicOr(&args.st->flags, ST_BAD_CATEGORY); acc = nan(""); }
+            if (anyzero) atomicOr(&args.st->flags, ST_ZERO_NORM);
+            args.out[p] = acc;
+        }
+    }
+}
+
+
 template <int MODE, int FMODE, bool LDSTAB>
 static void launch_sweep_mode(hipStream_t s, int cmax, unsigned grid, const SweepArgs& a) {
     constexpr int NTH = 64 * kSweepWaves;
@@ -881,8 +1151,44 @@ static void launch_sweep_f(hipStream_t s, int cmax, unsigned grid, int fmode, co
     else launch_sweep_mode<MODE, F_ANY, LDSTAB>(s, cmax, grid, a);
 }
 
+template <int MODE>
+static void launch_sweep_wide(hipStream_t s, int n_cat, int64_t n_pairs, int fmode, const SweepArgs& a) {
+    // dynamic LDS = WPB * C * 64 * 4 bytes of per-lane count columns
+    if (n_cat <= 64) {
+        const int64_t blocks = (n_pairs + 3) / 4;
+        const unsigned grid = (unsigned)(blocks < 4096 ? blocks : 4096);
+        const size_t dyn = (size_t)4 * n_cat * 256;
+        if (fmode == F_KEY) k_sweep_wide<MODE, F_KEY, 4><<<grid, 256, dyn, s>>>(a);
+        else k_sweep_wide<MODE, F_ANY, 4><<<grid, 256, dyn, s>>>(a);
+    } else {
+        const unsigned grid = (unsigned)(n_pairs < 8192 ? n_pairs : 8192);
+        const size_t dyn = (size_t)n_cat * 256;
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_wide<MODE, F_KEY, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 256);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_wide<MODE, F_ANY, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 256);
+            attr = true;
+        }
+        if (fmode == F_KEY) k_sweep_wide<MODE, F_KEY, 1><<<grid, 64, dyn, s>>>(a);
+        else k_sweep_wide<MODE, F_ANY, 1><<<grid, 64, dyn, s>>>(a);
+    }
+}
+
 void launch_sweep(hipStream_t s, int n_categories, bool hellinger2, bool unit_weights, bool wf_pow, const SweepArgs& a) {
     if (a.n_pairs <= 0) return;
+    {
+        bool wide = n_categories > 32;
+        if (const char* f = getenv("LCHD_FORCE_WIDE")) wide = wide || atoi(f) != 0;  // test hook
+        if (wide) {
+            bool h2 = hellinger2;
+            if (const char* f = getenv("LCHD_FORCE_GENERIC")) h2 = h2 && atoi(f) == 0;
+            const int fmode = (a.env_a.cdf_keys && a.env_b.cdf_keys) ? F_KEY : F_ANY;
+            if (!h2) launch_sweep_wide<MODE_GEN>(s, n_categories, a.n_pairs, fmode, a);
+            else if (unit_weights) launch_sweep_wide<MODE_H2U>(s, n_categories, a.n_pairs, fmode, a);
+            else launch_sweep_wide<MODE_H2W>(s, n_categories, a.n_pairs, fmode, a);
+            return;
+        }
+    }
     const int64_t blocks = (a.n_pairs + kSweepWaves - 1) / kSweepWaves;
     const unsigned grid = (unsigned)(blocks < 4096 ? blocks : 4096);  // grid-stride: LDS tables are built once per block
     int cmax = n_categories;

@@ -220,7 +220,7 @@ def test_large_environments_retry(lh, oracle):
 
 def test_many_categories(lh, oracle):
     rng = np.random.default_rng(19)
-    for ncat in (1, 8, 9, 16, 17, 25, 32):
+    for ncat in (1, 8, 9, 16, 17, 25, 32, 33, 64, 65, 200, 255):
         cats = [f"c{i}" for i in range(ncat)]
         sa, xa = cloud(rng, 300, box=12.0, cats=cats)
         sb, xb = cloud(rng, 300, box=12.0, cats=cats)
@@ -232,6 +232,11 @@ def test_many_categories(lh, oracle):
 
         got, want = both(lh, oracle, run)
         assert np.max(np.abs(got - want)) < TIGHT, ncat
+
+
+def test_too_many_categories_is_loud(lh):
+    with pytest.raises(NotImplementedError):
+        lh.LoCoHD([f"c{i}" for i in range(256)]).from_anchors(["c0"], ["c0"], [0.0], [0.0])
 
 
 def test_error_behaviour(lh):
@@ -267,7 +272,9 @@ def test_error_behaviour(lh):
 
 @pytest.mark.parametrize("hook", [{"LCHD_FORCE_CMAX": "8"}, {"LCHD_FORCE_CMAX": "12"}, {"LCHD_FORCE_CMAX": "16"},
                                   {"LCHD_FORCE_CMAX": "24"}, {"LCHD_FORCE_CMAX": "32"}, {"LCHD_FORCE_GENERIC": "1"},
-                                  {"LCHD_FORCE_BIGENV": "1"}, {"LCHD_FORCE_GENERIC": "1", "LCHD_FORCE_CMAX": "16"}])
+                                  {"LCHD_FORCE_BIGENV": "1"}, {"LCHD_FORCE_GENERIC": "1", "LCHD_FORCE_CMAX": "16"},
+                                  {"LCHD_FORCE_WIDE": "1"}, {"LCHD_FORCE_WIDE": "1", "LCHD_FORCE_GENERIC": "1"},
+                                  {"LCHD_NO_CDF_KEYS": "1"}, {"LCHD_NO_CDF_KEYS": "1", "LCHD_FORCE_WIDE": "1"}])
 def test_every_sweep_kernel_variant(lh, oracle, hook, monkeypatch):
     """The sweep kernel is instantiated per category-slot count / distance family / table placement; the launcher's
     test hooks force each instantiation onto the same inputs (an -O3 miscompile of one variant was caught this way)."""
