@@ -360,10 +360,19 @@ class LoCoHD:
     # ---- argument conversion helpers ------------------------------------------------------------------------
     @staticmethod
     def _matrix(m) -> np.ndarray:
+        """Vec<Vec<f64>> -> rectangular f64 matrix.  Ragged rows (the reference sorts each row with a prefix of seq,
+        utils.rs:25-39) are padded with +inf: points at infinite distance only ever add zero-width intervals
+        (F(inf) - F(inf) = 0), so the scores are unchanged."""
         try:
             arr = _f64(m)
-        except ValueError as e:  # ragged Vec<Vec<f64>>
-            raise NotImplementedError("ragged distance matrices are not supported by the HIP core") from e
+        except ValueError:
+            rows = [_f64(r).reshape(-1) for r in m]
+            width = max((len(r) for r in rows), default=0)
+            if any(len(r) == 0 for r in rows):
+                raise N.PanicException("index out of bounds: empty distance row (src/locohd.rs:74)")
+            arr = np.full((len(rows), width), np.inf)
+            for k, r in enumerate(rows):
+                arr[k, : len(r)] = r
         if arr.ndim == 1 and arr.size == 0:
             arr = arr.reshape(0, 0)
         if arr.ndim != 2:

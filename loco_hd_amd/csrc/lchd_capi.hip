@@ -583,9 +583,9 @@ extern "C" int lchd_from_primitives_dev(lchd_ctx* c, lchd_cloud* a, lchd_cloud* 
         if (f & ST_BAD_ANCHOR) return status_to_rc(f, DRV_PRIMS);
         if (f & ST_ENV_OVERFLOW) {
             const int64_t need = c->h_status->max_env;
-            if (need > 4096)
-                return fail(LCHD_EUNSUPPORTED, "an environment holds %lld points; this build sorts at most 4096 per environment "
-                                               "in the thresholded path", (long long)need);
+            if (need > 16384)
+                return fail(LCHD_EUNSUPPORTED, "an environment holds %lld points; this build sorts at most 16384 per environment",
+                            (long long)need);
             cap = next_pow2_host(need);
             c->cap_hint = cap;
             continue;

@@ -252,13 +252,16 @@ __device__ __forceinline__ bool tag_pair_accepted(const DevConfig& cfg, int32_t 
 //   distance        sqrt(sum(diff^2)), same summation order as utils.rs:1-8                 (:537)
 //   sort            ascending distance                                                       (:541)
 // ------------------------------------------------------------------------------------------------
-template <int CAP>
-__global__ __launch_bounds__(64) void k_env_cells(const DevConfig* __restrict__ cfgp, CloudView c, GridView g,
-                                                  const uint32_t* __restrict__ uniq, int side, double thr,
+template <int NT>
+__global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ cfgp, CloudView c, GridView g,
+                                                  const uint32_t* __restrict__ uniq, int side, double thr, int cap,
                                                   EnvStore env, DeviceStatus* st) {
-    __shared__ uint64_t key[CAP];
-    __shared__ uint8_t val[CAP];
-    const int lane = threadIdx.x;
+    // dynamic LDS: cap * 9 bytes (u64 keys, then u8 categories)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* key = reinterpret_cast<uint64_t*>(smem);
+    uint8_t* val = smem + (size_t)cap * 8;
+    __shared__ int count_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t e = blockIdx.x;
     if (e >= (int64_t)st->n_unique[side]) return;
     const DevConfig cfg = *cfgp;
@@ -270,14 +273,18 @@ __global__ __launch_bounds__(64) void k_env_cells(const DevConfig* __restrict__ 
     const int cy = cell_coord(ay, g.min[1], g.inv[1], g.dim[1]);
     const int cz = cell_coord(az, g.min[2], g.inv[2], g.dim[2]);
     const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
+    if (NT > 64) {
+        if (tid == 0) count_s = 0;
+        __syncthreads();
+    }
 
-    int count = 0;
+    int count = 0;  // NT == 64: the wave's running count; NT > 64: unused (count_s is the shared cursor)
     for (int zz = max(cz - 1, 0); zz <= min(cz + 1, g.dim[2] - 1); ++zz) {
         for (int yy = max(cy - 1, 0); yy <= min(cy + 1, g.dim[1] - 1); ++yy) {
             // the (up to) three x-neighbour cells of one (y,z) row are contiguous in the cell-ordered arrays
             const int row = (zz * g.dim[1] + yy) * g.dim[0];
             const int beg = (int)g.cell_start[row + x0], end = (int)g.cell_start[row + x1 + 1];
-            for (int base = beg; base < end; base += 64) {
+            for (int base = beg + wave * 64; base < end; base += NT) {
                 const int idx = base + lane;
                 bool ok = false;
                 double d2 = 0.0;
@@ -289,9 +296,14 @@ __global__ __launch_bounds__(64) void k_env_cells(const DevConfig* __restrict__ 
                     if (d2 < thr2) ok = (g.porig[idx] == anchor) || tag_pair_accepted(cfg, atag, g.ptag[idx]);
                 }
                 const unsigned long long m = __ballot(ok);
+                int wbase = count;
+                if (NT > 64) {  // several waves append concurrently: reserve a slice of the list per wave-iteration
+                    if (lane == 0 && m) wbase = atomicAdd(&count_s, __popcll(m));
+                    wbase = __shfl(wbase, 0);
+                }
                 if (ok) {
-                    const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
-                    if (pos < CAP) {
+                    const int pos = wbase + __popcll(m & ((1ull << lane) - 1ull));
+                    if (pos < cap) {
                         key[pos] = d2u(sqrt(d2));
                         val[pos] = g.pcat[idx];
                     }
@@ -300,8 +312,12 @@ __global__ __launch_bounds__(64) void k_env_cells(const DevConfig* __restrict__ 
             }
         }
     }
-    if (count > CAP) {  // the host re-launches a larger variant
-        if (lane == 0) {
+    if (NT > 64) {
+        __syncthreads();
+        count = count_s;
+    }
+    if (count > cap) {  // the host re-launches a larger variant
+        if (tid == 0) {
             atomicOr(&st->flags, ST_ENV_OVERFLOW);
             atomicMax(&st->max_env, (uint32_t)count);
             env.len[e] = 0;
@@ -309,32 +325,40 @@ __global__ __launch_bounds__(64) void k_env_cells(const DevConfig* __restrict__ 
         return;
     }
     if (count == 0) {
-        if (lane == 0) { atomicOr(&st->flags, ST_EMPTY_ENV); env.len[e] = 0; }
+        if (tid == 0) { atomicOr(&st->flags, ST_EMPTY_ENV); env.len[e] = 0; }
         return;
     }
     const int n2 = next_pow2(count);
-    for (int i = count + lane; i < n2; i += 64) { key[i] = kPadKey; val[i] = 0; }
+    for (int i = count + tid; i < n2; i += NT) { key[i] = kPadKey; val[i] = 0; }
     __syncthreads();
-    bitonic_sort_lds<64>(key, val, n2, lane);
-    if (env.cdf_keys) keys_to_cdf_lds<64>(key, count, lane, cfgp);
+    bitonic_sort_lds<NT>(key, val, n2, tid);
+    if (env.cdf_keys) keys_to_cdf_lds<NT>(key, count, tid, cfgp);
     uint64_t* ok_ = env.key + e * env.stride;
     uint8_t* oc_ = env.cat + e * env.stride;
-    for (int i = lane; i < count; i += 64) { ok_[i] = key[i]; oc_[i] = val[i]; }
-    if (lane == 0) env.len[e] = count;
+    for (int i = tid; i < count; i += NT) { ok_[i] = key[i]; oc_[i] = val[i]; }
+    if (tid == 0) env.len[e] = count;
 }
 
 bool launch_env_cells(hipStream_t s, int cap, const DevConfig* cfg, const CloudView& c, const GridView& g,
                       const uint32_t* uniq, int side, int64_t max_envs, double thr, EnvStore env, DeviceStatus* st) {
     if (max_envs <= 0) return true;
-    const dim3 grid((unsigned)max_envs), block(64);
-    switch (cap) {
-        case 256: k_env_cells<256><<<grid, block, 0, s>>>(cfg, c, g, uniq, side, thr, env, st); return true;
-        case 512: k_env_cells<512><<<grid, block, 0, s>>>(cfg, c, g, uniq, side, thr, env, st); return true;
-        case 1024: k_env_cells<1024><<<grid, block, 0, s>>>(cfg, c, g, uniq, side, thr, env, st); return true;
-        case 2048: k_env_cells<2048><<<grid, block, 0, s>>>(cfg, c, g, uniq, side, thr, env, st); return true;
-        case 4096: k_env_cells<4096><<<grid, block, 0, s>>>(cfg, c, g, uniq, side, thr, env, st); return true;
-        default: return false;
+    if (cap < 64 || cap > 16384 || (cap & (cap - 1))) return false;
+    const dim3 grid((unsigned)max_envs);
+    const size_t lds = (size_t)cap * 9;
+    if (cap <= 2048) {
+        k_env_cells<64><<<grid, 64, lds, s>>>(cfg, c, g, uniq, side, thr, cap, env, st);
+    } else if (cap <= 4096) {
+        k_env_cells<256><<<grid, 256, lds, s>>>(cfg, c, g, uniq, side, thr, cap, env, st);
+    } else {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_cells<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      16384 * 9);
+            attr_set = true;
+        }
+        k_env_cells<1024><<<grid, 1024, lds, s>>>(cfg, c, g, uniq, side, thr, cap, env, st);
     }
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------------

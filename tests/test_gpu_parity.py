@@ -234,6 +234,49 @@ def test_many_categories(lh, oracle):
         assert np.max(np.abs(got - want)) < TIGHT, ncat
 
 
+def test_ragged_distance_matrix(lh, oracle):
+    """Rows of different lengths: the reference co-sorts each row with a prefix of seq (utils.rs:25-39)."""
+    rng = np.random.default_rng(31)
+    s, x = cloud(rng, 40, box=8.0)
+    full = np.sqrt(((x[:, None, :] - x[None, :, :]) ** 2).sum(-1))
+    lens = rng.integers(25, 41, 40)
+    ragged = []
+    for i in range(25):  # row i must contain its own 0 => keep at least i+1 columns
+        ragged.append(full[i, : max(int(lens[i]), i + 1)].tolist())
+    lchd = lh.LoCoHD(CATS, lh.WeightFunction("hyper_exp", [1.0, 0.3]))
+    got = np.asarray(lchd.from_dmxs(s, s, ragged, [r[::1] for r in ragged]))
+    assert np.max(np.abs(got)) == 0.0
+    lo = oracle.LoCoHD(CATS, oracle.WeightFunction("hyper_exp", [1.0, 0.3]))
+    other = full[:25, :40]
+    want = []
+    for i in range(25):
+        (seq_r, d_r), (seq_o, d_o) = _sorted_env(s, ragged[i]), _sorted_env(s, other[i])
+        want.append(lo.from_anchors(seq_r, seq_o, d_r, d_o))
+    got = np.asarray(lchd.from_dmxs(s, s, ragged, other))
+    assert np.max(np.abs(got - np.asarray(want))) < TIGHT
+
+
+def _sorted_env(seq, row):
+    row = np.asarray(row, dtype=float)
+    order = np.argsort(row, kind="stable")
+    return [seq[k] for k in order], row[order].tolist()
+
+
+def test_big_environments_block_kernel(lh, oracle):
+    """Environments of ~6000 points: the multi-wave environment kernel (capacity 8192) and the global sqrt tables."""
+    rng = np.random.default_rng(37)
+    sa, xa = cloud(rng, 7000, box=6.0)
+    sb, xb = cloud(rng, 6500, box=6.0)
+    anchors = [(int(i), int(j)) for i, j in zip(rng.integers(0, 7000, 6), rng.integers(0, 6500, 6))]
+
+    def run(mod):
+        lchd = mod.LoCoHD(CATS, mod.WeightFunction("hyper_exp", [1.0, 0.2]))
+        return np.asarray(lchd.from_primitives(prims(mod, sa, xa), prims(mod, sb, xb), anchors, 11.0))
+
+    got, want = both(lh, oracle, run)
+    assert np.max(np.abs(got - want)) < TIGHT
+
+
 def test_too_many_categories_is_loud(lh):
     with pytest.raises(NotImplementedError):
         lh.LoCoHD([f"c{i}" for i in range(256)]).from_anchors(["c0"], ["c0"], [0.0], [0.0])
