@@ -56,6 +56,28 @@ __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
     return ((uint64_t)hi << 32) | lo;
 }
 
+// Inclusive prefix sum across the 64 lanes with DPP adds (row_shr 1/2/4/8 inside each row of 16 lanes, then the
+// two row broadcasts): 6 VALU instructions, no LDS crossbar traffic.  Lanes without a source add the identity 0.
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x) {
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return (uint32_t)v;
+}
+// 16-bit count fields never carry into each other (every count < 65536), so a u64 of four fields scans as two u32
+__device__ __forceinline__ uint64_t wave_incl_scan_fields(uint64_t x) {
+    const uint32_t lo = wave_incl_scan_u32((uint32_t)x), hi = wave_incl_scan_u32((uint32_t)(x >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
+    const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, l), hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K0: uniform grid.  Points keep their f64 coordinates; only the bucketing uses the grid.
 // ------------------------------------------------------------------------------------------------
@@ -187,6 +209,14 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t* key, uint8_t* val, in
     }
 }
 
+// hyper_exp and uniform are the common weight functions and stay inline; the pow-based CDFs are called.
+__device__ __noinline__ double cdf_pow_based(int kind, const double* p, int np, double x) { return cdf_eval(kind, p, np, x); }
+__device__ __forceinline__ double cdf_lean(int kind, const double* __restrict__ p, int np, double x) {
+    if (kind == WF_HYPER_EXP) return cdf_hyper_exp(p, np, x);
+    if (kind == WF_UNIFORM) return cdf_uniform(p, x);
+    return cdf_pow_based(kind, p, np, x);
+}
+
 // Single-weight-function configurations: replace the sorted distances by F(distance) so that the sweep kernel never
 // evaluates a CDF (every pair that re-uses this environment would recompute the same values).  F is non-decreasing,
 // so the order is unchanged; a running maximum removes last-bit inversions of the floating-point CDF (the merge in
@@ -198,7 +228,7 @@ __device__ __forceinline__ void keys_to_cdf_lds(uint64_t* key, int n, int tid, c
     const int chunk = (n + NT - 1) / NT, lo = min(tid * chunk, n), hi = min(lo + chunk, n);
     uint64_t m = 0;
     for (int i = lo; i < hi; ++i) {
-        const uint64_t f = d2u(cdf_eval(wf.kind, prm, wf.n_params, u2d(key[i])) + 0.0);
+        const uint64_t f = d2u(cdf_lean(wf.kind, prm, wf.n_params, u2d(key[i])) + 0.0);
         m = f > m ? f : m;
         key[i] = m;
     }
@@ -366,50 +396,142 @@ bool launch_env_cells(hipStream_t s, int cap, const DevConfig* cfg, const CloudV
 // utils.rs:10-22 + :25-39) or from_dmxs (a caller-supplied distance-matrix row, src/locohd.rs:439-440).
 // Dynamic LDS: n2 * 9 bytes.
 // ------------------------------------------------------------------------------------------------
+constexpr int kRowBuckets = 2048;     // distance buckets of the dense-row sort
+constexpr int kRowCoarse = 256;       // uniform bins of the row's empirical distance CDF
+constexpr int kRowBucketLimit = 64;   // a fuller bucket sends the row to the bitonic network instead
+
 template <int NT>
 __global__ __launch_bounds__(NT) void k_env_rows(const DevConfig* __restrict__ cfgp, CloudView c, const double* __restrict__ dmx,
                                                  int64_t ld, int64_t row_len, int n2, EnvStore env, DeviceStatus* st) {
+    // Sorting one row of n <= 16384 distances in O(n): an empirical CDF of the row on kRowCoarse uniform bins of
+    // [0, d_max] gives every point an interpolated rank; rank * kRowBuckets / n is its bucket, so buckets hold
+    // ~n / kRowBuckets points whatever the shape of the cloud.  One LDS histogram + scan + scatter puts the points
+    // into bucket order, then one thread finishes each bucket with an insertion sort on the exact f64 keys.  The map
+    // distance -> bucket is monotone, which is all correctness needs; a pathological row (a bucket with more than
+    // kRowBucketLimit points, e.g. thousands of identical distances) takes the bitonic network instead.
+    // Distances are recomputed in every phase (3 L2-resident loads + a sqrt) instead of being kept in registers.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* key = reinterpret_cast<uint64_t*>(smem);
     uint8_t* val = smem + (size_t)n2 * 8;
-    const int tid = threadIdx.x;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem + (size_t)n2 * 9 + ((16 - (((size_t)n2 * 9) & 15)) & 15));  // [kRowBuckets + 1]
+    __shared__ double red_max[16];
+    __shared__ uint32_t red_cnt[16];
+    __shared__ uint32_t scan_carry;
+    __shared__ uint32_t coarse[kRowCoarse + 1], cum[kRowCoarse + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t r = blockIdx.x;
     const int n = (int)row_len;
+    const double* __restrict__ row = dmx ? dmx + r * ld : nullptr;
+    double ax = 0.0, ay = 0.0, az = 0.0;
+    if (!dmx) { ax = c.x[r]; ay = c.y[r]; az = c.z[r]; }
+    auto dist_of = [&](int i, bool& bad) -> double {
+        if (dmx) {
+            double v = row[i];
+            if (!(v >= 0.0)) { bad = true; v = 0.0; }  // negative or NaN
+            return v + 0.0;                              // -0.0 -> +0.0
+        }
+        const double dx = ax - c.x[i], dy = ay - c.y[i], dz = az - c.z[i];
+        double d2 = dx * dx;  // utils.rs:1-8 order, uncontracted
+        d2 = d2 + dy * dy;
+        d2 = d2 + dz * dz;
+        return sqrt(d2);
+    };
+
+    // 1. largest finite distance
     bool bad = false;
-    if (dmx) {
-        const double* row = dmx + r * ld;
-        for (int i = tid; i < n2; i += NT) {
-            uint64_t k = kPadKey;
-            uint8_t v = 0;
-            if (i < n) {
-                double d = row[i];
-                if (!(d >= 0.0)) { bad = true; d = 0.0; }  // negative or NaN
-                k = d2u(d + 0.0);                            // -0.0 -> +0.0
-                v = c.cat[i];
-            }
-            key[i] = k;
-            val[i] = v;
-        }
-    } else {
-        const double ax = c.x[r], ay = c.y[r], az = c.z[r];
-        for (int i = tid; i < n2; i += NT) {
-            uint64_t k = kPadKey;
-            uint8_t v = 0;
-            if (i < n) {
-                const double dx = ax - c.x[i], dy = ay - c.y[i], dz = az - c.z[i];
-                double d2 = dx * dx;
-                d2 = d2 + dy * dy;
-                d2 = d2 + dz * dz;
-                k = d2u(sqrt(d2));
-                v = c.cat[i];
-            }
-            key[i] = k;
-            val[i] = v;
-        }
+    double dmax = 0.0;
+    for (int i = tid; i < n; i += NT) {
+        const double v = dist_of(i, bad);
+        if (v < 1.0e300 && v > dmax) dmax = v;
     }
     if (bad) atomicOr(&st->flags, ST_BAD_DISTANCE);
+    for (int m = 32; m > 0; m >>= 1) dmax = fmax(dmax, shfl_xor_f64(dmax, m));
+    if (lane == 0) red_max[wave] = dmax;
+    for (int b = tid; b <= kRowBuckets; b += NT) hist[b] = 0u;
+    for (int b = tid; b <= kRowCoarse; b += NT) coarse[b] = 0u;
+    if (tid == 0) scan_carry = 0;
     __syncthreads();
-    bitonic_sort_lds<NT>(key, val, n2, tid);
+    for (int w = 0; w < NT / 64; ++w) dmax = fmax(dmax, red_max[w]);
+    // 2. empirical CDF on the coarse bins
+    const double inv_w = dmax > 0.0 ? (double)kRowCoarse / dmax : 0.0;
+    for (int i = tid; i < n; i += NT) {
+        const double v = dist_of(i, bad);
+        if (v <= dmax) atomicAdd(&coarse[min((int)(v * inv_w), kRowCoarse - 1)], 1u);
+    }
+    __syncthreads();
+    if (wave == 0) {  // cum[b] = points below bin b
+        uint32_t carry = 0;
+        for (int base = 0; base < kRowCoarse; base += 64) {
+            const uint32_t v = coarse[base + lane];
+            const uint32_t incl = wave_incl_scan_u32(v);
+            cum[base + lane] = carry + incl - v;
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        if (lane == 0) cum[kRowCoarse] = carry;
+    }
+    __syncthreads();
+    const double rank_scale = n > 0 ? (double)kRowBuckets / (double)n : 0.0;
+    auto bucket_of = [&](double v) -> int {
+        if (!(v <= dmax)) return kRowBuckets - 1;  // +inf entries of a distance matrix
+        const double t = v * inv_w;
+        const int bin = min((int)t, kRowCoarse - 1);
+        const double frac = fmin(t - (double)bin, 1.0);
+        const double q = ((double)cum[bin] + frac * (double)coarse[bin]) * rank_scale;
+        return q < (double)kRowBuckets ? (int)q : kRowBuckets - 1;
+    };
+    // 3. bucket histogram
+    uint32_t biggest = 0;
+    for (int i = tid; i < n; i += NT) biggest = max(biggest, atomicAdd(&hist[bucket_of(dist_of(i, bad))], 1u) + 1u);
+    for (int m = 32; m > 0; m >>= 1) biggest = max(biggest, (uint32_t)__shfl_xor((int)biggest, m));
+    if (lane == 0) red_cnt[wave] = biggest;
+    __syncthreads();
+    for (int w = 0; w < NT / 64; ++w) biggest = max(biggest, red_cnt[w]);
+
+    if (biggest > (uint32_t)kRowBucketLimit) {
+        for (int i = tid; i < n2; i += NT) {
+            key[i] = i < n ? d2u(dist_of(i, bad)) : kPadKey;
+            val[i] = i < n ? c.cat[i] : (uint8_t)0;
+        }
+        __syncthreads();
+        bitonic_sort_lds<NT>(key, val, n2, tid);
+    } else {
+        // 4. exclusive scan: hist[b] = first slot of bucket b
+        for (int base = 0; base < kRowBuckets; base += NT) {
+            const int b = base + tid;
+            const uint32_t v = b < kRowBuckets ? hist[b] : 0u;
+            const uint32_t incl = wave_incl_scan_u32(v);
+            if (lane == 63) red_cnt[wave] = incl;
+            __syncthreads();
+            uint32_t wpre = 0;
+            for (int w = 0; w < wave; ++w) wpre += red_cnt[w];
+            const uint32_t carry = scan_carry;
+            if (b < kRowBuckets) hist[b] = carry + wpre + incl - v;
+            __syncthreads();
+            if (tid == NT - 1) scan_carry = carry + wpre + incl;
+            __syncthreads();
+        }
+        // 5. scatter; the bucket cursor advances in place, so afterwards hist[b] = END of bucket b
+        for (int i = tid; i < n; i += NT) {
+            const double v = dist_of(i, bad);
+            const uint32_t pos = atomicAdd(&hist[bucket_of(v)], 1u);
+            key[pos] = d2u(v);
+            val[pos] = c.cat[i];
+        }
+        __syncthreads();
+        // 6. finish every bucket with an insertion sort on the exact keys
+        for (int b = tid; b < kRowBuckets; b += NT) {
+            const int lo = b ? (int)hist[b - 1] : 0, hi = (int)hist[b];
+            for (int i = lo + 1; i < hi; ++i) {
+                const uint64_t k = key[i];
+                const uint8_t v = val[i];
+                int j = i - 1;
+                while (j >= lo && key[j] > k) { key[j + 1] = key[j]; val[j + 1] = val[j]; --j; }
+                key[j + 1] = k;
+                val[j + 1] = v;
+            }
+        }
+        __syncthreads();
+    }
     if (tid == 0) {
         env.len[r] = n;
         if (n > 0 && key[0] != 0ull) atomicOr(&st->flags, ST_FIRST_NOT_ZERO);  // src/locohd.rs:74-77, on the distance
@@ -425,7 +547,7 @@ bool launch_env_rows(hipStream_t s, int cap, const DevConfig* cfg, const CloudVi
                      int64_t n_rows, int64_t row_len, EnvStore env, DeviceStatus* st) {
     if (n_rows <= 0) return true;
     if (cap > 16384 || row_len > cap) return false;
-    const size_t lds = (size_t)cap * 9;
+    const size_t lds = (size_t)cap * 9 + 16 + (size_t)(kRowBuckets + 1) * sizeof(uint32_t);
     const dim3 grid((unsigned)n_rows);
     if (cap <= 1024) {
         k_env_rows<64><<<grid, 64, lds, s>>>(cfg, c, dmx, ld, row_len, cap, env, st);
@@ -435,7 +557,7 @@ bool launch_env_rows(hipStream_t s, int cap, const DevConfig* cfg, const CloudVi
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_rows<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                16384 * 9);
+                                16384 * 9 + 16 + (kRowBuckets + 1) * 4);
             attr_set = true;
         }
         k_env_rows<1024><<<grid, 1024, lds, s>>>(cfg, c, dmx, ld, row_len, cap, env, st);
@@ -495,28 +617,6 @@ __device__ __forceinline__ int merge_path(const uint64_t* A, int nA, const uint6
     return lo;
 }
 
-// Inclusive prefix sum across the 64 lanes with DPP adds (row_shr 1/2/4/8 inside each row of 16 lanes, then the
-// two row broadcasts): 6 VALU instructions, no LDS crossbar traffic.  Lanes without a source add the identity 0.
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x) {
-    int v = (int)x;
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
-    return (uint32_t)v;
-}
-// 16-bit count fields never carry into each other (every count < 65536), so a u64 of four fields scans as two u32
-__device__ __forceinline__ uint64_t wave_incl_scan_fields(uint64_t x) {
-    const uint32_t lo = wave_incl_scan_u32((uint32_t)x), hi = wave_incl_scan_u32((uint32_t)(x >> 32));
-    return ((uint64_t)hi << 32) | lo;
-}
-__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
-    const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, l), hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
-    return ((uint64_t)hi << 32) | lo;
-}
-
 // spread the four 4-bit fields of the low 16 bits of x into four 16-bit fields
 __device__ __forceinline__ uint64_t spread4(uint64_t x) {
     x &= 0xFFFFull;
@@ -525,8 +625,6 @@ __device__ __forceinline__ uint64_t spread4(uint64_t x) {
     return x;
 }
 
-// hyper_exp and uniform are the common weight functions and stay inline; the pow-based CDFs are called.
-__device__ __noinline__ double cdf_pow_based(int kind, const double* p, int np, double x) { return cdf_eval(kind, p, np, x); }
 // One pair's weight function.  hyper_exp with <= 4 terms and uniform keep their parameters in (scalar)
 // registers; everything else goes through the out-of-line evaluator with the parameter pointer.
 struct WfRegs {
