@@ -8,7 +8,9 @@ entry point fails loudly -- there is no Python/CPU fallback for the scoring path
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
 import os
+import sys
 from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
@@ -78,6 +80,27 @@ _PROTOS = {
 _lib = None
 
 
+def _preload_torch_hip_runtime() -> None:
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so with the same soname as /opt/rocm's.  A process can only
+    hold one of them: if ours pulled in the system runtime first, a later `import torch` would find no GPU.  So when
+    torch is installed but not imported yet, map its bundled runtime first; our library then binds to it (exactly what
+    happens when torch is imported first)."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    cand = Path(spec.origin).parent / "lib" / "libamdhip64.so"
+    if cand.exists():
+        try:
+            C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load the HIP core.  Raises ImportError if it has not been built -- never falls back."""
     global _lib
@@ -87,6 +110,7 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `make -C {_PKG / 'csrc'}` (hipcc --offload-arch=gfx950). "
                 "loco_hd_amd has no CPU fallback for the scoring path."
             )
+        _preload_torch_hip_runtime()
         handle = C.CDLL(str(LIB_PATH))
         for name, (res, args) in _PROTOS.items():
             fn = getattr(handle, name)

@@ -1,0 +1,158 @@
+"""BASELINE.json configs 3-5 (and the dense variant of config 2) as parity cases: the synthetic inputs of
+SURVEY.md section 8(d) at sizes the CPU oracle finishes in seconds, plus size-independent properties at the full
+sizes (self-comparison = 0, symmetry, range, anchor order).  The full-size C2a / C5 runs with an oracle parity
+gate over ~10^5-10^6 pairs live in bench.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TIGHT = 1e-11
+CG_TYPES = ["Cent", "AmideC", "OH", "Pos", "Neg", "Aro", "Ali", "Sulf"]  # primitive_typings/coarse_grained_with_centroid.config.json
+
+
+@pytest.fixture(scope="module")
+def lh():
+    import loco_hd_amd
+
+    return loco_hd_amd
+
+
+def cg_structure(rng, n_res, side):
+    """3 points per residue, the first one a "Cent" centroid; tag = per-residue id."""
+    n = 3 * n_res
+    xyz = rng.uniform(0.0, side, (n, 3))
+    seq = [CG_TYPES[0] if i % 3 == 0 else CG_TYPES[1 + int(k)] for i, k in enumerate(rng.integers(0, 7, n))]
+    tags = [f"A/{i // 3}-RES" for i in range(n)]
+    return seq, xyz, tags
+
+
+def prims(mod, seq, xyz, tags):
+    return [mod.PrimitiveAtom(s, t, c) for s, t, c in zip(seq, tags, xyz)]
+
+
+def test_c3_casp_style_all_vs_all(lh, oracle):
+    """Decoy-vs-decoy with centroid anchors, accept_same=False, uniform[3,10], threshold 10
+    (python_codes/casp14/casp14_extend_with_locohd.py:35-37,72-79)."""
+    rng = np.random.default_rng(3)
+    n_res = 200
+    side = (3 * n_res / 0.023) ** (1 / 3)
+    base = cg_structure(rng, n_res, side)
+    decoys = [(base[0], base[1] + rng.normal(0.0, 1.5, base[1].shape), base[2]) for _ in range(5)]
+    anchors = [(i, i) for i in range(0, 3 * n_res, 3)]
+
+    def run(mod):
+        lchd = mod.LoCoHD(CG_TYPES, mod.WeightFunction("uniform", [3.0, 10.0]), mod.TagPairingRule({"accept_same": False}))
+        ps = [prims(mod, *d) for d in decoys]
+        return {(a, b): np.asarray(lchd.from_primitives(ps[a], ps[b], anchors, 10.0)) for a in range(5) for b in range(a + 1, 5)}
+
+    got, want = run(lh), run(oracle)
+    for k in want:
+        assert np.max(np.abs(got[k] - want[k])) < TIGHT, k
+    # symmetry of the Hellinger-based score under swapping the two structures
+    lchd = lh.LoCoHD(CG_TYPES, lh.WeightFunction("uniform", [3.0, 10.0]), lh.TagPairingRule({"accept_same": False}))
+    ab = np.asarray(lchd.from_primitives(prims(lh, *decoys[0]), prims(lh, *decoys[1]), anchors, 10.0))
+    ba = np.asarray(lchd.from_primitives(prims(lh, *decoys[1]), prims(lh, *decoys[0]), anchors, 10.0))
+    assert np.max(np.abs(ab - ba)) < 1e-13
+
+
+def test_c4_md_trajectory_frames(lh, oracle):
+    """One reference structure vs jittered frames through the device-resident session
+    (python_codes/trajectory_analyzer.py:97-119): frames only replace coordinates."""
+    import torch
+    from loco_hd_amd.device import DeviceSession
+
+    rng = np.random.default_rng(4)
+    n_res = 220
+    side = (3 * n_res / 0.023) ** (1 / 3)
+    seq, xyz, tags = cg_structure(rng, n_res, side)
+    frames = [xyz + rng.normal(0.0, 0.5, xyz.shape) for _ in range(6)]
+    anchors = [(i, i) for i in range(0, 3 * n_res, 3)]
+    rule = {"accept_same": False}
+
+    lchd = lh.LoCoHD(CG_TYPES, lh.WeightFunction("uniform", [3.0, 10.0]), lh.TagPairingRule(rule))
+    interner = {}
+    packed = lchd.pack(prims(lh, seq, xyz, tags), interner)
+    sess = DeviceSession(lchd, interner=interner)
+    ref = sess.upload(packed.xyz, packed.cat, packed.tag)
+    cur = sess.upload(packed.xyz, packed.cat, packed.tag)
+    d_anchors = torch.tensor(anchors, dtype=torch.int64, device="cuda")
+    got = []
+    for f in frames:
+        sess.set_coords(cur, f)
+        got.append(sess.from_primitives(ref, cur, d_anchors, 10.0).cpu().numpy())
+    sess.close()
+
+    lo = oracle.LoCoHD(CG_TYPES, oracle.WeightFunction("uniform", [3.0, 10.0]), oracle.TagPairingRule(rule))
+    ref_p = prims(oracle, seq, xyz, tags)
+    for f, g in zip(frames, got):
+        want = np.asarray(lo.from_primitives(ref_p, prims(oracle, seq, f, tags), anchors, 10.0))
+        assert np.max(np.abs(g - want)) < TIGHT
+
+
+def test_c5_stress_reduced(lh, oracle):
+    """Two large labelled clouds, 25 categories, random anchor pairs (reduced: 30k points, 40k pairs)."""
+    rng = np.random.default_rng(5)
+    n, c = 30_000, 25
+    side = (n / 0.05) ** (1 / 3)
+    xa, xb = rng.uniform(0, side, (n, 3)), rng.uniform(0, side, (n, 3))
+    ca, cb = rng.integers(0, c, n).astype(np.int32), rng.integers(0, c, n).astype(np.int32)
+    pairs = np.stack([rng.integers(0, n, 40_000), rng.integers(0, n, 40_000)], 1).astype(np.int64)
+    cats = [f"c{i}" for i in range(c)]
+    tag = np.zeros(n, dtype=np.int32)
+    lchd = lh.LoCoHD(cats, lh.WeightFunction("hyper_exp", [1.0, 0.1]))
+    from loco_hd_amd.api import _Packed
+
+    got = lchd.from_packed(_Packed(xa, ca, tag), _Packed(xb, cb, tag), pairs, 10.0)
+    lo = oracle.LoCoHD(cats, oracle.WeightFunction("hyper_exp", [1.0, 0.1]))
+    want = np.asarray(lo.from_arrays(xa, ca, tag, xb, cb, tag, pairs, 10.0))
+    assert np.max(np.abs(got - want)) < TIGHT
+    assert got.min() >= 0.0 and got.max() <= 1.0 + 1e-12
+
+
+def test_c2b_dense_from_coords_properties(lh):
+    """from_coords on 6000-atom clouds (whole-cloud environments): properties that need no oracle."""
+    rng = np.random.default_rng(2)
+    n = 6000
+    side = (n / 0.05) ** (1 / 3)
+    cats = [f"c{i}" for i in range(10)]
+    xa, xb = rng.uniform(0, side, (n, 3)), rng.uniform(0, side, (n, 3))
+    sa, sb = rng.choice(cats, n).tolist(), rng.choice(cats, n).tolist()
+    lchd = lh.LoCoHD(cats, lh.WeightFunction("hyper_exp", [1.0, 0.1]))
+    same = np.asarray(lchd.from_coords(sa, sa, xa, xa))
+    assert np.max(np.abs(same)) == 0.0
+    ab, ba = np.asarray(lchd.from_coords(sa, sb, xa, xb)), np.asarray(lchd.from_coords(sb, sa, xb, xa))
+    assert np.max(np.abs(ab - ba)) < 1e-13 and ab.min() >= 0.0 and ab.max() <= 1.0
+    # a permutation of the atoms permutes the scores (every atom is its own anchor; environments are sets)
+    perm = rng.permutation(n)
+    pa = np.asarray(lchd.from_coords([sa[i] for i in perm], [sb[i] for i in perm], xa[perm], xb[perm]))
+    assert np.max(np.abs(pa - ab[perm])) < 1e-13
+    # and the thresholded path with a threshold beyond the cloud diameter sees the same environments
+    prim = lambda s, x: [lh.PrimitiveAtom(t, "", c) for t, c in zip(s[:1500], x[:1500])]
+    dense = np.asarray(lchd.from_coords(sa[:1500], sb[:1500], xa[:1500], xb[:1500]))
+    thr = np.asarray(lchd.from_primitives(prim(sa, xa), prim(sb, xb), [(i, i) for i in range(1500)], 1e4))
+    assert np.max(np.abs(dense - thr)) < 1e-13
+
+
+def test_full_size_c2a_properties(lh):
+    """10k-atom clouds, 10^5 anchor pairs: order preservation and repeat-consistency on the device-resident path."""
+    import torch
+    from loco_hd_amd.device import DeviceSession
+
+    rng = np.random.default_rng(2)
+    n, c = 10_000, 10
+    side = (n / 0.05) ** (1 / 3)
+    xa, xb = rng.uniform(0, side, (n, 3)), rng.uniform(0, side, (n, 3))
+    ca, cb = rng.integers(0, c, n).astype(np.int32), rng.integers(0, c, n).astype(np.int32)
+    lchd = lh.LoCoHD([f"c{i}" for i in range(c)], lh.WeightFunction("hyper_exp", [1.0, 0.1]))
+    sess = DeviceSession(lchd)
+    a, b = sess.upload(xa, ca), sess.upload(xb, cb)
+    pairs = torch.from_numpy(np.stack([rng.integers(0, n, 100_000), rng.integers(0, n, 100_000)], 1)).cuda()
+    s1 = sess.from_primitives(a, b, pairs, 10.0).clone()
+    perm = torch.randperm(pairs.shape[0], device="cuda")
+    s2 = sess.from_primitives(a, b, pairs[perm].contiguous(), 10.0)
+    assert torch.equal(s1[perm], s2)  # output i <-> anchor pair i, bit for bit
+    s3 = sess.from_primitives(b, a, pairs.flip(1).contiguous(), 10.0)
+    assert float((s1 - s3).abs().max()) < 1e-13
+    assert float(s1.min()) >= 0.0 and float(s1.max()) <= 1.0
+    sess.close()
