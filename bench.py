@@ -73,6 +73,18 @@ def make_workload(name: str, rank: int, n_pairs: int):
                 wf=("hyper_exp", [1.0, 0.1]), label=label, n=n)
 
 
+def measured_traffic(kernel_name: str, workload_label: str):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/), if they were
+    taken for this kernel and workload; PMC counters cannot be read from inside this process."""
+    try:
+        t = json.loads((ROOT / "profiles" / "r01" / "traffic_c2a.json").read_text())
+    except (OSError, ValueError):
+        return None, None
+    if t.get("kernel") in kernel_name and workload_label.startswith(t.get("workload_prefix", "\0")):
+        return t.get("traffic_bytes_per_launch"), "profiles/r01/traffic_c2a.json (separate rocprofv3 --pmc passes of this command)"
+    return None, None
+
+
 def usable_cores() -> int:
     """CPU threads this process may really use: affinity mask and cgroup quota, not just os.cpu_count()."""
     n = os.cpu_count() or 1
@@ -187,6 +199,7 @@ def main():
         dom = max(("env", "sweep"), key=lambda k: phase_ms[k])
         dom_name = {"env": "k_env_cells (2 launches: side A + side B)", "sweep": "k_sweep"}[dom]
         achieved = algo_bytes / (phase_ms[dom] * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic(dom_name, w["label"]) if p == 1_000_000 else (None, None)
         result = {
             "metric": "anchor-pair LoCoHD scores/sec",
             "value": p * world * args.steps / elapsed,
@@ -202,7 +215,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": w["label"], "pairs_per_gpu": p, "mean_env_points_per_pair": env_points / p},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": dom_name,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": dom_name,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": phase_ms[dom]},
             "kernel_ms": phase_ms,
         }
