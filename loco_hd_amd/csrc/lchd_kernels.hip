@@ -670,6 +670,19 @@ __device__ __forceinline__ double cdf_dev(const WfRegs& w, double x) {
     else return 0.0;  // unreachable: the host routes tables with other weight functions to the WFANY build
 }
 
+// sqrt for x in [0, ~1]: v_rsq_f64 seed + Goldschmidt refinement (the same scheme the compiler's IEEE sqrt uses, minus
+// its range scaling and special-case fix-ups, which H^2 in [0, 1] never needs).  Result within 1 ulp; sqrt(0) = 0.
+__device__ __forceinline__ double sqrt_unit(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    return x > 0.0 ? g : 0.0;
+}
+
 // StatisticalDistance::run for the non-default distances; out of line so that the sweep kernel stays small.
 __device__ __noinline__ double sd_generic(int kind, double p0, double p1, const double* p, const double* q, int C) {
     return sd_eval<0>(kind, p0, p1, [&](int c) { return p[c]; }, [&](int c) { return q[c]; }, C);
@@ -834,7 +847,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, LCHD_SWEEP_MINW) void k_sweep(Swe
                 // (which also returns exactly 0 for identical environments).
                 double h2 = 1.0 - (ra * rb) * D;
                 if (h2 < 1e-3) h2 = exact_h2();
-                return sqrt(h2);
+                return sqrt_unit(h2);
             } else {
                 double pn[CMAX], qn[CMAX];
                 double sa_ = 0.0, sb_ = 0.0;  // pmf.rs:67-68: fresh sums
@@ -851,9 +864,15 @@ __global__ __launch_bounds__(64 * kSweepWaves, LCHD_SWEEP_MINW) void k_sweep(Swe
 
 #pragma unroll
         for (int k = 0; k < NW; ++k) { exA[k] = cntA[k]; exB[k] = cntB[k]; }
-        load_state();
         double F_carry = cdf_of_key(kA[0]);  // F(0): both anchors sit at distance 0
-        double H_carry = bad_cat ? 0.0 : distance();
+        double H_carry;
+        if constexpr (H2) {
+            // only the two anchors: both PMFs are point masses => H = 0 if they share the category, else 1 (exactly)
+            H_carry = (tA[0] == tB[0]) ? 0.0 : 1.0;
+        } else {
+            load_state();
+            H_carry = bad_cat ? 0.0 : distance();
+        }
         double acc = 0.0;
 
         const int mA = nA - 1, mB = nB - 1, M = mA + mB;  // non-anchor events
@@ -1100,7 +1119,7 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
                 // (which also returns exactly 0 for identical environments).
                 double h2 = 1.0 - (ra * rb) * D;
                 if (h2 < 1e-3) h2 = exact_h2();
-                return sqrt(h2);
+                return sqrt_unit(h2);
             } else {
                 double pn[kWideMaxCat], qn[kWideMaxCat];
                 double sa_ = 0.0, sb_ = 0.0;  // pmf.rs:67-68: fresh sums
