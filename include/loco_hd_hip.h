@@ -120,6 +120,14 @@ int lchd_from_primitives(lchd_ctx *ctx, const lchd_config *cfg, const double *xy
  * PyO3 boundary, src/locohd/primitive_atom.rs:4-16).  xyz/cat/tag are HOST pointers here. */
 typedef struct lchd_cloud lchd_cloud;
 int lchd_cloud_create(lchd_ctx *ctx, const double *xyz, const int32_t *cat, const int32_t *tag, int64_t n, lchd_cloud **out);
+/* A BATCH of structures in one device object (additive; replaces a Python loop of from_primitives calls such as
+ * python_codes/casp14/casp14_extend_with_locohd.py:42-88 or python_codes/trajectory_analyzer.py:112-120): the atoms of
+ * all structures are concatenated, sid[i] in [0, n_struct) names the structure of atom i, and an environment only ever
+ * contains atoms of its anchor's own structure.  Anchor indices are positions in the concatenated arrays, so one
+ * lchd_from_primitives_dev call can score anchor pairs of many structure pairs (pass the same batch as `a` and `b`
+ * for all-vs-all). */
+int lchd_cloud_create_batch(lchd_ctx *ctx, const double *xyz, const int32_t *cat, const int32_t *tag, const int32_t *sid,
+                            int64_t n, int32_t n_struct, lchd_cloud **out);
 /* Replace the coordinates of an existing cloud (MD frames: same atoms, new positions). Host pointer [n][3]. */
 int lchd_cloud_set_coords(lchd_ctx *ctx, lchd_cloud *cloud, const double *xyz);
 void lchd_cloud_destroy(lchd_ctx *ctx, lchd_cloud *cloud);

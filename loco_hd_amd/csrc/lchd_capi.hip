@@ -127,9 +127,11 @@ struct lchd_cloud {
     double *x = nullptr, *y = nullptr, *z = nullptr;
     uint8_t* cat = nullptr;
     int32_t* tag = nullptr;
+    int32_t* sid = nullptr;  // batch of structures: structure id per atom (nullptr = one structure)
+    int32_t n_struct = 1;
     int64_t n = 0;
     double bbmin[3] = {0, 0, 0}, bbmax[3] = {0, 0, 0};
-    CloudView view() const { return CloudView{x, y, z, cat, tag, (int32_t)n}; }
+    CloudView view() const { return CloudView{x, y, z, cat, tag, (int32_t)n, sid, n_struct}; }
 };
 
 enum { PH_CELLS = 0, PH_ANCHORS = 1, PH_ENV = 2, PH_SWEEP = 3, PH_N = 4 };
@@ -379,6 +381,23 @@ extern "C" int lchd_cloud_create(lchd_ctx* c, const double* xyz, const int32_t* 
     return LCHD_OK;
 }
 
+extern "C" int lchd_cloud_create_batch(lchd_ctx* c, const double* xyz, const int32_t* cat, const int32_t* tag, const int32_t* sid,
+                                       int64_t n, int32_t n_struct, lchd_cloud** out) {
+    if (n_struct < 1 || !sid) return fail(LCHD_EVALUE, "a batch needs n_struct >= 1 and a structure id per atom");
+    for (int64_t i = 0; i < n; ++i)
+        if (sid[i] < 0 || sid[i] >= n_struct) return fail(LCHD_EVALUE, "structure id %d of atom %lld is outside [0, %d)", sid[i], (long long)i, n_struct);
+    lchd_cloud* cl = nullptr;
+    if (int rc = lchd_cloud_create(c, xyz, cat, tag, n, &cl)) return rc;
+    cl->n_struct = n_struct;
+    if (n) {
+        hipError_t e = hipMalloc(&cl->sid, sizeof(int32_t) * n);
+        if (e == hipSuccess) e = hipMemcpy(cl->sid, sid, sizeof(int32_t) * n, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { lchd_cloud_destroy(c, cl); return fail(LCHD_EDEVICE, "HIP error %d while uploading structure ids", (int)e); }
+    }
+    *out = cl;
+    return LCHD_OK;
+}
+
 extern "C" int lchd_cloud_set_coords(lchd_ctx* c, lchd_cloud* cl, const double* xyz) {
     if (!c || !cl || !xyz) return fail(LCHD_EVALUE, "null argument");
     return upload_coords(c, cl, xyz);
@@ -392,6 +411,7 @@ extern "C" void lchd_cloud_destroy(lchd_ctx* c, lchd_cloud* cl) {
     (void)hipFree(cl->z);
     (void)hipFree(cl->cat);
     (void)hipFree(cl->tag);
+    (void)hipFree(cl->sid);
     delete cl;
 }
 
@@ -456,8 +476,10 @@ static GridPlan plan_grid(const lchd_cloud* cl, double thr) {
         g.dim[k] = (int)nd;
         total *= g.dim[k];
     }
-    while (total > (1ll << 18)) {  // keep the single-workgroup scan cheap: coarsen the largest axis
+    total *= cl->n_struct;
+    while (total > (1ll << 23)) {  // bound the cell arrays (8M cells): coarsen the largest axis
         int k = (g.dim[0] >= g.dim[1] && g.dim[0] >= g.dim[2]) ? 0 : (g.dim[1] >= g.dim[2] ? 1 : 2);
+        if (g.dim[k] == 1) break;
         total /= g.dim[k];
         g.dim[k] = (g.dim[k] + 1) / 2;
         total *= g.dim[k];
@@ -468,12 +490,12 @@ static GridPlan plan_grid(const lchd_cloud* cl, double thr) {
         const double cell = ext > 0.0 ? ext / g.dim[k] : 1.0;
         g.inv[k] = 1.0 / (cell * (1.0 + 1e-12));
     }
-    g.n_cells = g.dim[0] * g.dim[1] * g.dim[2];
+    g.n_cells = cl->n_struct * g.dim[0] * g.dim[1] * g.dim[2];
     return g;
 }
 
 struct SideBufs {
-    uint32_t *cell_of, *cell_count, *cursor, *cell_start, *porig, *slot, *uniq;
+    uint32_t *cell_of, *cell_count, *cursor, *cell_start, *porig, *slot, *uniq, *scan_tmp;
     double *px, *py, *pz;
     uint8_t* pcat;
     int32_t* ptag;
@@ -494,6 +516,7 @@ static void carve_side(Arena& a, int64_t n, int n_cells, int64_t max_envs, int c
     b.porig = a.take<uint32_t>(m);
     b.slot = a.take<uint32_t>(m + 1);
     b.uniq = a.take<uint32_t>(m);
+    b.scan_tmp = a.take<uint32_t>(std::max<size_t>(m, (size_t)n_cells) / 4096 + 4);
     const size_t ne = (size_t)std::max<int64_t>(max_envs, 1);
     b.env.key = a.take<uint64_t>(ne * (size_t)cap);
     b.env.cat = a.take<uint8_t>(ne * (size_t)cap);
@@ -549,11 +572,11 @@ extern "C" int lchd_from_primitives_dev(lchd_ctx* c, lchd_cloud* a, lchd_cloud* 
         hipStream_t s = c->stream;
         HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(DeviceStatus), s));
         mark(c, 0);
-        launch_cell_build(s, cva, gva, sa.cell_of, sa.cell_count, sa.cursor, sa.px, sa.py, sa.pz, sa.pcat, sa.ptag, sa.porig, sa.cell_start);
-        launch_cell_build(s, cvb, gvb, sb.cell_of, sb.cell_count, sb.cursor, sb.px, sb.py, sb.pz, sb.pcat, sb.ptag, sb.porig, sb.cell_start);
+        launch_cell_build(s, cva, gva, sa.cell_of, sa.cell_count, sa.cursor, sa.px, sa.py, sa.pz, sa.pcat, sa.ptag, sa.porig, sa.cell_start, sa.scan_tmp);
+        launch_cell_build(s, cvb, gvb, sb.cell_of, sb.cell_count, sb.cursor, sb.px, sb.py, sb.pz, sb.pcat, sb.ptag, sb.porig, sb.cell_start, sb.scan_tmp);
         mark(c, 1);
-        launch_anchor_dedupe(s, d_anchors, n_pairs, 0, (int32_t)a->n, sa.slot, sa.uniq, c->d_status);
-        launch_anchor_dedupe(s, d_anchors, n_pairs, 1, (int32_t)b->n, sb.slot, sb.uniq, c->d_status);
+        launch_anchor_dedupe(s, d_anchors, n_pairs, 0, (int32_t)a->n, sa.slot, sa.uniq, c->d_status, sa.scan_tmp);
+        launch_anchor_dedupe(s, d_anchors, n_pairs, 1, (int32_t)b->n, sb.slot, sb.uniq, c->d_status, sb.scan_tmp);
         mark(c, 2);
         if (!launch_env_cells(s, cap, c->d_cfg, cva, gva, sa.uniq, 0, max_env_a, thr, sa.env, c->d_status) ||
             !launch_env_cells(s, cap, c->d_cfg, cvb, gvb, sb.uniq, 1, max_env_b, thr, sb.env, c->d_status))

@@ -54,13 +54,15 @@ struct CloudView {
     const uint8_t* cat;
     const int32_t* tag;
     int32_t n;
+    const int32_t* sid;   // structure id per atom for a batch of structures (nullptr = one structure)
+    int32_t n_struct;     // >= 1
 };
 
 // Uniform grid over one cloud (replaces KdTree::build_by_ordered_float, src/locohd.rs:504-510).
 struct GridView {
     double min[3], inv[3];   // cell index = clamp(floor((p - min) * inv), 0, dim-1)
-    int32_t dim[3];
-    int32_t n_cells;
+    int32_t dim[3];          // per structure; cell = ((sid * dim[2] + cz) * dim[1] + cy) * dim[0] + cx
+    int32_t n_cells;         // n_struct * dim[0] * dim[1] * dim[2]
     const uint32_t* cell_start;  // [n_cells + 1]
     // points permuted into cell order
     const double *px, *py, *pz;
@@ -78,12 +80,13 @@ struct EnvStore {
     int32_t cdf_keys;  // 1: key = bits of F(distance) for the configuration's single weight function (sweep needs no CDF evaluation)
 };
 
+// `scan_tmp` holds (n / 4096 + 2) u32 of scratch for the multi-block scan
 void launch_cell_build(hipStream_t s, const CloudView& c, GridView g, uint32_t* cell_of, uint32_t* cell_count,
                        uint32_t* cell_cursor, double* px, double* py, double* pz, uint8_t* pcat, int32_t* ptag,
-                       uint32_t* porig, uint32_t* cell_start);
+                       uint32_t* porig, uint32_t* cell_start, uint32_t* scan_tmp);
 
 void launch_anchor_dedupe(hipStream_t s, const int64_t* anchors, int64_t n_pairs, int side, int32_t n_points,
-                          uint32_t* flag_then_slot, uint32_t* uniq, DeviceStatus* st);
+                          uint32_t* flag_then_slot, uint32_t* uniq, DeviceStatus* st, uint32_t* scan_tmp);
 
 // returns false if `cap` is not an available variant
 bool launch_env_cells(hipStream_t s, int cap, const DevConfig* cfg, const CloudView& c, const GridView& g,

@@ -86,7 +86,8 @@ __global__ void k_cell_count(CloudView c, GridView g, uint32_t* cell_of, uint32_
         const int cx = cell_coord(c.x[i], g.min[0], g.inv[0], g.dim[0]);
         const int cy = cell_coord(c.y[i], g.min[1], g.inv[1], g.dim[1]);
         const int cz = cell_coord(c.z[i], g.min[2], g.inv[2], g.dim[2]);
-        const uint32_t cell = (uint32_t)((cz * g.dim[1] + cy) * g.dim[0] + cx);
+        const int sid = c.sid ? c.sid[i] : 0;
+        const uint32_t cell = (uint32_t)((((int64_t)sid * g.dim[2] + cz) * g.dim[1] + cy) * g.dim[0] + cx);
         cell_of[i] = cell;
         atomicAdd(&cell_count[cell], 1u);
     }
@@ -139,14 +140,59 @@ __global__ void k_cell_scatter(CloudView c, const uint32_t* cell_of, const uint3
     }
 }
 
+// Multi-block exclusive scan for large inputs (batches of structures: millions of atoms / cells):
+// per-block sums -> single-workgroup scan of the sums -> per-block scan with the block's offset.  4096 items per block.
+constexpr int kScanItems = 4096;
+__global__ __launch_bounds__(1024) void k_scan_block_sums(const uint32_t* in, int n, uint32_t* bsum) {
+    __shared__ uint32_t ws[16];
+    const int tid = threadIdx.x, base = blockIdx.x * kScanItems;
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int i = base + k * 1024 + tid; v += i < n ? in[i] : 0u; }
+    for (int m = 32; m > 0; m >>= 1) v += (uint32_t)__shfl_xor((int)v, m);
+    if ((tid & 63) == 0) ws[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) { uint32_t t = 0; for (int w = 0; w < 16; ++w) t += ws[w]; bsum[blockIdx.x] = t; }
+}
+__global__ __launch_bounds__(1024) void k_scan_apply(const uint32_t* in, uint32_t* out, int n, const uint32_t* bpre, int n_blocks,
+                                                     uint32_t* total_out) {
+    __shared__ uint32_t ws[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, base = blockIdx.x * kScanItems;
+    // thread t owns items base + 4t .. base + 4t + 3 (blocked), so one wave scan + a 16-entry LDS pass suffice
+    uint32_t v[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int i = base + 4 * tid + k; v[k] = i < n ? in[i] : 0u; sum += v[k]; }
+    const uint32_t incl = wave_incl_scan_u32(sum);
+    if (lane == 63) ws[wave] = incl;
+    __syncthreads();
+    uint32_t pre = bpre[blockIdx.x] + incl - sum;
+    for (int w = 0; w < wave; ++w) pre += ws[w];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int i = base + 4 * tid + k; if (i < n) out[i] = pre; pre += v[k]; }
+    if (blockIdx.x == n_blocks - 1 && tid == 1023) {
+        out[n] = pre;
+        if (total_out) *total_out = pre;
+    }
+}
+static void launch_exclusive_scan(hipStream_t s, const uint32_t* in, uint32_t* out, int n, uint32_t* total_out, uint32_t* tmp) {
+    if (n <= 2 * kScanItems || !tmp) {
+        k_exclusive_scan<<<1, 1024, 0, s>>>(in, out, n, total_out);
+        return;
+    }
+    const int nb = (n + kScanItems - 1) / kScanItems;
+    k_scan_block_sums<<<nb, 1024, 0, s>>>(in, n, tmp);
+    k_exclusive_scan<<<1, 1024, 0, s>>>(tmp, tmp, nb, nullptr);
+    k_scan_apply<<<nb, 1024, 0, s>>>(in, out, n, tmp, nb, total_out);
+}
+
 void launch_cell_build(hipStream_t s, const CloudView& c, GridView g, uint32_t* cell_of, uint32_t* cell_count,
                        uint32_t* cell_cursor, double* px, double* py, double* pz, uint8_t* pcat, int32_t* ptag,
-                       uint32_t* porig, uint32_t* cell_start) {
+                       uint32_t* porig, uint32_t* cell_start, uint32_t* scan_tmp) {
     (void)hipMemsetAsync(cell_count, 0, sizeof(uint32_t) * (size_t)(g.n_cells + 1), s);
     (void)hipMemsetAsync(cell_cursor, 0, sizeof(uint32_t) * (size_t)(g.n_cells + 1), s);
-    const int nb = (c.n + 255) / 256 > 2048 ? 2048 : (c.n + 255) / 256;
+    const int nb = (c.n + 255) / 256 > 4096 ? 4096 : (c.n + 255) / 256;
     if (c.n > 0) k_cell_count<<<nb, 256, 0, s>>>(c, g, cell_of, cell_count);
-    k_exclusive_scan<<<1, 1024, 0, s>>>(cell_count, cell_start, g.n_cells, nullptr);
+    launch_exclusive_scan(s, cell_count, cell_start, g.n_cells, nullptr, scan_tmp);
     if (c.n > 0) k_cell_scatter<<<nb, 256, 0, s>>>(c, cell_of, cell_start, cell_cursor, px, py, pz, pcat, ptag, porig);
 }
 
@@ -168,16 +214,16 @@ __global__ void k_compact_anchors(const uint32_t* slot, int32_t n_points, uint32
 }
 
 void launch_anchor_dedupe(hipStream_t s, const int64_t* anchors, int64_t n_pairs, int side, int32_t n_points,
-                          uint32_t* flag_then_slot, uint32_t* uniq, DeviceStatus* st) {
+                          uint32_t* flag_then_slot, uint32_t* uniq, DeviceStatus* st, uint32_t* scan_tmp) {
     (void)hipMemsetAsync(flag_then_slot, 0, sizeof(uint32_t) * (size_t)(n_points + 1), s);
     if (n_pairs > 0) {
         const int64_t nbp = (n_pairs + 255) / 256;
         k_mark_anchors<<<(int)(nbp > 4096 ? 4096 : nbp), 256, 0, s>>>(anchors, n_pairs, side, n_points, flag_then_slot, st);
     }
-    k_exclusive_scan<<<1, 1024, 0, s>>>(flag_then_slot, flag_then_slot, n_points, &st->n_unique[side]);
+    launch_exclusive_scan(s, flag_then_slot, flag_then_slot, n_points, &st->n_unique[side], scan_tmp);
     if (n_points > 0) {
         const int nb = (n_points + 255) / 256;
-        k_compact_anchors<<<nb > 2048 ? 2048 : nb, 256, 0, s>>>(flag_then_slot, n_points, uniq);
+        k_compact_anchors<<<nb > 4096 ? 4096 : nb, 256, 0, s>>>(flag_then_slot, n_points, uniq);
     }
 }
 
@@ -298,6 +344,7 @@ __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ 
     const uint32_t anchor = uniq[e];
     const double ax = c.x[anchor], ay = c.y[anchor], az = c.z[anchor];
     const int32_t atag = c.tag[anchor];
+    const int asid = c.sid ? c.sid[anchor] : 0;
     const double thr2 = thr * thr;
     const int cx = cell_coord(ax, g.min[0], g.inv[0], g.dim[0]);
     const int cy = cell_coord(ay, g.min[1], g.inv[1], g.dim[1]);
@@ -312,7 +359,7 @@ __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ 
     for (int zz = max(cz - 1, 0); zz <= min(cz + 1, g.dim[2] - 1); ++zz) {
         for (int yy = max(cy - 1, 0); yy <= min(cy + 1, g.dim[1] - 1); ++yy) {
             // the (up to) three x-neighbour cells of one (y,z) row are contiguous in the cell-ordered arrays
-            const int row = (zz * g.dim[1] + yy) * g.dim[0];
+            const int row = (int)((((int64_t)asid * g.dim[2] + zz) * g.dim[1] + yy) * g.dim[0]);  // neighbours of the anchor's own structure only
             const int beg = (int)g.cell_start[row + x0], end = (int)g.cell_start[row + x1 + 1];
             for (int base = beg + wave * 64; base < end; base += NT) {
                 const int idx = base + lane;

@@ -56,6 +56,24 @@ class DeviceSession:
         self._clouds.append(h)
         return h
 
+    def upload_batch(self, structures):
+        """Put MANY structures into HBM as one object.  `structures` = sequence of (xyz [n_k][3], cat [n_k], tag [n_k] or
+        None).  Returns (handle, offsets): atom j of structure k is global atom offsets[k] + j -- the index to use in the
+        anchor tensor; environments never mix atoms of different structures."""
+        xs, cs, ts, ss, offs = [], [], [], [], [0]
+        for k, st in enumerate(structures):
+            xyz = np.ascontiguousarray(st[0], dtype=np.float64).reshape(-1, 3)
+            cat = np.ascontiguousarray(st[1], dtype=np.int32)
+            tag = np.zeros(len(cat), dtype=np.int32) if len(st) < 3 or st[2] is None else np.ascontiguousarray(st[2], dtype=np.int32)
+            xs.append(xyz); cs.append(cat); ts.append(tag); ss.append(np.full(len(cat), k, dtype=np.int32))
+            offs.append(offs[-1] + len(cat))
+        xyz, cat, tag, sid = np.concatenate(xs), np.concatenate(cs), np.concatenate(ts), np.concatenate(ss)
+        h = C.c_void_p()
+        N.check(N.lib().lchd_cloud_create_batch(self._ctx, N.dp(xyz), N.ip(cat), N.ip(tag), N.ip(sid), len(xyz), len(structures),
+                                                C.byref(h)))
+        self._clouds.append(h)
+        return h, np.asarray(offs, dtype=np.int64)
+
     def set_coords(self, cloud, xyz: np.ndarray):
         xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
         N.check(N.lib().lchd_cloud_set_coords(self._ctx, cloud, N.dp(xyz)))

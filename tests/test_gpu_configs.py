@@ -156,3 +156,44 @@ def test_full_size_c2a_properties(lh):
     assert float((s1 - s3).abs().max()) < 1e-13
     assert float(s1.min()) >= 0.0 and float(s1.max()) <= 1.0
     sess.close()
+
+
+def test_batched_structures_match_single_calls(lh):
+    """C3 / C4 as ONE device call: many structures in one batch object, anchor pairs of many structure pairs in one
+    anchor tensor.  Must equal the per-structure-pair calls bit for bit (environments never mix structures)."""
+    import torch
+    from loco_hd_amd.device import DeviceSession
+
+    rng = np.random.default_rng(6)
+    n_res = 150
+    side = (3 * n_res / 0.023) ** (1 / 3)
+    base = cg_structure(rng, n_res, side)
+    decoys = [(base[0], base[1] + rng.normal(0.0, 1.0 + 0.3 * k, base[1].shape), base[2]) for k in range(6)]
+    lchd = lh.LoCoHD(CG_TYPES, lh.WeightFunction("uniform", [3.0, 10.0]), lh.TagPairingRule({"accept_same": False}))
+    interner = {}
+    packed = [lchd.pack(prims(lh, *d), interner) for d in decoys]
+    local_anchors = np.arange(0, 3 * n_res, 3)
+
+    # reference: one from_primitives call per structure pair
+    want = {}
+    for a in range(6):
+        for b in range(a + 1, 6):
+            want[(a, b)] = lchd.from_packed(packed[a], packed[b], np.stack([local_anchors, local_anchors], 1), 10.0, interner=interner)
+
+    sess = DeviceSession(lchd, interner=interner)
+    batch, offs = sess.upload_batch([(p.xyz, p.cat, p.tag) for p in packed])
+    pair_list = sorted(want)
+    anchors = np.concatenate([np.stack([offs[a] + local_anchors, offs[b] + local_anchors], 1) for a, b in pair_list])
+    scores = sess.from_primitives(batch, batch, torch.from_numpy(anchors).cuda(), 10.0).cpu().numpy()
+    for k, (a, b) in enumerate(pair_list):
+        got = scores[k * len(local_anchors):(k + 1) * len(local_anchors)]
+        assert np.array_equal(got, want[(a, b)]), (a, b)
+
+    # C4 shape: one reference structure against a batch of frames
+    ref = sess.upload(packed[0].xyz, packed[0].cat, packed[0].tag)
+    frames, foffs = sess.upload_batch([(p.xyz, p.cat, p.tag) for p in packed[1:]])
+    anchors = np.concatenate([np.stack([local_anchors, foffs[f] + local_anchors], 1) for f in range(5)])
+    scores = sess.from_primitives(ref, frames, torch.from_numpy(anchors).cuda(), 10.0).cpu().numpy()
+    for f in range(5):
+        assert np.array_equal(scores[f * len(local_anchors):(f + 1) * len(local_anchors)], want[(0, f + 1)])
+    sess.close()
