@@ -146,8 +146,10 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("LCHD_BENCH_FORCE_DIST"))  # the latter: exercise RCCL init + gather on one GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import loco_hd_amd as lh
@@ -162,18 +164,18 @@ def main():
     anchors = torch.from_numpy(w["pairs"]).to(dev)
     p = anchors.shape[0]
     out = torch.empty(p, dtype=torch.float64, device=dev)
-    gathered = torch.empty(p * world, dtype=torch.float64, device=dev) if (world > 1 and rank == 0) else None
+    gathered = torch.empty(p * world, dtype=torch.float64, device=dev) if (use_dist and rank == 0) else None
     sess.enable_timing(True)
 
     def step():
         sess.from_primitives(cloud_a, cloud_b, anchors, w["thr"], out=out)
-        if world > 1:
-            gather_scores(out, gathered, world, rank)
+        if use_dist:
+            gather_scores(out, gathered, world, rank, force_collective=True)
 
     phase_ms = {"cells": 0.0, "anchors": 0.0, "env": 0.0, "sweep": 0.0}
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -181,11 +183,11 @@ def main():
         step()
         for k, v in sess.last_ms().items():
             phase_ms[k] += v
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -226,13 +228,24 @@ def main():
             result["parity_sample_pairs"] = m
             if not (err <= 1e-6):
                 result["parity_failed"] = True
-        print(json.dumps(result), flush=True)
-        if result.get("parity_failed"):
-            sys.exit(3)
-    if world > 1:
+        final_line = json.dumps(result)
+    if use_dist:
+        if rank == 0 and gathered is not None:
+            assert torch.equal(gathered[:p], out), "gathered scores differ from the local ones"
         dist.barrier()
         dist.destroy_process_group()
     sess.close()
+    if rank == 0:
+        # RCCL prints a version banner through C stdio; flush it first so that the JSON line is the LAST line of stdout
+        import ctypes
+
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(final_line, flush=True)
+        if json.loads(final_line).get("parity_failed"):
+            sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -17,11 +17,11 @@ def shard_bounds(n_pairs: int, world: int, rank: int) -> Tuple[int, int, int]:
     return lo, min(lo + chunk, n_pairs), chunk
 
 
-def gather_scores(local, gathered, world: int, rank: int, group=None) -> None:
+def gather_scores(local, gathered, world: int, rank: int, group=None, force_collective: bool = False) -> None:
     """Gather equal-length score vectors to rank 0: gathered[r*len : (r+1)*len] = rank r's `local`."""
     import torch.distributed as dist
 
-    if world == 1:
+    if world == 1 and not force_collective:
         if gathered is not None:
             gathered[: local.numel()].copy_(local)
         return
