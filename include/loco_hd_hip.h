@@ -139,6 +139,22 @@ void lchd_cloud_destroy(lchd_ctx *ctx, lchd_cloud *cloud);
 int lchd_from_primitives_dev(lchd_ctx *ctx, lchd_cloud *a, lchd_cloud *b, const int64_t *d_anchors,
                              const int32_t *d_wf_index, int64_t n_pairs, double threshold_distance, double *d_out);
 
+/* Split form of lchd_from_primitives_dev: _async enqueues the whole pass on the context's stream and returns without
+ * waiting; lchd_ctx_finish waits, re-runs the pass with a larger environment capacity if one overflowed, and returns
+ * the status.  Between the two calls the host is free (e.g. to stage the next batch of frames). */
+int lchd_from_primitives_dev_async(lchd_ctx *ctx, lchd_cloud *a, lchd_cloud *b, const int64_t *d_anchors,
+                                   const int32_t *d_wf_index, int64_t n_pairs, double threshold_distance, double *d_out);
+int lchd_ctx_finish(lchd_ctx *ctx);
+
+/* Trajectory frames (python_codes/trajectory_analyzer.py:97-119: same atoms, new coordinates per frame).  A frames
+ * buffer is a batch cloud with room for `capacity_frames` copies of `tmpl`'s atoms (categories and tags replicated on
+ * the device once).  lchd_frames_load copies a HOST block xyz[n_frames][n_atoms][3] into pinned staging, then enqueues
+ * the H2D copy, the SoA unpack and the bounding-box reduction on `hip_stream` (NULL = the context's stream) and
+ * returns; passes that use the buffer are ordered behind the upload with events, so uploading chunk k+1 on a second
+ * stream overlaps the scoring of chunk k (use two buffers). */
+int lchd_frames_create(lchd_ctx *ctx, const lchd_cloud *tmpl, int32_t capacity_frames, lchd_cloud **out);
+int lchd_frames_load(lchd_ctx *ctx, lchd_cloud *frames, const double *xyz, int32_t n_frames, void *hip_stream);
+
 /* Per-kernel timing of the most recent *_dev / driver call, measured with hipEvents on the context's stream.
  * names: "cells", "anchors", "env", "sweep"; returns milliseconds, <0 if unknown name / timing disabled. */
 int lchd_ctx_enable_timing(lchd_ctx *ctx, int32_t on);

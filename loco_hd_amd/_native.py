@@ -73,6 +73,10 @@ _PROTOS = {
     "lchd_cloud_set_coords": (C.c_int, [_VP, _VP, _DP]),
     "lchd_cloud_destroy": (None, [_VP, _VP]),
     "lchd_from_primitives_dev": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _i64, _f64, _VP]),
+    "lchd_from_primitives_dev_async": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _i64, _f64, _VP]),
+    "lchd_ctx_finish": (C.c_int, [_VP]),
+    "lchd_frames_create": (C.c_int, [_VP, _VP, _i32, C.POINTER(_VP)]),
+    "lchd_frames_load": (C.c_int, [_VP, _VP, _DP, _i32, _VP]),
     "lchd_ctx_enable_timing": (C.c_int, [_VP, _i32]),
     "lchd_ctx_last_ms": (C.c_double, [_VP, C.c_char_p]),
     "lchd_ctx_last_env_points": (C.c_int64, [_VP]),

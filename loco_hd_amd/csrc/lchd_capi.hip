@@ -130,6 +130,14 @@ struct lchd_cloud {
     int32_t* sid = nullptr;  // batch of structures: structure id per atom (nullptr = one structure)
     int32_t n_struct = 1;
     int64_t n = 0;
+    // trajectory-frames buffer (lchd_frames_create): capacity, staging and cross-stream hand-off
+    int64_t n_tmpl = 0;        // atoms per frame
+    int32_t cap_frames = 0;    // frames the arrays can hold
+    double* d_raw = nullptr;   // device staging of the caller's [frames][atoms][3] block
+    double* h_pinned = nullptr;
+    unsigned long long* d_bbox = nullptr;  // [7]: order-preserving keys of min xyz, max xyz, non-finite flag
+    hipEvent_t ev_ready = nullptr, ev_used = nullptr;
+    bool bbox_pending = false, used_valid = false;
     double bbmin[3] = {0, 0, 0}, bbmax[3] = {0, 0, 0};
     CloudView view() const { return CloudView{x, y, z, cat, tag, (int32_t)n, sid, n_struct}; }
 };
@@ -158,6 +166,18 @@ struct lchd_ctx {
     bool timing = false;
     hipEvent_t ev[PH_N + 1] = {};
     float ms[PH_N] = {-1, -1, -1, -1};
+    // a from_primitives call that has been enqueued but not finished (lchd_from_primitives_dev_async)
+    struct {
+        bool active = false;
+        lchd_cloud *a = nullptr, *b = nullptr;
+        const int64_t* anchors = nullptr;
+        const int32_t* wf = nullptr;
+        int64_t n_pairs = 0;
+        double thr = 0.0;
+        double* out = nullptr;
+        int cap = 0;
+        SweepArgs sw{};
+    } pend;
     // most recent sweep (for lchd_ctx_last_env_points)
     SweepArgs last{};
     bool last_valid = false;
@@ -412,6 +432,11 @@ extern "C" void lchd_cloud_destroy(lchd_ctx* c, lchd_cloud* cl) {
     (void)hipFree(cl->cat);
     (void)hipFree(cl->tag);
     (void)hipFree(cl->sid);
+    (void)hipFree(cl->d_raw);
+    (void)hipFree(cl->d_bbox);
+    if (cl->h_pinned) (void)hipHostFree(cl->h_pinned);
+    if (cl->ev_ready) (void)hipEventDestroy(cl->ev_ready);
+    if (cl->ev_used) (void)hipEventDestroy(cl->ev_used);
     delete cl;
 }
 
@@ -531,93 +556,200 @@ static int next_pow2_host(int64_t n) {
     return p;
 }
 
-extern "C" int lchd_from_primitives_dev(lchd_ctx* c, lchd_cloud* a, lchd_cloud* b, const int64_t* d_anchors,
-                                        const int32_t* d_wf_index, int64_t n_pairs, double thr, double* d_out) {
+// A frames buffer computes its bounding box on the device while it is being filled; fetch it before planning a grid.
+static int resolve_bbox(lchd_ctx* c, lchd_cloud* cl) {
+    if (!cl->bbox_pending) return LCHD_OK;
+    HIP_TRY(hipEventSynchronize(cl->ev_ready));
+    unsigned long long k[7];
+    HIP_TRY(hipMemcpy(k, cl->d_bbox, sizeof k, hipMemcpyDeviceToHost));
+    cl->bbox_pending = false;
+    if (k[6]) return fail(LCHD_EVALUE, "non-finite coordinate in a trajectory frame");
+    auto dec = [](unsigned long long u) { u = (u >> 63) ? (u ^ 0x8000000000000000ull) : ~u; double d; memcpy(&d, &u, 8); return d; };
+    for (int q = 0; q < 3; ++q) { cl->bbmin[q] = dec(k[q]); cl->bbmax[q] = dec(k[3 + q]); }
+    return LCHD_OK;
+}
+
+// Everything of one from_primitives pass up to (and including) the asynchronous status read-back; no host sync.
+static int prims_enqueue(lchd_ctx* c) {
+    auto& P = c->pend;
+    lchd_cloud *a = P.a, *b = P.b;
+    const int64_t n_pairs = P.n_pairs;
+    const double thr = P.thr;
+    const int cap = P.cap;
+    const GridPlan ga = plan_grid(a, thr), gb = plan_grid(b, thr);
+    const int64_t max_env_a = std::min<int64_t>(a->n, n_pairs), max_env_b = std::min<int64_t>(b->n, n_pairs);
+    SideBufs sa{}, sb{};
+    {
+        Arena dry(nullptr, 0, true);
+        carve_side(dry, a->n, ga.n_cells, max_env_a, cap, sa);
+        carve_side(dry, b->n, gb.n_cells, max_env_b, cap, sb);
+        if (int rc = ensure_ws(c, dry.off + 4096)) return rc;
+    }
+    Arena ar(c->ws, c->ws_cap, false);
+    carve_side(ar, a->n, ga.n_cells, max_env_a, cap, sa);
+    carve_side(ar, b->n, gb.n_cells, max_env_b, cap, sb);
+    sa.env.cdf_keys = sb.env.cdf_keys = (c->h_cfg.n_wf == 1 && !getenv("LCHD_NO_CDF_KEYS")) ? 1 : 0;
+
+    auto grid_view = [](const GridPlan& g, const SideBufs& s) {
+        GridView v{};
+        for (int k = 0; k < 3; ++k) { v.min[k] = g.min[k]; v.inv[k] = g.inv[k]; v.dim[k] = g.dim[k]; }
+        v.n_cells = g.n_cells;
+        v.cell_start = s.cell_start;
+        v.px = s.px; v.py = s.py; v.pz = s.pz;
+        v.pcat = s.pcat; v.ptag = s.ptag; v.porig = s.porig;
+        return v;
+    };
+    const GridView gva = grid_view(ga, sa), gvb = grid_view(gb, sb);
+    const CloudView cva = a->view(), cvb = b->view();
+    hipStream_t s = c->stream;
+    // frames buffers are filled on another stream: order this pass behind their upload
+    if (a->ev_ready && a->cap_frames) HIP_TRY(hipStreamWaitEvent(s, a->ev_ready, 0));
+    if (b->ev_ready && b->cap_frames) HIP_TRY(hipStreamWaitEvent(s, b->ev_ready, 0));
+    HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(DeviceStatus), s));
+    mark(c, 0);
+    launch_cell_build(s, cva, gva, sa.cell_of, sa.cell_count, sa.cursor, sa.px, sa.py, sa.pz, sa.pcat, sa.ptag, sa.porig, sa.cell_start, sa.scan_tmp);
+    launch_cell_build(s, cvb, gvb, sb.cell_of, sb.cell_count, sb.cursor, sb.px, sb.py, sb.pz, sb.pcat, sb.ptag, sb.porig, sb.cell_start, sb.scan_tmp);
+    mark(c, 1);
+    launch_anchor_dedupe(s, P.anchors, n_pairs, 0, (int32_t)a->n, sa.slot, sa.uniq, c->d_status, sa.scan_tmp);
+    launch_anchor_dedupe(s, P.anchors, n_pairs, 1, (int32_t)b->n, sb.slot, sb.uniq, c->d_status, sb.scan_tmp);
+    mark(c, 2);
+    if (!launch_env_cells(s, cap, c->d_cfg, cva, gva, sa.uniq, 0, max_env_a, thr, sa.env, c->d_status) ||
+        !launch_env_cells(s, cap, c->d_cfg, cvb, gvb, sb.uniq, 1, max_env_b, thr, sb.env, c->d_status))
+        return fail(LCHD_EUNSUPPORTED, "no environment kernel variant with capacity %d", cap);
+    mark(c, 3);
+    SweepArgs sw{};
+    sw.cfg = c->d_cfg;
+    sw.env_a = sa.env;
+    sw.env_b = sb.env;
+    sw.anchors = P.anchors;
+    sw.slot_a = sa.slot;
+    sw.slot_b = sb.slot;
+    sw.n_slot_a = a->n;
+    sw.n_slot_b = b->n;
+    sw.wf_index = P.wf;
+    sw.n_pairs = n_pairs;
+    sw.out = P.out;
+    sw.st = c->d_status;
+    sw.sqrt_tab = c->d_tabs;
+    sw.rsqrt_tab = c->d_tabs + 65536;
+    launch_sweep(s, c->h_cfg.n_categories, c->hellinger2, c->unit_weights, c->wf_pow, sw);
+    mark(c, 4);
+    if (a->ev_used) { HIP_TRY(hipEventRecord(a->ev_used, s)); a->used_valid = true; }
+    if (b->ev_used) { HIP_TRY(hipEventRecord(b->ev_used, s)); b->used_valid = true; }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->h_status, c->d_status, sizeof(DeviceStatus), hipMemcpyDeviceToHost, s));
+    P.sw = sw;
+    return LCHD_OK;
+}
+
+extern "C" int lchd_from_primitives_dev_async(lchd_ctx* c, lchd_cloud* a, lchd_cloud* b, const int64_t* d_anchors,
+                                              const int32_t* d_wf_index, int64_t n_pairs, double thr, double* d_out) {
     if (!c || !a || !b) return fail(LCHD_EVALUE, "null argument");
     if (!c->cfg_set) return fail(LCHD_EVALUE, "lchd_ctx_set_config has not been called");
+    if (c->pend.active) return fail(LCHD_EVALUE, "a previous asynchronous call has not been finished (lchd_ctx_finish)");
     c->last_valid = false;
     if (n_pairs <= 0) return LCHD_OK;
     if (!(thr > 0.0))  // within_radius returns nothing => dists[0] panics (src/locohd.rs:74)
         return fail(LCHD_EPANIC, "index out of bounds: threshold_distance = %g leaves every environment empty", thr);
     if (a->n == 0 || b->n == 0) return fail(LCHD_EPANIC, "index out of bounds: anchor pairs given for an empty structure");
     if (!std::isfinite(thr)) thr = 1.7e308;
+    if (int rc = resolve_bbox(c, a)) return rc;
+    if (int rc = resolve_bbox(c, b)) return rc;
+    auto& P = c->pend;
+    P.a = a; P.b = b; P.anchors = d_anchors; P.wf = d_wf_index; P.n_pairs = n_pairs; P.thr = thr; P.out = d_out;
+    P.cap = c->cap_hint;
+    if (int rc = prims_enqueue(c)) return rc;
+    P.active = true;
+    return LCHD_OK;
+}
 
-    const GridPlan ga = plan_grid(a, thr), gb = plan_grid(b, thr);
-    const int64_t max_env_a = std::min<int64_t>(a->n, n_pairs), max_env_b = std::min<int64_t>(b->n, n_pairs);
-    int cap = c->cap_hint;
+extern "C" int lchd_ctx_finish(lchd_ctx* c) {
+    if (!c) return fail(LCHD_EVALUE, "null context");
+    auto& P = c->pend;
+    if (!P.active) return LCHD_OK;
+    P.active = false;
     for (int attempt = 0; attempt < 6; ++attempt) {
-        SideBufs sa{}, sb{};
-        {
-            Arena dry(nullptr, 0, true);
-            carve_side(dry, a->n, ga.n_cells, max_env_a, cap, sa);
-            carve_side(dry, b->n, gb.n_cells, max_env_b, cap, sb);
-            if (int rc = ensure_ws(c, dry.off + 4096)) return rc;
-        }
-        Arena ar(c->ws, c->ws_cap, false);
-        carve_side(ar, a->n, ga.n_cells, max_env_a, cap, sa);
-        carve_side(ar, b->n, gb.n_cells, max_env_b, cap, sb);
-        sa.env.cdf_keys = sb.env.cdf_keys = (c->h_cfg.n_wf == 1 && !getenv("LCHD_NO_CDF_KEYS")) ? 1 : 0;
-
-        auto grid_view = [](const GridPlan& g, const SideBufs& s) {
-            GridView v{};
-            for (int k = 0; k < 3; ++k) { v.min[k] = g.min[k]; v.inv[k] = g.inv[k]; v.dim[k] = g.dim[k]; }
-            v.n_cells = g.n_cells;
-            v.cell_start = s.cell_start;
-            v.px = s.px; v.py = s.py; v.pz = s.pz;
-            v.pcat = s.pcat; v.ptag = s.ptag; v.porig = s.porig;
-            return v;
-        };
-        const GridView gva = grid_view(ga, sa), gvb = grid_view(gb, sb);
-        const CloudView cva = a->view(), cvb = b->view();
-        hipStream_t s = c->stream;
-        HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(DeviceStatus), s));
-        mark(c, 0);
-        launch_cell_build(s, cva, gva, sa.cell_of, sa.cell_count, sa.cursor, sa.px, sa.py, sa.pz, sa.pcat, sa.ptag, sa.porig, sa.cell_start, sa.scan_tmp);
-        launch_cell_build(s, cvb, gvb, sb.cell_of, sb.cell_count, sb.cursor, sb.px, sb.py, sb.pz, sb.pcat, sb.ptag, sb.porig, sb.cell_start, sb.scan_tmp);
-        mark(c, 1);
-        launch_anchor_dedupe(s, d_anchors, n_pairs, 0, (int32_t)a->n, sa.slot, sa.uniq, c->d_status, sa.scan_tmp);
-        launch_anchor_dedupe(s, d_anchors, n_pairs, 1, (int32_t)b->n, sb.slot, sb.uniq, c->d_status, sb.scan_tmp);
-        mark(c, 2);
-        if (!launch_env_cells(s, cap, c->d_cfg, cva, gva, sa.uniq, 0, max_env_a, thr, sa.env, c->d_status) ||
-            !launch_env_cells(s, cap, c->d_cfg, cvb, gvb, sb.uniq, 1, max_env_b, thr, sb.env, c->d_status))
-            return fail(LCHD_EUNSUPPORTED, "no environment kernel variant with capacity %d", cap);
-        mark(c, 3);
-        SweepArgs sw{};
-        sw.cfg = c->d_cfg;
-        sw.env_a = sa.env;
-        sw.env_b = sb.env;
-        sw.anchors = d_anchors;
-        sw.slot_a = sa.slot;
-        sw.slot_b = sb.slot;
-        sw.n_slot_a = a->n;
-        sw.n_slot_b = b->n;
-        sw.wf_index = d_wf_index;
-        sw.n_pairs = n_pairs;
-        sw.out = d_out;
-        sw.st = c->d_status;
-        sw.sqrt_tab = c->d_tabs;
-        sw.rsqrt_tab = c->d_tabs + 65536;
-        launch_sweep(s, c->h_cfg.n_categories, c->hellinger2, c->unit_weights, c->wf_pow, sw);
-        mark(c, 4);
-        HIP_TRY(hipGetLastError());
-        if (int rc = read_status(c)) return rc;
+        HIP_TRY(hipStreamSynchronize(c->stream));
         collect_times(c, 0, 4);
         const uint32_t f = c->h_status->flags;
         if (f & ST_BAD_ANCHOR) return status_to_rc(f, DRV_PRIMS);
-        if (f & ST_ENV_OVERFLOW) {
+        if (f & ST_ENV_OVERFLOW) {  // an environment did not fit the kernel variant's LDS capacity: run the pass again, larger
             const int64_t need = c->h_status->max_env;
             if (need > 16384)
                 return fail(LCHD_EUNSUPPORTED, "an environment holds %lld points; this build sorts at most 16384 per environment",
                             (long long)need);
-            cap = next_pow2_host(need);
-            c->cap_hint = cap;
+            P.cap = next_pow2_host(need);
+            c->cap_hint = P.cap;
+            if (int rc = prims_enqueue(c)) return rc;
             continue;
         }
-        c->last = sw;
+        c->last = P.sw;
         c->last_valid = true;
         return status_to_rc(f, DRV_PRIMS);
     }
     return fail(LCHD_EDEVICE, "environment capacity retry did not converge");
+}
+
+extern "C" int lchd_from_primitives_dev(lchd_ctx* c, lchd_cloud* a, lchd_cloud* b, const int64_t* d_anchors,
+                                        const int32_t* d_wf_index, int64_t n_pairs, double thr, double* d_out) {
+    if (int rc = lchd_from_primitives_dev_async(c, a, b, d_anchors, d_wf_index, n_pairs, thr, d_out)) return rc;
+    return lchd_ctx_finish(c);
+}
+
+// ------------------------------------------------------------------------------------------------
+// trajectory frames: a batch cloud whose structures are frames of one template structure
+// ------------------------------------------------------------------------------------------------
+extern "C" int lchd_frames_create(lchd_ctx* c, const lchd_cloud* tmpl, int32_t capacity_frames, lchd_cloud** out) {
+    if (!c || !tmpl || capacity_frames < 1) return fail(LCHD_EVALUE, "bad argument");
+    if (tmpl->sid) return fail(LCHD_EVALUE, "the template of a frames buffer must be a single structure");
+    const int64_t nt = tmpl->n, total = nt * capacity_frames;
+    if (nt < 1 || total > ((int64_t)1 << 30)) return fail(LCHD_EUNSUPPORTED, "frames buffer of %lld atoms is out of range", (long long)total);
+    lchd_cloud* cl = new lchd_cloud();
+    cl->n_tmpl = nt;
+    cl->cap_frames = capacity_frames;
+    cl->n = 0;
+    cl->n_struct = 1;
+    auto bail = [&](hipError_t e, const char* what) {
+        lchd_cloud_destroy(c, cl);
+        return fail(LCHD_EDEVICE, "HIP error %d in %s", (int)e, what);
+    };
+    hipError_t e;
+    if ((e = hipMalloc(&cl->x, sizeof(double) * total)) != hipSuccess) return bail(e, "hipMalloc(x)");
+    if ((e = hipMalloc(&cl->y, sizeof(double) * total)) != hipSuccess) return bail(e, "hipMalloc(y)");
+    if ((e = hipMalloc(&cl->z, sizeof(double) * total)) != hipSuccess) return bail(e, "hipMalloc(z)");
+    if ((e = hipMalloc(&cl->cat, total)) != hipSuccess) return bail(e, "hipMalloc(cat)");
+    if ((e = hipMalloc(&cl->tag, sizeof(int32_t) * total)) != hipSuccess) return bail(e, "hipMalloc(tag)");
+    if ((e = hipMalloc(&cl->sid, sizeof(int32_t) * total)) != hipSuccess) return bail(e, "hipMalloc(sid)");
+    if ((e = hipMalloc(&cl->d_raw, sizeof(double) * 3 * total)) != hipSuccess) return bail(e, "hipMalloc(raw)");
+    if ((e = hipMalloc(&cl->d_bbox, sizeof(unsigned long long) * 7)) != hipSuccess) return bail(e, "hipMalloc(bbox)");
+    if ((e = hipHostMalloc(&cl->h_pinned, sizeof(double) * 3 * total)) != hipSuccess) return bail(e, "hipHostMalloc");
+    if ((e = hipEventCreateWithFlags(&cl->ev_ready, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreateWithFlags(&cl->ev_used, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    launch_frames_labels(c->stream, tmpl->cat, tmpl->tag, nt, capacity_frames, cl->cat, cl->tag, cl->sid);
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(e, "frames label fill");
+    *out = cl;
+    return LCHD_OK;
+}
+
+extern "C" int lchd_frames_load(lchd_ctx* c, lchd_cloud* fr, const double* xyz, int32_t n_frames, void* hip_stream) {
+    if (!c || !fr || !xyz || !fr->cap_frames) return fail(LCHD_EVALUE, "not a frames buffer");
+    if (n_frames < 1 || n_frames > fr->cap_frames) return fail(LCHD_EVALUE, "%d frames do not fit a buffer of %d", n_frames, fr->cap_frames);
+    if (c->pend.active && (c->pend.a == fr || c->pend.b == fr))
+        return fail(LCHD_EVALUE, "this frames buffer is in use by an unfinished asynchronous call");
+    hipStream_t s = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->stream;
+    const int64_t total = fr->n_tmpl * n_frames;
+    // the pinned staging block is free again once the previous upload from it has completed
+    if (fr->ev_ready && fr->bbox_pending) HIP_TRY(hipEventSynchronize(fr->ev_ready));
+    memcpy(fr->h_pinned, xyz, sizeof(double) * 3 * (size_t)total);
+    if (fr->used_valid) HIP_TRY(hipStreamWaitEvent(s, fr->ev_used, 0));  // do not overwrite frames a running pass still reads
+    HIP_TRY(hipMemcpyAsync(fr->d_raw, fr->h_pinned, sizeof(double) * 3 * (size_t)total, hipMemcpyHostToDevice, s));
+    launch_frames_unpack(s, fr->d_raw, total, fr->x, fr->y, fr->z, fr->d_bbox);
+    HIP_TRY(hipEventRecord(fr->ev_ready, s));
+    HIP_TRY(hipGetLastError());
+    fr->n = total;
+    fr->n_struct = n_frames;
+    fr->bbox_pending = true;
+    return LCHD_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -111,6 +111,11 @@ struct SweepArgs {
     const double* rsqrt_tab;  // [65536] 1/sqrt(k)
 };
 void launch_sweep(hipStream_t s, int n_categories, bool hellinger2, bool unit_weights, bool wf_pow, const SweepArgs& a);
+// trajectory frames: replicate the template's labels / unpack [frames][atoms][3] into SoA + bounding box keys
+void launch_frames_labels(hipStream_t s, const uint8_t* tcat, const int32_t* ttag, int64_t n_tmpl, int32_t n_frames, uint8_t* cat,
+                          int32_t* tag, int32_t* sid);
+void launch_frames_unpack(hipStream_t s, const double* raw, int64_t n_atoms, double* x, double* y, double* z,
+                          unsigned long long* bbox7);
 void launch_fill_sqrt_tables(hipStream_t s, double* sqrt_tab, double* rsqrt_tab);  // 65536 entries each
 void launch_env_points(hipStream_t s, const SweepArgs& a, unsigned long long* out);
 

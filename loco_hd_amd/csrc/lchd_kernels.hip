@@ -1434,3 +1434,50 @@ void launch_fill_sqrt_tables(hipStream_t s, double* sqrt_tab, double* rsqrt_tab)
     k_fill_sqrt_tables<<<256, 256, 0, s>>>(sqrt_tab, rsqrt_tab);
 }
 }  // namespace lchd
+
+namespace lchd {
+__global__ void k_frames_labels(const uint8_t* tcat, const int32_t* ttag, int64_t n_tmpl, int64_t total, uint8_t* cat, int32_t* tag,
+                                int32_t* sid) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t f = i / n_tmpl, k = i - f * n_tmpl;
+        cat[i] = tcat[k];
+        tag[i] = ttag[k];
+        sid[i] = (int32_t)f;
+    }
+}
+void launch_frames_labels(hipStream_t s, const uint8_t* tcat, const int32_t* ttag, int64_t n_tmpl, int32_t n_frames, uint8_t* cat,
+                          int32_t* tag, int32_t* sid) {
+    k_frames_labels<<<2048, 256, 0, s>>>(tcat, ttag, n_tmpl, n_tmpl * n_frames, cat, tag, sid);
+}
+
+// order-preserving map double -> u64 (so that atomicMin / atomicMax on integers order like the doubles)
+__device__ __forceinline__ unsigned long long ordered_key(double d) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(d);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__global__ void k_frames_unpack(const double* __restrict__ raw, int64_t n, double* __restrict__ x, double* __restrict__ y,
+                                double* __restrict__ z, unsigned long long* bbox7) {
+    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    bool bad = false;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double vx = raw[3 * i], vy = raw[3 * i + 1], vz = raw[3 * i + 2];
+        x[i] = vx; y[i] = vy; z[i] = vz;
+        bad = bad || !(fabs(vx) < INFINITY) || !(fabs(vy) < INFINITY) || !(fabs(vz) < INFINITY);
+        mn[0] = fmin(mn[0], vx); mn[1] = fmin(mn[1], vy); mn[2] = fmin(mn[2], vz);
+        mx[0] = fmax(mx[0], vx); mx[1] = fmax(mx[1], vy); mx[2] = fmax(mx[2], vz);
+    }
+    for (int m = 32; m > 0; m >>= 1)
+        for (int k = 0; k < 3; ++k) { mn[k] = fmin(mn[k], shfl_xor_f64(mn[k], m)); mx[k] = fmax(mx[k], shfl_xor_f64(mx[k], m)); }
+    const unsigned long long anybad = __ballot(bad);
+    if ((threadIdx.x & 63) == 0) {
+        for (int k = 0; k < 3; ++k) { atomicMin(&bbox7[k], ordered_key(mn[k])); atomicMax(&bbox7[3 + k], ordered_key(mx[k])); }
+        if (anybad) atomicOr(&bbox7[6], 1ull);
+    }
+}
+void launch_frames_unpack(hipStream_t s, const double* raw, int64_t n_atoms, double* x, double* y, double* z, unsigned long long* bbox7) {
+    static const unsigned long long init[7] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull, 0ull};
+    (void)hipMemcpyAsync(bbox7, init, sizeof init, hipMemcpyHostToDevice, s);
+    const int64_t nb = (n_atoms + 255) / 256;
+    k_frames_unpack<<<(unsigned)(nb < 1024 ? nb : 1024), 256, 0, s>>>(raw, n_atoms, x, y, z, bbox7);
+}
+}  // namespace lchd

@@ -94,6 +94,68 @@ class DeviceSession:
                                                  float(threshold_distance), C.c_void_p(out.data_ptr())))
         return out
 
+    # ---- asynchronous form + trajectory streaming ----------------------------------------------------------------
+    def from_primitives_async(self, cloud_a, cloud_b, anchors, threshold_distance: float, out, wf_index=None):
+        """Enqueue one pass and return immediately; `finish()` waits for it and raises on errors."""
+        torch = self.torch
+        assert anchors.is_cuda and anchors.dtype == torch.int64 and anchors.is_contiguous()
+        assert out.is_cuda and out.dtype == torch.float64 and out.is_contiguous() and out.numel() >= anchors.shape[0]
+        wf_ptr = None if wf_index is None else C.c_void_p(wf_index.data_ptr())
+        N.check(N.lib().lchd_from_primitives_dev_async(self._ctx, cloud_a, cloud_b, C.c_void_p(anchors.data_ptr()), wf_ptr,
+                                                       anchors.shape[0], float(threshold_distance), C.c_void_p(out.data_ptr())))
+
+    def finish(self):
+        N.check(N.lib().lchd_ctx_finish(self._ctx))
+
+    def frames_buffer(self, template_cloud, capacity_frames: int):
+        """Device buffer for `capacity_frames` frames of the template structure (same atoms, new coordinates)."""
+        h = C.c_void_p()
+        N.check(N.lib().lchd_frames_create(self._ctx, template_cloud, int(capacity_frames), C.byref(h)))
+        self._clouds.append(h)
+        return h
+
+    def load_frames(self, buf, xyz: np.ndarray, stream=None):
+        """Stage xyz [n_frames][n_atoms][3] (host) into a frames buffer; the copy runs on `stream` (a torch.cuda.Stream)
+        without waiting, so it overlaps a pass that is running on the session's own stream."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+        assert xyz.ndim == 3 and xyz.shape[2] == 3
+        sp = None if stream is None else C.c_void_p(stream.cuda_stream)
+        N.check(N.lib().lchd_frames_load(self._ctx, buf, N.dp(xyz), xyz.shape[0], sp))
+
+    def score_trajectory(self, ref_cloud, frames_xyz: np.ndarray, local_pairs, threshold_distance: float, chunk: int = 1024):
+        """MD-trajectory mode (python_codes/trajectory_analyzer.py:97-119): score every frame of `frames_xyz`
+        [n_frames][n_atoms][3] against the reference structure for the anchor pairs `local_pairs` [(atom in reference,
+        atom in frame)].  Frames are streamed in chunks: while chunk k is scored, chunk k+1 is copied on a second
+        stream into the other of two buffers.  Returns a float64 array [n_frames][len(local_pairs)]."""
+        torch = self.torch
+        frames_xyz = np.ascontiguousarray(frames_xyz, dtype=np.float64)
+        n_frames, n_atoms = frames_xyz.shape[0], frames_xyz.shape[1]
+        lp = np.ascontiguousarray(local_pairs, dtype=np.int64).reshape(-1, 2)
+        chunk = max(1, min(int(chunk), n_frames))
+        dev = torch.device("cuda", self.device)
+        offs = torch.arange(chunk, dtype=torch.int64, device=dev).repeat_interleave(len(lp)) * n_atoms
+        anchors = torch.from_numpy(np.tile(lp, (chunk, 1))).to(dev)
+        anchors[:, 1] += offs
+        anchors = anchors.contiguous()
+        out = torch.empty(n_frames * len(lp), dtype=torch.float64, device=dev)
+        bufs = [self.frames_buffer(ref_cloud, chunk), self.frames_buffer(ref_cloud, chunk)]
+        copy_stream = torch.cuda.Stream(device=dev)
+        starts = list(range(0, n_frames, chunk))
+        self.load_frames(bufs[0], frames_xyz[starts[0]:starts[0] + chunk], copy_stream)
+        for k, f0 in enumerate(starts):
+            nf = min(chunk, n_frames - f0)
+            self.from_primitives_async(ref_cloud, bufs[k % 2], anchors[: nf * len(lp)], threshold_distance,
+                                       out[f0 * len(lp):(f0 + nf) * len(lp)])
+            if k + 1 < len(starts):
+                f1 = starts[k + 1]
+                self.load_frames(bufs[(k + 1) % 2], frames_xyz[f1:f1 + chunk], copy_stream)
+            self.finish()
+        res = out.cpu().numpy().reshape(n_frames, len(lp))
+        for b in bufs:
+            N.lib().lchd_cloud_destroy(self._ctx, b)
+            self._clouds.remove(b)
+        return res
+
     def close(self):
         if self._ctx:
             for h in self._clouds:

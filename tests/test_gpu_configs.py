@@ -197,3 +197,39 @@ def test_batched_structures_match_single_calls(lh):
     for f in range(5):
         assert np.array_equal(scores[f * len(local_anchors):(f + 1) * len(local_anchors)], want[(0, f + 1)])
     sess.close()
+
+
+def test_trajectory_streaming_matches_single_calls(lh, oracle):
+    """BASELINE config 4: frames streamed in chunks through two device buffers on a copy stream."""
+    from loco_hd_amd.device import DeviceSession
+
+    rng = np.random.default_rng(8)
+    n_res = 120
+    side = (3 * n_res / 0.023) ** (1 / 3)
+    seq, xyz, tags = cg_structure(rng, n_res, side)
+    n_frames = 23  # not a multiple of the chunk size
+    frames = xyz[None, :, :] + rng.normal(0.0, 0.5, (n_frames,) + xyz.shape)
+    la = np.arange(0, 3 * n_res, 3)
+    local_pairs = np.stack([la, la], 1)
+    rule = {"accept_same": False}
+    lchd = lh.LoCoHD(CG_TYPES, lh.WeightFunction("uniform", [3.0, 10.0]), lh.TagPairingRule(rule))
+    interner = {}
+    packed = lchd.pack(prims(lh, seq, xyz, tags), interner)
+    sess = DeviceSession(lchd, interner=interner)
+    ref = sess.upload(packed.xyz, packed.cat, packed.tag)
+    got = sess.score_trajectory(ref, frames, local_pairs, 10.0, chunk=5)
+    assert got.shape == (n_frames, len(la))
+    sess.close()
+    lo = oracle.LoCoHD(CG_TYPES, oracle.WeightFunction("uniform", [3.0, 10.0]), oracle.TagPairingRule(rule))
+    ref_p = prims(oracle, seq, xyz, tags)
+    for f in (0, 4, 5, 11, 22):
+        want = np.asarray(lo.from_primitives(ref_p, prims(oracle, seq, frames[f], tags), [(int(i), int(i)) for i in la], 10.0))
+        assert np.max(np.abs(got[f] - want)) < TIGHT, f
+    # non-finite coordinates in a frame are refused
+    sess = DeviceSession(lchd, interner=interner)
+    ref = sess.upload(packed.xyz, packed.cat, packed.tag)
+    bad = frames.copy()
+    bad[3, 7, 1] = np.nan
+    with pytest.raises(ValueError):
+        sess.score_trajectory(ref, bad, local_pairs, 10.0, chunk=8)
+    sess.close()
