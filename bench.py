@@ -163,18 +163,33 @@ def main():
     cloud_b = sess.upload(w["xyz_b"], w["cat_b"])
     anchors = torch.from_numpy(w["pairs"]).to(dev)
     p = anchors.shape[0]
-    out = torch.empty(p, dtype=torch.float64, device=dev)
-    gathered = torch.empty(p * world, dtype=torch.float64, device=dev) if (use_dist and rank == 0) else None
+    # Two score buffers: the RCCL gather of step k (asynchronous, on RCCL's stream) overlaps the scoring of step k+1.
+    outs = [torch.empty(p, dtype=torch.float64, device=dev) for _ in range(2)]
+    gathered = [torch.empty(p * world, dtype=torch.float64, device=dev) if (use_dist and rank == 0) else None for _ in range(2)]
+    pending = [None, None]
     sess.enable_timing(True)
+    counter = [0]
 
     def step():
-        sess.from_primitives(cloud_a, cloud_b, anchors, w["thr"], out=out)
+        k = counter[0] % 2
+        counter[0] += 1
+        if pending[k] is not None:  # the gather that last read this buffer must be done before it is overwritten
+            pending[k].wait()
+            pending[k] = None
+        sess.from_primitives(cloud_a, cloud_b, anchors, w["thr"], out=outs[k])
         if use_dist:
-            gather_scores(out, gathered, world, rank, force_collective=True)
+            pending[k] = gather_scores(outs[k], gathered[k], world, rank, force_collective=True, async_op=True)
+
+    def drain():
+        for k in range(2):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
 
     phase_ms = {"cells": 0.0, "anchors": 0.0, "env": 0.0, "sweep": 0.0}
     for _ in range(args.warmup):
         step()
+    drain()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -183,6 +198,7 @@ def main():
         step()
         for k, v in sess.last_ms().items():
             phase_ms[k] += v
+    drain()  # every gather of the timed steps has completed inside the timed region
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -194,6 +210,7 @@ def main():
 
     phase_ms = {k: v / max(args.steps, 1) for k, v in phase_ms.items()}
     env_points = sess.last_env_points()  # sum over this rank's pairs of n_A + n_B
+    out = outs[(counter[0] - 1) % 2]
     scores = out.cpu().numpy()
 
     if rank == 0:
@@ -230,8 +247,8 @@ def main():
                 result["parity_failed"] = True
         final_line = json.dumps(result)
     if use_dist:
-        if rank == 0 and gathered is not None:
-            assert torch.equal(gathered[:p], out), "gathered scores differ from the local ones"
+        if rank == 0 and gathered[(counter[0] - 1) % 2] is not None:
+            assert torch.equal(gathered[(counter[0] - 1) % 2][:p], out), "gathered scores differ from the local ones"
         dist.barrier()
         dist.destroy_process_group()
     sess.close()

@@ -17,17 +17,19 @@ def shard_bounds(n_pairs: int, world: int, rank: int) -> Tuple[int, int, int]:
     return lo, min(lo + chunk, n_pairs), chunk
 
 
-def gather_scores(local, gathered, world: int, rank: int, group=None, force_collective: bool = False) -> None:
-    """Gather equal-length score vectors to rank 0: gathered[r*len : (r+1)*len] = rank r's `local`."""
+def gather_scores(local, gathered, world: int, rank: int, group=None, force_collective: bool = False, async_op: bool = False):
+    """Gather equal-length score vectors to rank 0: gathered[r*len : (r+1)*len] = rank r's `local`.
+    With async_op=True the collective's work handle is returned (call .wait() before reusing `local`)."""
     import torch.distributed as dist
 
     if world == 1 and not force_collective:
         if gathered is not None:
             gathered[: local.numel()].copy_(local)
-        return
+        return None
     n = local.numel()
     chunks = [gathered[r * n:(r + 1) * n] for r in range(world)] if rank == 0 else None
-    dist.gather(local, gather_list=chunks, dst=0, group=group)
+    work = dist.gather(local, gather_list=chunks, dst=0, group=group, async_op=async_op)
+    return work if async_op else None
 
 
 def score_sharded(score_fn: Callable, anchors, world: int, rank: int, group=None):
