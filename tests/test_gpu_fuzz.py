@@ -1,0 +1,91 @@
+"""Seeded random configurations of the whole API surface, HIP path vs CPU oracle.
+
+Every case draws: cloud sizes and density, category count, category weights, weight function family and parameters
+(ranges of /root/reference/tests/generate_locohd_testcases.py:19-67), statistical distance (:70-103), tag rule,
+threshold, single vs. dictionary weight functions and the driver (from_primitives / from_coords / from_dmxs)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def draw_wf(rng):
+    k = rng.integers(0, 5)
+    if k == 0:
+        return ("hyper_exp", [1.0, 1.0 / rng.uniform(3.0, 20.0)])
+    if k == 1:
+        return ("hyper_exp", np.concatenate([rng.uniform(1e-5, 1.0, 3), 1.0 / rng.uniform(3.0, 20.0, 3)]).tolist())
+    if k == 2:
+        return ("dagum", [rng.uniform(0.5, 3.0), rng.uniform(1.5, 4.0), rng.uniform(1.0, 25.0)])
+    a = rng.uniform(0.5, 10.0)
+    if k == 3:
+        return ("uniform", [a, a + rng.uniform(0.1, 10.0)])
+    return ("kumaraswamy", [a, a + rng.uniform(0.1, 10.0), rng.uniform(1.00001, 10.0), rng.uniform(1.00001, 10.0)])
+
+
+def draw_sd(rng):
+    k = rng.integers(0, 6)
+    if k <= 1:
+        return ("Hellinger", [2.0])
+    if k == 2:
+        return ("Hellinger", [rng.uniform(1.0, 5.0)])
+    if k == 3:
+        return ("Kolmogorov-Smirnov", [])
+    if k == 4:
+        return ("Kullback-Leibler", [rng.uniform(0.001, 5.0)])
+    return ("Renyi", [rng.uniform(0.001, 5.0), rng.uniform(0.001, 5.0)])
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_configuration(oracle, seed):
+    import loco_hd_amd as lh
+
+    rng = np.random.default_rng(1000 + seed)
+    ncat = int(rng.choice([2, 3, 5, 7, 10, 13, 20, 25, 31, 40]))
+    cats = [f"t{i}" for i in range(ncat)]
+    weights = None if rng.random() < 0.6 else rng.uniform(0.2, 3.0, ncat).tolist()
+    na, nb = int(rng.integers(20, 400)), int(rng.integers(20, 400))
+    box = float(rng.uniform(6.0, 40.0))
+    xa, xb = rng.uniform(-box, box, (na, 3)), rng.uniform(-box, box, (nb, 3))
+    if rng.random() < 0.3:  # lattice coordinates: many exact distance ties
+        xa, xb = np.round(xa), np.round(xb)
+    sa, sb = rng.choice(cats, na).tolist(), rng.choice(cats, nb).tolist()
+    multi = rng.random() < 0.3
+    wfs = {f"k{i}": draw_wf(rng) for i in range(3)} if multi else draw_wf(rng)
+    sd = draw_sd(rng)
+    mode = rng.choice(["prims", "prims", "prims", "coords", "dmxs"])
+    tag_kind = rng.integers(0, 4)
+    tags_a = [f"r{i // 4}" for i in range(na)]
+    tags_b = [f"r{i // 4}" for i in range(nb)]
+    rule = [{"accept_same": True}, {"accept_same": False},
+            {"tag_pairs": {(f"r{i}", f"r{j}") for i in range(0, 20) for j in range(0, 100, 7)}, "accepted_pairs": bool(rng.integers(0, 2)),
+             "ordered": bool(rng.integers(0, 2))}, None][tag_kind]
+    if tag_kind == 0:  # accept_same=True with distinct tags would empty most environments; use uniform tags instead
+        tags_a, tags_b = [""] * na, [""] * nb
+    thr = float(rng.uniform(0.3, 1.5) * box)
+    npairs = int(rng.integers(1, 300))
+    pairs = [(int(i), int(j)) for i, j in zip(rng.integers(0, na, npairs), rng.integers(0, nb, npairs))]
+    keys = [f"k{int(i)}" for i in rng.integers(0, 3, max(npairs, na))]
+
+    def run(mod):
+        wf = {k: mod.WeightFunction(*v) for k, v in wfs.items()} if multi else mod.WeightFunction(*wfs)
+        lchd = mod.LoCoHD(cats, wf, None if rule is None else mod.TagPairingRule(rule), category_weights=weights,
+                          statistical_distance=mod.StatisticalDistance(*sd))
+        if mode == "prims":
+            pa = [mod.PrimitiveAtom(s, t, c) for s, t, c in zip(sa, tags_a, xa)]
+            pb = [mod.PrimitiveAtom(s, t, c) for s, t, c in zip(sb, tags_b, xb)]
+            ap = [(i, j, k) for (i, j), k in zip(pairs, keys)] if multi else pairs
+            return np.asarray(lchd.from_primitives(pa, pb, ap, thr))
+        n = min(na, nb)
+        if mode == "coords":
+            return np.asarray(lchd.from_coords(sa[:n], sb[:n], xa[:n], xb[:n], keys[:n] if multi else None))
+        da = np.sqrt(((xa[:n, None, :] - xa[None, :, :]) ** 2).sum(-1))
+        db = np.sqrt(((xb[:n, None, :] - xb[None, :, :]) ** 2).sum(-1))
+        return np.asarray(lchd.from_dmxs(sa, sb, da, db, keys[:n] if multi else None))
+
+    got, want = run(lh), run(oracle)
+    assert got.shape == want.shape
+    finite = np.isfinite(want)
+    assert np.array_equal(finite, np.isfinite(got))
+    tol = 1e-10 * max(1.0, float(np.max(np.abs(want[finite]))) if finite.any() else 1.0)
+    assert np.max(np.abs(got[finite] - want[finite]), initial=0.0) < tol, (seed, mode, sd, wfs)
