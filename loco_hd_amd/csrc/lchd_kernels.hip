@@ -1329,7 +1329,9 @@ static void launch_sweep_mode(hipStream_t s, int cmax, unsigned grid, const Swee
     if (cmax <= 8) k_sweep<8, MODE, FMODE, LDSTAB><<<grid, NTH, 0, s>>>(a);
     else if (cmax <= 12) k_sweep<12, MODE, FMODE, LDSTAB><<<grid, NTH, 0, s>>>(a);
     else if (cmax <= 16) k_sweep<16, MODE, FMODE, LDSTAB><<<grid, NTH, 0, s>>>(a);
+    else if (cmax <= 20) k_sweep<20, MODE, FMODE, LDSTAB><<<grid, NTH, 0, s>>>(a);
     else if (cmax <= 24) k_sweep<24, MODE, FMODE, LDSTAB><<<grid, NTH, 0, s>>>(a);
+    else if (cmax <= 28) k_sweep<28, MODE, FMODE, LDSTAB><<<grid, NTH, 0, s>>>(a);
     else k_sweep<32, MODE, FMODE, LDSTAB><<<grid, NTH, 0, s>>>(a);
 }
 template <int MODE, bool LDSTAB>

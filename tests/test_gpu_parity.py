@@ -314,7 +314,7 @@ def test_error_behaviour(lh):
 
 
 @pytest.mark.parametrize("hook", [{"LCHD_FORCE_CMAX": "8"}, {"LCHD_FORCE_CMAX": "12"}, {"LCHD_FORCE_CMAX": "16"},
-                                  {"LCHD_FORCE_CMAX": "24"}, {"LCHD_FORCE_CMAX": "32"}, {"LCHD_FORCE_GENERIC": "1"},
+                                  {"LCHD_FORCE_CMAX": "20"}, {"LCHD_FORCE_CMAX": "24"}, {"LCHD_FORCE_CMAX": "28"}, {"LCHD_FORCE_CMAX": "32"}, {"LCHD_FORCE_GENERIC": "1"},
                                   {"LCHD_FORCE_BIGENV": "1"}, {"LCHD_FORCE_GENERIC": "1", "LCHD_FORCE_CMAX": "16"},
                                   {"LCHD_FORCE_WIDE": "1"}, {"LCHD_FORCE_WIDE": "1", "LCHD_FORCE_GENERIC": "1"},
                                   {"LCHD_NO_CDF_KEYS": "1"}, {"LCHD_NO_CDF_KEYS": "1", "LCHD_FORCE_WIDE": "1"}])
