@@ -356,6 +356,56 @@ __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ 
     }
 
     int count = 0;  // NT == 64: the wave's running count; NT > 64: unused (count_s is the shared cursor)
+    if constexpr (NT == 64) {
+        // One wavefront: the latency of the dependent loads (cell_start -> atoms) dominates, so fetch the bounds of all
+        // nine (y,z) rows first and then walk the rows 64 atoms at a time with the coordinate loads of all rows of a
+        // step issued together.
+        int rb[9], re[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int zz = cz - 1 + k / 3, yy = cy - 1 + k % 3;
+            const bool in = zz >= 0 && zz < g.dim[2] && yy >= 0 && yy < g.dim[1];
+            const int row = in ? (int)((((int64_t)asid * g.dim[2] + zz) * g.dim[1] + yy) * g.dim[0]) : 0;
+            const int b_ = (int)g.cell_start[row + x0], e_ = (int)g.cell_start[row + x1 + 1];
+            rb[k] = in ? b_ : 0;
+            re[k] = in ? e_ : 0;
+        }
+        int maxlen = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) maxlen = max(maxlen, re[k] - rb[k]);
+        for (int c0 = 0; c0 < maxlen; c0 += 64) {
+            double X[9], Y[9], Z[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int idx = rb[k] + c0 + lane;
+                const bool v = idx < re[k];
+                X[k] = v ? g.px[idx] : 0.0;
+                Y[k] = v ? g.py[idx] : 0.0;
+                Z[k] = v ? g.pz[idx] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                if (rb[k] + c0 < re[k]) {  // wave-uniform: this row still has atoms at this step
+                    const int idx = rb[k] + c0 + lane;
+                    const double dx = X[k] - ax, dy = Y[k] - ay, dz = Z[k] - az;
+                    double d2 = dx * dx;   // TU is built with -ffp-contract=off: same roundings as the
+                    d2 = d2 + dy * dy;     // reference's `distance += diff * diff`
+                    d2 = d2 + dz * dz;
+                    bool ok = false;
+                    if (idx < re[k] && d2 < thr2) ok = (g.porig[idx] == anchor) || tag_pair_accepted(cfg, atag, g.ptag[idx]);
+                    const unsigned long long m = __ballot(ok);
+                    if (ok) {
+                        const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
+                        if (pos < cap) {
+                            key[pos] = d2u(sqrt(d2));
+                            val[pos] = g.pcat[idx];
+                        }
+                    }
+                    count += __popcll(m);
+                }
+            }
+        }
+    } else {
     for (int zz = max(cz - 1, 0); zz <= min(cz + 1, g.dim[2] - 1); ++zz) {
         for (int yy = max(cy - 1, 0); yy <= min(cy + 1, g.dim[1] - 1); ++yy) {
             // the (up to) three x-neighbour cells of one (y,z) row are contiguous in the cell-ordered arrays
@@ -367,17 +417,16 @@ __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ 
                 double d2 = 0.0;
                 if (idx < end) {
                     const double dx = g.px[idx] - ax, dy = g.py[idx] - ay, dz = g.pz[idx] - az;
-                    d2 = dx * dx;          // TU is built with -ffp-contract=off: same roundings as the
-                    d2 = d2 + dy * dy;     // reference's `distance += diff * diff`
+                    d2 = dx * dx;
+                    d2 = d2 + dy * dy;
                     d2 = d2 + dz * dz;
                     if (d2 < thr2) ok = (g.porig[idx] == anchor) || tag_pair_accepted(cfg, atag, g.ptag[idx]);
                 }
                 const unsigned long long m = __ballot(ok);
-                int wbase = count;
-                if (NT > 64) {  // several waves append concurrently: reserve a slice of the list per wave-iteration
-                    if (lane == 0 && m) wbase = atomicAdd(&count_s, __popcll(m));
-                    wbase = __shfl(wbase, 0);
-                }
+                int wbase = 0;
+                // several waves append concurrently: reserve a slice of the list per wave-iteration
+                if (lane == 0 && m) wbase = atomicAdd(&count_s, __popcll(m));
+                wbase = __shfl(wbase, 0);
                 if (ok) {
                     const int pos = wbase + __popcll(m & ((1ull << lane) - 1ull));
                     if (pos < cap) {
@@ -385,9 +434,9 @@ __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ 
                         val[pos] = g.pcat[idx];
                     }
                 }
-                count += __popcll(m);
             }
         }
+    }
     }
     if (NT > 64) {
         __syncthreads();
