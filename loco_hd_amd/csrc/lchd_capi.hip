@@ -829,8 +829,8 @@ static int dense_driver(lchd_ctx* c, const lchd_config* cfg, const int32_t* seq_
     if (cols_a > len_seq_a || cols_b > len_seq_b) return fail(LCHD_EPANIC, "index out of bounds: a distance row is longer than its seq");
     if (cols_a == 0 || cols_b == 0) return fail(LCHD_EPANIC, "index out of bounds: empty distance row (src/locohd.rs:74)");
     const int cap_a = next_pow2_host(cols_a), cap_b = next_pow2_host(cols_b);
-    if (cap_a > 16384 || cap_b > 16384)
-        return fail(LCHD_EUNSUPPORTED, "dense rows of more than 16384 points are not supported by this build (got %lld / %lld)",
+    if (cols_a > 65535 || cols_b > 65535)
+        return fail(LCHD_EUNSUPPORTED, "dense rows of more than 65535 points are not supported by this build (got %lld / %lld)",
                     (long long)cols_a, (long long)cols_b);
     lchd_cloud *a = nullptr, *b = nullptr;
     int rc = lchd_cloud_create(c, xyz_a, seq_a, nullptr, cols_a, &a);

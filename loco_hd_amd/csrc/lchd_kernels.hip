@@ -492,13 +492,14 @@ bool launch_env_cells(hipStream_t s, int cap, const DevConfig* cfg, const CloudV
 // utils.rs:10-22 + :25-39) or from_dmxs (a caller-supplied distance-matrix row, src/locohd.rs:439-440).
 // Dynamic LDS: n2 * 9 bytes.
 // ------------------------------------------------------------------------------------------------
-constexpr int kRowBuckets = 2048;     // distance buckets of the dense-row sort
+constexpr int kRowBucketsSmall = 2048;   // distance buckets of the dense-row sort (rows <= 16384 points)
+constexpr int kRowBucketsBig = 16384;    // ... for rows of up to 65535 points (keys stay in global memory)
 constexpr int kRowCoarse = 256;       // uniform bins of the row's empirical distance CDF
 constexpr int kRowBucketLimit = 64;   // a fuller bucket sends the row to the bitonic network instead
 
-template <int NT>
+template <int NT, bool GLOBALKV>
 __global__ __launch_bounds__(NT) void k_env_rows(const DevConfig* __restrict__ cfgp, CloudView c, const double* __restrict__ dmx,
-                                                 int64_t ld, int64_t row_len, int n2, EnvStore env, DeviceStatus* st) {
+                                                 int64_t ld, int64_t row_len, int n2, int n_buckets, EnvStore env, DeviceStatus* st) {
     // Sorting one row of n <= 16384 distances in O(n): an empirical CDF of the row on kRowCoarse uniform bins of
     // [0, d_max] gives every point an interpolated rank; rank * kRowBuckets / n is its bucket, so buckets hold
     // ~n / kRowBuckets points whatever the shape of the cloud.  One LDS histogram + scan + scatter puts the points
@@ -506,10 +507,15 @@ __global__ __launch_bounds__(NT) void k_env_rows(const DevConfig* __restrict__ c
     // distance -> bucket is monotone, which is all correctness needs; a pathological row (a bucket with more than
     // kRowBucketLimit points, e.g. thousands of identical distances) takes the bitonic network instead.
     // Distances are recomputed in every phase (3 L2-resident loads + a sqrt) instead of being kept in registers.
+    // GLOBALKV (rows of 16 385 .. 65 535 points): the keys are sorted in place in the environment store (global memory,
+    // L2-resident per row) and only the bucket histogram lives in LDS; otherwise keys and categories are in LDS too.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t* key = reinterpret_cast<uint64_t*>(smem);
-    uint8_t* val = smem + (size_t)n2 * 8;
-    uint32_t* hist = reinterpret_cast<uint32_t*>(smem + (size_t)n2 * 9 + ((16 - (((size_t)n2 * 9) & 15)) & 15));  // [kRowBuckets + 1]
+    const int64_t r_ = blockIdx.x;
+    uint64_t* key = GLOBALKV ? env.key + r_ * env.stride : reinterpret_cast<uint64_t*>(smem);
+    uint8_t* val = GLOBALKV ? env.cat + r_ * env.stride : smem + (size_t)n2 * 8;
+    uint32_t* hist = GLOBALKV ? reinterpret_cast<uint32_t*>(smem)
+                              : reinterpret_cast<uint32_t*>(smem + (size_t)n2 * 9 + ((16 - (((size_t)n2 * 9) & 15)) & 15));  // [n_buckets + 1]
+    const int kRowBuckets = n_buckets;
     __shared__ double red_max[16];
     __shared__ uint32_t red_cnt[16];
     __shared__ uint32_t scan_carry;
@@ -634,29 +640,42 @@ __global__ __launch_bounds__(NT) void k_env_rows(const DevConfig* __restrict__ c
     }
     __syncthreads();
     if (env.cdf_keys) keys_to_cdf_lds<NT>(key, n, tid, cfgp);
-    uint64_t* ok_ = env.key + r * env.stride;
-    uint8_t* oc_ = env.cat + r * env.stride;
-    for (int i = tid; i < n; i += NT) { ok_[i] = key[i]; oc_[i] = val[i]; }
+    if constexpr (!GLOBALKV) {
+        uint64_t* ok_ = env.key + r * env.stride;
+        uint8_t* oc_ = env.cat + r * env.stride;
+        for (int i = tid; i < n; i += NT) { ok_[i] = key[i]; oc_[i] = val[i]; }
+    }
 }
 
 bool launch_env_rows(hipStream_t s, int cap, const DevConfig* cfg, const CloudView& c, const double* dmx, int64_t ld,
                      int64_t n_rows, int64_t row_len, EnvStore env, DeviceStatus* st) {
     if (n_rows <= 0) return true;
-    if (cap > 16384 || row_len > cap) return false;
-    const size_t lds = (size_t)cap * 9 + 16 + (size_t)(kRowBuckets + 1) * sizeof(uint32_t);
+    if (cap > 65536 || row_len > cap || row_len > 65535) return false;
     const dim3 grid((unsigned)n_rows);
+    if (cap > 16384) {  // keys in global memory, 64 KB histogram in LDS
+        const size_t lds = (size_t)(kRowBucketsBig + 1) * sizeof(uint32_t) + 16;
+        static bool attr_big = false;
+        if (!attr_big) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_rows<1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)((kRowBucketsBig + 1) * sizeof(uint32_t) + 16));
+            attr_big = true;
+        }
+        k_env_rows<1024, true><<<grid, 1024, lds, s>>>(cfg, c, dmx, ld, row_len, cap, kRowBucketsBig, env, st);
+        return true;
+    }
+    const size_t lds = (size_t)cap * 9 + 16 + (size_t)(kRowBucketsSmall + 1) * sizeof(uint32_t);
     if (cap <= 1024) {
-        k_env_rows<64><<<grid, 64, lds, s>>>(cfg, c, dmx, ld, row_len, cap, env, st);
+        k_env_rows<64, false><<<grid, 64, lds, s>>>(cfg, c, dmx, ld, row_len, cap, kRowBucketsSmall, env, st);
     } else if (cap <= 4096) {
-        k_env_rows<256><<<grid, 256, lds, s>>>(cfg, c, dmx, ld, row_len, cap, env, st);
+        k_env_rows<256, false><<<grid, 256, lds, s>>>(cfg, c, dmx, ld, row_len, cap, kRowBucketsSmall, env, st);
     } else {
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_rows<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                16384 * 9 + 16 + (kRowBuckets + 1) * 4);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_rows<1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      16384 * 9 + 16 + (kRowBucketsSmall + 1) * 4);
             attr_set = true;
         }
-        k_env_rows<1024><<<grid, 1024, lds, s>>>(cfg, c, dmx, ld, row_len, cap, env, st);
+        k_env_rows<1024, false><<<grid, 1024, lds, s>>>(cfg, c, dmx, ld, row_len, cap, kRowBucketsSmall, env, st);
     }
     return true;
 }

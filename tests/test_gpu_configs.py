@@ -233,3 +233,27 @@ def test_trajectory_streaming_matches_single_calls(lh, oracle):
     with pytest.raises(ValueError):
         sess.score_trajectory(ref, bad, local_pairs, 10.0, chunk=8)
     sess.close()
+
+
+def test_dense_rows_beyond_lds_capacity(lh, oracle):
+    """from_coords on 17 000-atom clouds: rows no longer fit in LDS, the keys are bucket-sorted in global memory.
+    Checked against the oracle's sweep on NumPy-sorted environments for a sample of rows, plus self-comparison."""
+    rng = np.random.default_rng(9)
+    n = 17_000
+    side = (n / 0.05) ** (1 / 3)
+    cats = [f"c{i}" for i in range(6)]
+    xa, xb = rng.uniform(0, side, (n, 3)), rng.uniform(0, side, (n, 3))
+    sa, sb = rng.choice(cats, n).tolist(), rng.choice(cats, n).tolist()
+    lchd = lh.LoCoHD(cats, lh.WeightFunction("hyper_exp", [1.0, 0.1]))
+    got = np.asarray(lchd.from_coords(sa, sb, xa, xb))
+    assert got.shape == (n,) and np.all(np.isfinite(got)) and got.min() >= 0.0 and got.max() <= 1.0
+    lo = oracle.LoCoHD(cats, oracle.WeightFunction("hyper_exp", [1.0, 0.1]))
+    sa_arr, sb_arr = np.asarray(sa), np.asarray(sb)
+    for i in (0, 1, 4242, 9999, n - 1):
+        da = np.sqrt((((xa[i] - xa) ** 2)[:, 0] + ((xa[i] - xa) ** 2)[:, 1]) + ((xa[i] - xa) ** 2)[:, 2])
+        db = np.sqrt((((xb[i] - xb) ** 2)[:, 0] + ((xb[i] - xb) ** 2)[:, 1]) + ((xb[i] - xb) ** 2)[:, 2])
+        oa, ob = np.argsort(da, kind="stable"), np.argsort(db, kind="stable")
+        want = lo.from_anchors(sa_arr[oa].tolist(), sb_arr[ob].tolist(), da[oa].tolist(), db[ob].tolist())
+        assert abs(got[i] - want) < TIGHT, i
+    same = np.asarray(lchd.from_coords(sa, sa, xa, xa))
+    assert np.max(np.abs(same)) == 0.0
