@@ -705,6 +705,9 @@ bool launch_env_rows(hipStream_t s, int cap, const DevConfig* cfg, const CloudVi
 enum { MODE_H2U = 0, MODE_H2W = 1, MODE_GEN = 2 };
 // where F(t) comes from: the environment keys already are F values / inline CDFs only / any CDF
 enum { F_KEY = 0, F_FAST = 1, F_ANY = 2 };
+#ifndef LCHD_BRANCHFREE_HEADS
+#define LCHD_BRANCHFREE_HEADS 1
+#endif
 #ifndef LCHD_SWEEP_WAVES
 #define LCHD_SWEEP_WAVES 4
 #endif
@@ -803,8 +806,9 @@ __device__ __noinline__ double sd_generic(int kind, double p0, double p1, const 
     return sd_eval<0>(kind, p0, p1, [&](int c) { return p[c]; }, [&](int c) { return q[c]; }, C);
 }
 
+// register budget: 4 waves/SIMD (<= 128 VGPRs) up to 12 category slots, 3 (<= 168) up to 16, 2 beyond
 template <int CMAX, int MODE, int FMODE, bool LDSTAB>
-__global__ __launch_bounds__(64 * kSweepWaves, LCHD_SWEEP_MINW) void k_sweep(SweepArgs args) {
+__global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 12 ? 4 : (CMAX <= 16 ? 3 : 2))) void k_sweep(SweepArgs args) {
     constexpr int EPL = kSweepEPL, TILE = kSweepTile, WPB = kSweepWaves;
     constexpr int NW = CMAX / 4;          // u64 words of 16-bit count fields per side
     constexpr int NH = (CMAX + 15) / 16;  // u64 words of 4-bit histogram fields per side
@@ -900,7 +904,10 @@ __global__ __launch_bounds__(64 * kSweepWaves, LCHD_SWEEP_MINW) void k_sweep(Swe
         }
 
         // ---- per-lane state -------------------------------------------------------------------------
-        uint64_t exA[NW], exB[NW];   // packed category counts at this lane's position
+        uint64_t exA[NW], exB[NW];   // packed category counts at the start of this lane's chunk
+        uint64_t dA[NH], dB[NH];     // what the chunk has added so far, 4 bits per category
+#pragma unroll
+        for (int k = 0; k < NH; ++k) dA[k] = dB[k] = 0;
         int totA = 1, totB = 1;      // points seen per side (incl. anchor)
         double ra = 0.0, rb = 0.0;   // H2: 1/sqrt(total weight)
         double na = 0.0, nb = 0.0;   // H2W: total weights
@@ -948,7 +955,9 @@ __global__ __launch_bounds__(64 * kSweepWaves, LCHD_SWEEP_MINW) void k_sweep(Swe
 #pragma unroll
                 for (int f = 0; f < 4; ++f) {
                     const int c = 4 * k + f;
-                    const double d = root_of(c, field(exA, c)) * ra - root_of(c, field(exB, c)) * rb;  // equal inputs cancel exactly
+                    const int ca = field(exA, c) + (int)((dA[c >> 4] >> ((c & 15) * 4)) & 15ull);
+                    const int cb = field(exB, c) + (int)((dB[c >> 4] >> ((c & 15) * 4)) & 15ull);
+                    const double d = root_of(c, ca) * ra - root_of(c, cb) * rb;  // equal inputs cancel exactly
                     acc2 = fma(d, d, acc2);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -996,11 +1005,35 @@ __global__ __launch_bounds__(64 * kSweepWaves, LCHD_SWEEP_MINW) void k_sweep(Swe
             const int T = min(TILE, M - k0);
             const int nAt = min(TILE, mA - ia), nBt = min(TILE, mB - ib);
             wave_sync_lds();  // previous tile fully consumed
-            for (int t = lane; t < nAt; t += 64) { sA[t] = kA[1 + ia + t]; cA[t] = tA[1 + ia + t]; }
-            for (int t = lane; t < nBt; t += 64) { sB[t] = kB[1 + ib + t]; cB[t] = tB[1 + ib + t]; }
+            {   // stage the tile: all global loads of a list are issued before the first LDS write (one latency, not six)
+                uint64_t rk[EPL];
+                uint8_t rc[EPL];
+#pragma unroll
+                for (int u = 0; u < EPL; ++u) {
+                    const int t = lane + 64 * u;
+                    rk[u] = t < nAt ? kA[1 + ia + t] : 0ull;
+                    rc[u] = t < nAt ? tA[1 + ia + t] : (uint8_t)0;
+                }
+#pragma unroll
+                for (int u = 0; u < EPL; ++u) {
+                    const int t = lane + 64 * u;
+                    if (t < nAt) { sA[t] = rk[u]; cA[t] = rc[u]; }
+                }
+#pragma unroll
+                for (int u = 0; u < EPL; ++u) {
+                    const int t = lane + 64 * u;
+                    rk[u] = t < nBt ? kB[1 + ib + t] : 0ull;
+                    rc[u] = t < nBt ? tB[1 + ib + t] : (uint8_t)0;
+                }
+#pragma unroll
+                for (int u = 0; u < EPL; ++u) {
+                    const int t = lane + 64 * u;
+                    if (t < nBt) { sB[t] = rk[u]; cB[t] = rc[u]; }
+                }
+            }
             wave_sync_lds();
             // lane l owns merged events [d0, d1); each lane searches the END of its chunk
-            const int epl = (T + 63) >> 6;  // <= EPL (= 8): the 4-bit histogram fields hold up to 15
+            const int epl = (T + 63) >> 6;  // <= EPL (= 6): the 4-bit histogram fields hold up to 15
             const int d0 = min(lane * epl, T), d1 = min(d0 + epl, T);
             const int i1 = merge_path(sA, nAt, sB, nBt, d1);
             int i0 = __shfl_up(i1, 1);
@@ -1039,34 +1072,61 @@ __global__ __launch_bounds__(64 * kSweepWaves, LCHD_SWEEP_MINW) void k_sweep(Swe
             totB = 1 + ib + j0;
             load_state();
 
-            // pass 2: sequential sweep of this lane's events
+            // pass 2: sequential sweep of this lane's events.  Branch-free: both list heads stay in registers and the one
+            // that was consumed is refilled with a single (address-selected) LDS read.  The packed counts exA/exB stay
+            // fixed at their chunk-start values; what the chunk itself adds (<= 6 per category) is kept in 4-bit fields.
             int i = i0, j = j0;
-            uint64_t ka = (i < i1) ? sA[i] : kPadKey, kb = (j < j1) ? sB[j] : kPadKey;  // list heads stay in registers
+            uint64_t ka = (i < i1) ? sA[i] : kPadKey, kb = (j < j1) ? sB[j] : kPadKey;
+#pragma unroll
+            for (int k = 0; k < NH; ++k) dA[k] = dB[k] = 0;
             double Fp = 0.0, Hp = 0.0, firstF = 0.0, local = 0.0;
             for (int e = 0; e < epl; ++e) {
                 if (d0 + e < d1) {
                     const bool takeA = (ka <= kb);  // an exhausted list shows the pad key (> every real key)
                     const uint64_t key = takeA ? ka : kb;
+#if LCHD_BRANCHFREE_HEADS
+                    const int ct = (takeA ? cA : cB)[takeA ? i : j];
+                    i += takeA ? 1 : 0;
+                    j += takeA ? 0 : 1;
+                    {
+                        const int nidx = takeA ? i : j, nend = takeA ? i1 : j1;
+                        const uint64_t nk = (takeA ? sA : sB)[min(nidx, TILE - 1)];
+                        const uint64_t nh = nidx < nend ? nk : kPadKey;
+                        ka = takeA ? nh : ka;
+                        kb = takeA ? kb : nh;
+                    }
+#else
                     const int ct = takeA ? cA[i] : cB[j];
                     if (takeA) { ++i; ka = (i < i1) ? sA[i] : kPadKey; } else { ++j; kb = (j < j1) ? sB[j] : kPadKey; }
+#endif
                     const double F = cdf_of_key(key);
                     if (e == 0) firstF = F; else local += (F - Fp) * Hp;
-                    // pmf.rs:47-63: one more point of category ct on one side
-                    const int sh = (ct & 3) * 16;
-                    const uint64_t inc = 1ull << sh;
-                    uint64_t wA = 0, wB = 0;
-#pragma unroll
-                    for (int k = 0; k < NW; ++k) {
-                        const bool hit = ((ct >> 2) == k);
-                        wA = hit ? exA[k] : wA;
-                        wB = hit ? exB[k] : wB;
-                        exA[k] += (hit && takeA) ? inc : 0ull;
-                        exB[k] += (hit && !takeA) ? inc : 0ull;
-                    }
-                    const int cntA_ = (int)((wA >> sh) & 0xFFFFull), cntB_ = (int)((wB >> sh) & 0xFFFFull);  // before the update
                     totA += takeA ? 1 : 0;
                     totB += takeA ? 0 : 1;
                     if constexpr (H2) {
+                        // pmf.rs:47-63: one more point of category ct on one side
+                        const int sh = (ct & 3) * 16, sh4 = (ct & 15) * 4;
+                        uint64_t wA = 0, wB = 0;
+#pragma unroll
+                        for (int k = 0; k < NW; ++k) {
+                            const bool hit = ((ct >> 2) == k);
+                            wA = hit ? exA[k] : wA;
+                            wB = hit ? exB[k] : wB;
+                        }
+                        uint64_t qA = dA[0], qB = dB[0];
+                        if constexpr (NH == 2) { qA = (ct & 16) ? dA[1] : qA; qB = (ct & 16) ? dB[1] : qB; }
+                        const int cntA_ = (int)((wA >> sh) & 0xFFFFull) + (int)((qA >> sh4) & 15ull);  // before the update
+                        const int cntB_ = (int)((wB >> sh) & 0xFFFFull) + (int)((qB >> sh4) & 15ull);
+                        const uint64_t inc4 = (ct < C) ? (1ull << sh4) : 0ull;
+                        if constexpr (NH == 2) {
+                            dA[0] += (takeA && !(ct & 16)) ? inc4 : 0ull;
+                            dA[1] += (takeA && (ct & 16)) ? inc4 : 0ull;
+                            dB[0] += (!takeA && !(ct & 16)) ? inc4 : 0ull;
+                            dB[1] += (!takeA && (ct & 16)) ? inc4 : 0ull;
+                        } else {
+                            dA[0] += takeA ? inc4 : 0ull;
+                            dB[0] += takeA ? 0ull : inc4;
+                        }
                         const int mine = takeA ? cntA_ : cntB_, other = takeA ? cntB_ : cntA_;
                         double delta = (sqrt_cnt(mine + 1) - sqrt_cnt(mine)) * sqrt_cnt(other);
                         if constexpr (MODE == MODE_H2W) {
