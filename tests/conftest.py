@@ -12,6 +12,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Build the native pieces if this is a fresh checkout (hipcc cross-compiles gfx950 without a GPU; ~40 s)."""
+    import subprocess
+
+    lib = ROOT / "loco_hd_amd" / "libloco_hd_hip.so"
+    srcs = list((ROOT / "loco_hd_amd" / "csrc").glob("*.hip")) + list((ROOT / "loco_hd_amd" / "csrc").glob("*.h")) + [ROOT / "include" / "loco_hd_hip.h"]
+    if not lib.exists() or lib.stat().st_mtime < max(p.stat().st_mtime for p in srcs):
+        subprocess.check_call(["make", "-C", str(ROOT / "loco_hd_amd" / "csrc"), "-j4"], stdout=subprocess.DEVNULL)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU oracle (test infrastructure; never imported by the product package)."""
