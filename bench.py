@@ -258,7 +258,7 @@ def main():
             "kernel_ms": phase_ms,
             "extras": extras,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg (and the parity gate on its sample) runs at N = 1 only
             base, err, m = cpu_baseline(w, scores)
             result["cpu_baseline"] = base
             result["max_abs_err_vs_cpu"] = err
