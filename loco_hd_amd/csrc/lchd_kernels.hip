@@ -454,10 +454,80 @@ __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ 
         if (tid == 0) { atomicOr(&st->flags, ST_EMPTY_ENV); env.len[e] = 0; }
         return;
     }
-    const int n2 = next_pow2(count);
-    for (int i = count + tid; i < n2; i += NT) { key[i] = kPadKey; val[i] = 0; }
-    __syncthreads();
-    bitonic_sort_lds<NT>(key, val, n2, tid);
+    bool sorted = false;
+    if constexpr (NT == 64) {
+        // Typical environments (<= 512 points) are sorted in O(n) by one wavefront: inside a sphere the number of points
+        // grows like d^3, so bucket = floor(256 * (d / thr)^3) spreads them almost evenly over 256 buckets (any
+        // monotone map is correct; it only has to be balanced to be fast).  LDS histogram with returned slots -> wave
+        // scan of the bucket sizes -> in-place scatter from registers -> each lane insertion-sorts the 4 consecutive
+        // buckets it owns on the exact f64 keys.  Clustered inputs (a lane with > 48 points) use the bitonic network.
+        constexpr int B = 256, EPT = 8;
+        if (count <= 64 * EPT) {
+            uint32_t* hist = reinterpret_cast<uint32_t*>(smem + (size_t)cap * 9 + ((16 - (((size_t)cap * 9) & 15)) & 15));  // [B + 1]
+            for (int b = lane; b <= B; b += 64) hist[b] = 0u;
+            __syncthreads();
+            const double qs = (double)B / (thr2 * thr);  // B / thr^3
+            uint64_t rk[EPT];
+            uint8_t rv[EPT];
+            uint16_t rb[EPT], rs[EPT];
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) {
+                const int i = lane + 64 * q;
+                rk[q] = 0; rv[q] = 0; rb[q] = 0; rs[q] = 0;
+                if (i < count) {
+                    rk[q] = key[i];
+                    rv[q] = val[i];
+                    const double d = u2d(rk[q]);
+                    const double t = d * d * d * qs;
+                    const int b = t < (double)B ? (int)t : B - 1;
+                    rb[q] = (uint16_t)b;
+                    rs[q] = (uint16_t)atomicAdd(&hist[b], 1u);
+                }
+            }
+            __syncthreads();
+            // exclusive scan of the 256 bucket sizes: lane l owns buckets 4l .. 4l+3
+            uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+            const uint32_t mine = h0 + h1 + h2 + h3;
+            const uint32_t incl = wave_incl_scan_u32(mine);
+            const uint32_t seg_lo = incl - mine;
+            const unsigned long long too_big = __ballot(mine > 48u);
+            __syncthreads();
+            hist[4 * lane] = seg_lo;
+            hist[4 * lane + 1] = seg_lo + h0;
+            hist[4 * lane + 2] = seg_lo + h0 + h1;
+            hist[4 * lane + 3] = seg_lo + h0 + h1 + h2;
+            __syncthreads();
+            if (!too_big) {
+#pragma unroll
+                for (int q = 0; q < EPT; ++q) {
+                    const int i = lane + 64 * q;
+                    if (i < count) {
+                        const uint32_t pos = hist[rb[q]] + rs[q];
+                        key[pos] = rk[q];
+                        val[pos] = rv[q];
+                    }
+                }
+                __syncthreads();
+                const int lo = (int)seg_lo, hi = (int)incl;
+                for (int i = lo + 1; i < hi; ++i) {
+                    const uint64_t k = key[i];
+                    const uint8_t v = val[i];
+                    int j = i - 1;
+                    while (j >= lo && key[j] > k) { key[j + 1] = key[j]; val[j + 1] = val[j]; --j; }
+                    key[j + 1] = k;
+                    val[j + 1] = v;
+                }
+                __syncthreads();
+                sorted = true;
+            }
+        }
+    }
+    if (!sorted) {
+        const int n2 = next_pow2(count);
+        for (int i = count + tid; i < n2; i += NT) { key[i] = kPadKey; val[i] = 0; }
+        __syncthreads();
+        bitonic_sort_lds<NT>(key, val, n2, tid);
+    }
     if (env.cdf_keys) keys_to_cdf_lds<NT>(key, count, tid, cfgp);
     uint64_t* ok_ = env.key + e * env.stride;
     uint8_t* oc_ = env.cat + e * env.stride;
@@ -472,7 +542,7 @@ bool launch_env_cells(hipStream_t s, int cap, const DevConfig* cfg, const CloudV
     const dim3 grid((unsigned)max_envs);
     const size_t lds = (size_t)cap * 9;
     if (cap <= 2048) {
-        k_env_cells<64><<<grid, 64, lds, s>>>(cfg, c, g, uniq, side, thr, cap, env, st);
+        k_env_cells<64><<<grid, 64, lds + 16 + 257 * sizeof(uint32_t), s>>>(cfg, c, g, uniq, side, thr, cap, env, st);
     } else if (cap <= 4096) {
         k_env_cells<256><<<grid, 256, lds, s>>>(cfg, c, g, uniq, side, thr, cap, env, st);
     } else {
