@@ -397,7 +397,7 @@ __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ 
                     if (ok) {
                         const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
                         if (pos < cap) {
-                            key[pos] = d2u(sqrt(d2));
+                            key[pos] = d2u(d2);  // the square root is taken after compaction (a sixth of the candidates survive)
                             val[pos] = g.pcat[idx];
                         }
                     }
@@ -475,10 +475,11 @@ __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ 
                 const int i = lane + 64 * q;
                 rk[q] = 0; rv[q] = 0; rb[q] = 0; rs[q] = 0;
                 if (i < count) {
-                    rk[q] = key[i];
+                    const double d2 = u2d(key[i]);
+                    const double d = sqrt(d2);  // utils.rs:1-8
+                    rk[q] = d2u(d);
                     rv[q] = val[i];
-                    const double d = u2d(rk[q]);
-                    const double t = d * d * d * qs;
+                    const double t = d2 * d * qs;
                     const int b = t < (double)B ? (int)t : B - 1;
                     rb[q] = (uint16_t)b;
                     rs[q] = (uint16_t)atomicAdd(&hist[b], 1u);
@@ -523,6 +524,10 @@ __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ 
         }
     }
     if (!sorted) {
+        if constexpr (NT == 64) {  // the keys still hold d^2
+            for (int i = tid; i < count; i += NT) key[i] = d2u(sqrt(u2d(key[i])));
+            __syncthreads();
+        }
         const int n2 = next_pow2(count);
         for (int i = count + tid; i < n2; i += NT) { key[i] = kPadKey; val[i] = 0; }
         __syncthreads();
