@@ -2,22 +2,28 @@
 //
 // Pipeline for one from_primitives call (reference: /root/reference/src/locohd.rs:479-567):
 //
-//   K0  cell list           k_cell_count / k_exclusive_scan / k_cell_scatter
-//                           (replaces KdTree::build_by_ordered_float, :504-510)
+//   K0  cell list           k_cell_count / k_exclusive_scan (or the 3-phase multi-block scan) / k_cell_scatter
+//                           (replaces KdTree::build_by_ordered_float, :504-510); batches of structures carry the
+//                           structure id as the slowest grid dimension
 //   K0' anchor de-dup       k_mark_anchors / scan / k_compact_anchors
 //                           (an anchor that occurs in many pairs gets its environment built once)
-//   K1  environment build   k_env_cells<CAP>: radius search + tag filter + distances + LDS bitonic sort
+//   K1  environment build   k_env_cells<NT>: radius search + tag filter + distances, then an O(n) bucket sort
+//                           (d^3 buckets, LDS histogram + scan + scatter + per-lane insertion sort) for environments
+//                           of <= 512 points, LDS bitonic network otherwise; optional CDF keying
 //                           (replaces env_from_idx :514-542, utils::sort_together utils.rs:25-39)
-//       dense variant       k_env_rows<NT>: whole cloud / given distance-matrix row (from_coords, from_dmxs)
-//   K2  sweep               k_sweep<CMAX>: merge-path partition of the two sorted environments, per-lane
-//                           sequential sweep with a wavefront prefix scan of packed category counts,
+//       dense variant       k_env_rows<NT,GLOBALKV>: whole cloud / given distance-matrix row (from_coords, from_dmxs),
+//                           bucket sort on the row's empirical distance CDF
+//   K2  sweep               k_sweep<CMAX,MODE,FMODE,LDSTAB>: merge-path partition of the two sorted environments,
+//                           per-lane sequential sweep with a wavefront DPP prefix scan of packed category counts,
 //                           statistical distance per breakpoint, CDF differences, wave64 shuffle reduce
-//                           (replaces stat_dist_integral :61-226, pmf.rs, statistical_distances.rs, cdfs.rs)
+//                           (replaces stat_dist_integral :61-226, pmf.rs, statistical_distances.rs, cdfs.rs);
+//                           k_sweep_wide for 33..255 categories
+//       trajectory frames   k_frames_labels / k_frames_unpack: SoA unpack + bounding box of a block of frames
 //
-// One wavefront (64 lanes, one 64-thread workgroup) owns one environment (K1) or one anchor pair (K2);
-// the launch has thousands of independent workgroups, so all 256 CUs / 8 XCDs are filled without any
-// inter-workgroup communication.  All arithmetic is f64 like the reference; no MFMA (there is no
-// contraction in this path).
+// One wavefront owns one environment (K1: a 64-thread workgroup) or one anchor pair (K2: four pairs per
+// 256-thread workgroup); a launch has thousands of independent wavefronts, so all 256 CUs / 8 XCDs are
+// filled without any inter-workgroup communication.  All arithmetic is f64 like the reference; no MFMA
+// (there is no contraction in this path).
 #include <cstdlib>
 
 #include "lchd_device.h"
