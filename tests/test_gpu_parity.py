@@ -354,3 +354,54 @@ def test_near_identical_environments(lh, oracle):
 
         got, want = both(lh, oracle, run)
         assert np.max(np.abs(got - want)) < TIGHT
+
+
+def test_degenerate_geometries(lh, oracle):
+    """Inputs that defeat the balanced-bucket assumptions of the sorting kernels (they must only get slower)."""
+    rng = np.random.default_rng(41)
+    cases = {
+        "all_identical": (np.zeros((300, 3)), np.zeros((280, 3)) + 0.5),
+        "two_clusters": (np.concatenate([rng.normal(0, 0.01, (200, 3)), rng.normal(8, 0.01, (200, 3))]),
+                         np.concatenate([rng.normal(0, 0.01, (150, 3)), rng.normal(8, 0.01, (250, 3))])),
+        "collinear": (np.stack([np.linspace(0, 30, 350), np.zeros(350), np.zeros(350)], 1),
+                      np.stack([np.linspace(0, 30, 350) ** 1.1, np.zeros(350), np.zeros(350)], 1)),
+        "far_from_origin": (rng.uniform(0, 20, (300, 3)) + 1.0e6, rng.uniform(0, 20, (300, 3)) - 1.0e6),
+        "single_atoms": (np.array([[1.0, 2.0, 3.0]]), np.array([[0.0, 0.0, 0.0]])),
+    }
+    for name, (xa, xb) in cases.items():
+        sa, sb = rng.choice(CATS, len(xa)).tolist(), rng.choice(CATS, len(xb)).tolist()
+        anchors = [(int(i), int(j)) for i, j in zip(rng.integers(0, len(xa), 120), rng.integers(0, len(xb), 120))]
+        for thr in (9.0, float("inf")):
+
+            def run(mod):
+                lchd = mod.LoCoHD(CATS, mod.WeightFunction("hyper_exp", [1.0, 0.2]))
+                return np.asarray(lchd.from_primitives(prims(mod, sa, xa), prims(mod, sb, xb), anchors, thr))
+
+            got, want = both(lh, oracle, run)
+            assert np.max(np.abs(got - want)) < TIGHT, (name, thr)
+        if len(xa) == len(xb):
+
+            def run_c(mod):
+                lchd = mod.LoCoHD(CATS, mod.WeightFunction("uniform", [0.5, 12.0]))
+                return np.asarray(lchd.from_coords(sa, sb, xa, xb))
+
+            got, want = both(lh, oracle, run_c)
+            assert np.max(np.abs(got - want)) < TIGHT, name
+
+
+def test_points_exactly_on_the_threshold(lh, oracle):
+    """Lattice points at distance exactly == threshold are outside (strict d^2 < thr^2, kd-tree 0.6 within_radius);
+    both paths must agree on every such boundary case."""
+    grid = np.array(list(itertools.product(range(-4, 5), repeat=3)), dtype=float)
+    rng = np.random.default_rng(43)
+    s = rng.choice(CATS, len(grid)).tolist()
+    s2 = rng.choice(CATS, len(grid)).tolist()
+    anchors = [(int(i), int(j)) for i, j in zip(rng.integers(0, len(grid), 150), rng.integers(0, len(grid), 150))]
+    for thr in (1.0, 2.0, 3.0, 5.0 ** 0.5, 3.0000000000000004):
+
+        def run(mod):
+            lchd = mod.LoCoHD(CATS, mod.WeightFunction("uniform", [0.0, 4.0]))
+            return np.asarray(lchd.from_primitives(prims(mod, s, grid), prims(mod, s2, grid), anchors, thr))
+
+        got, want = both(lh, oracle, run)
+        assert np.max(np.abs(got - want)) < TIGHT, thr
