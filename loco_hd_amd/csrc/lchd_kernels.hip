@@ -889,7 +889,7 @@ __device__ __noinline__ double sd_generic(int kind, double p0, double p1, const 
 
 // register budget: 4 waves/SIMD (<= 128 VGPRs) up to 12 category slots, 3 (<= 168) up to 16, 2 beyond
 template <int CMAX, int MODE, int FMODE, bool LDSTAB>
-__global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 12 ? 4 : (CMAX <= 16 ? 3 : 2))) void k_sweep(SweepArgs args) {
+__global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 12 ? 4 : (CMAX <= 16 ? 3 : 2)))) void k_sweep(SweepArgs args) {
     constexpr int EPL = kSweepEPL, TILE = kSweepTile, WPB = kSweepWaves;
     constexpr int NW = CMAX / 4;          // u64 words of 16-bit count fields per side
     constexpr int NH = (CMAX + 15) / 16;  // u64 words of 4-bit histogram fields per side
@@ -1061,9 +1061,30 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 12 ? 4 : (CMAX <= 16 ? 3
 #pragma unroll
                 for (int c = 0; c < CMAX; ++c) sb_ += vb[c];
                 if (sa_ == 0.0 || sb_ == 0.0) zero_norm = true;
+                const double ia_ = 1.0 / sa_, ib_ = 1.0 / sb_;  // one reciprocal per side (<= 1 ulp from pmf.rs:78-81's per-category divisions)
+                const int kind = cfgp->sd_kind;
+                if (kind == SD_KS) {  // statistical_distances.rs:12-21, straight from the registers
+                    double best = 0.0;
 #pragma unroll
-                for (int c = 0; c < CMAX; ++c) { pn[c] = va[c] / sa_; qn[c] = vb[c] / sb_; }
-                return sd_generic(cfgp->sd_kind, cfgp->sd_p0, cfgp->sd_p1, pn, qn, C);
+                    for (int c = 0; c < CMAX; ++c) best = fmax(best, fabs(va[c] * ia_ - vb[c] * ib_));  // padded slots give |0 - 0|
+                    return best;
+                }
+                if (kind == SD_KL) {  // :23-29
+                    const double eps = cfgp->sd_p0;
+                    double dist = 0.0;
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c) {
+                        if (c < C) {
+                            const double x = va[c] * ia_;
+                            dist += x * log((x + eps) / (vb[c] * ib_ + eps));
+                        }
+                    }
+                    return dist;
+                }
+                // general Hellinger exponent, Renyi: pow-heavy, evaluated out of line from a scratch copy
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) { pn[c] = va[c] * ia_; qn[c] = vb[c] * ib_; }
+                return sd_generic(kind, cfgp->sd_p0, cfgp->sd_p1, pn, qn, C);
             }
         };
 
@@ -1387,7 +1408,8 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
                     sb_ += qn[c];
                 }
                 if (sa_ == 0.0 || sb_ == 0.0) zero_norm = true;
-                for (int c = 0; c < C; ++c) { pn[c] /= sa_; qn[c] /= sb_; }
+                const double ia_ = 1.0 / sa_, ib_ = 1.0 / sb_;
+                for (int c = 0; c < C; ++c) { pn[c] *= ia_; qn[c] *= ib_; }
                 return sd_generic(cfgp->sd_kind, cfgp->sd_p0, cfgp->sd_p1, pn, qn, C);
             }
         };
