@@ -155,6 +155,21 @@ int lchd_ctx_finish(lchd_ctx *ctx);
 int lchd_frames_create(lchd_ctx *ctx, const lchd_cloud *tmpl, int32_t capacity_frames, lchd_cloud **out);
 int lchd_frames_load(lchd_ctx *ctx, lchd_cloud *frames, const double *xyz, int32_t n_frames, void *hip_stream);
 
+/* Frames given as SOURCE atoms (the step in front of the scoring path): the reference converts every
+ * frame on the host -- PrimitiveAssigner.assign_primitive_structure, loco_hd/atom_converter_utils.py:95-129, and its
+ * MD variant python_codes/trajectory_analyzer.py:37-74 -- where each primitive atom is np.mean(atom_coords, axis=0) over
+ * the float32 coordinates of the atoms its typing-scheme element matched.  The match (regexes on residue / atom names)
+ * depends on the topology only, so the host resolves it once into a CSR map and the device evaluates the centroids
+ * for every frame with np.mean's float32 arithmetic (sequential adds in member order, one division), bit for bit.
+ *   src_start [n_primitive_atoms + 1], src_idx [src_start[n]] : primitive atom p <- source atoms src_idx[src_start[p]..src_start[p+1])
+ *   atom_xyz  HOST float32 [n_frames][n_src_atoms][3]
+ * lchd_frames_load_atoms has the stream / overlap semantics of lchd_frames_load. */
+int lchd_frames_set_sources(lchd_ctx *ctx, lchd_cloud *frames, const int32_t *src_start, const int32_t *src_idx,
+                            int64_t n_src_atoms);
+int lchd_frames_load_atoms(lchd_ctx *ctx, lchd_cloud *frames, const float *atom_xyz, int32_t n_frames, void *hip_stream);
+/* Coordinates of a cloud / frames buffer back on the host as [n][3] f64 (n must equal the atoms it holds). */
+int lchd_cloud_get_coords(lchd_ctx *ctx, lchd_cloud *cloud, double *xyz_out, int64_t n);
+
 /* Per-kernel timing of the most recent *_dev / driver call, measured with hipEvents on the context's stream.
  * names: "cells", "anchors", "env", "sweep"; returns milliseconds, <0 if unknown name / timing disabled. */
 int lchd_ctx_enable_timing(lchd_ctx *ctx, int32_t on);

@@ -1,0 +1,96 @@
+"""`python -m loco_hd_amd` -- the reference's command line over the MI355X scoring path.
+
+Mirrors /root/reference/loco_hd/__main__.py: same flags (:49-134), same anchor-pairing file format
+`chain/resnum-RESNAME/atom,atom:chain/resnum-RESNAME/atom;...` (:12-30, README.md:213-235), same output lines
+`LoCoHD(<pair>) = <score>` (:203-204).  Structures are read with `loco_hd_amd.pdb_reader` (the reference uses
+BioPython's PDBParser, which this image does not have); scoring runs on the GPU through LoCoHD.from_primitives.
+"""
+from __future__ import annotations
+
+import json
+import sys
+from argparse import ArgumentParser, Namespace
+from pathlib import Path
+from typing import Dict, FrozenSet, List, Optional, Sequence, Tuple
+
+from .api import LoCoHD, TagPairingRule, WeightFunction
+from .atom_converter_utils import PrimitiveAssigner, PrimitiveAtomTemplate, prat_to_pra
+from .pdb_reader import PDBParser
+
+# chain ID (eg.: A), resi ID (eg.: 123-GLY), atom set (eg.: {CG, CZ})
+TagIDType = Tuple[str, str, FrozenSet[str]]
+
+
+def parse_anchor_pairing(anchor_pairing_str_list: Sequence[str]) -> List[Tuple[TagIDType, TagIDType]]:
+    """__main__.py:12-30.  A malformed entry raises ValueError from the tuple unpacking, like the reference."""
+    pairings = []
+    for entry in anchor_pairing_str_list:
+        tag1, tag2 = entry.split(":")
+        chain1, resi1, atoms1 = tag1.split("/")
+        chain2, resi2, atoms2 = tag2.split("/")
+        pairings.append(((chain1, resi1, frozenset(atoms1.split(","))), (chain2, resi2, frozenset(atoms2.split(",")))))
+    return pairings
+
+
+def pra_template_list_to_idx_dict(pra_templates: Sequence[PrimitiveAtomTemplate]) -> Dict[TagIDType, int]:
+    """__main__.py:33-47: (chain, "<resnum>-<resname>", atom set) -> index; a repeated id keeps its LAST index."""
+    out: Dict[TagIDType, int] = {}
+    for idx, prat in enumerate(pra_templates):
+        src = prat.atom_source
+        out[(src.source_residue[2], f"{src.source_residue[3][1]}-{src.source_residue_name}", frozenset(src.source_atom))] = idx
+    return out
+
+
+def parse_cli_args(argv: Optional[Sequence[str]] = None) -> Namespace:
+    p = ArgumentParser(prog="python -m loco_hd_amd")
+    p.add_argument("-s1", "--structure1", type=str, required=True, help="Path to the first pdb file to be compared.")
+    p.add_argument("-s2", "--structure2", type=str, required=True, help="Path to the second pdb file to be compared.")
+    p.add_argument("-pts", "--primitive_typing_scheme", type=str, required=True, help="Path to the primitive typing scheme json file.")
+    p.add_argument("-apf", "--anchor_pairing_file", type=Path, required=True,
+                   help="Text file of anchor pairs such as A/123-TYR/CG,CZ:B/45-ALA/CB (chain / residue / atom set of the "
+                        "primitive atom in structure 1 : the same for structure 2), separated by semicolons; newlines are ignored.")
+    p.add_argument("-mn", "--model_number", type=int, default=0, help="The model number in the pdb files to be compared (0 by default).")
+    p.add_argument("-nt", "--number_of_threads", type=int, default=None,
+                   help="Accepted for compatibility; the scoring runs on the GPU, not on a CPU thread pool.")
+    p.add_argument("-udc", "--upper_distance_cutoff", type=float, default=10.0, help="Upper distance cutoff of the environments.")
+    tpra_default = '{"accept_same": false}'
+    p.add_argument("-tpra", "--tag_pairing_rule_args", type=str, default=tpra_default,
+                   help=f"JSON dictionary that initializes the TagPairingRule ('{tpra_default}' by default).")
+    wfa_default = '{"function_name": "uniform", "parameters": [3.0, 10.0]}'
+    p.add_argument("-wfa", "--weight_function_args", type=str, default=wfa_default,
+                   help=f"JSON dictionary that initializes the WeightFunction ('{wfa_default}' by default).")
+    args = p.parse_args(argv)
+    args.tag_pairing_rule_args = json.loads(args.tag_pairing_rule_args)
+    args.weight_function_args = json.loads(args.weight_function_args)
+    return args
+
+
+def run(args: Namespace) -> List[str]:
+    """__main__.py:149-204; returns the output lines."""
+    with open(args.anchor_pairing_file, "r") as f:
+        pair_strs = f.read().replace("\n", "").split(";")
+    anchor_pairing = parse_anchor_pairing(pair_strs)
+
+    structure1 = PDBParser(QUIET=True).get_structure("s1", args.structure1)[args.model_number]
+    structure2 = PDBParser(QUIET=True).get_structure("s2", args.structure2)[args.model_number]
+    assigner = PrimitiveAssigner(Path(args.primitive_typing_scheme))
+    templates1 = assigner.assign_primitive_structure(structure1)
+    templates2 = assigner.assign_primitive_structure(structure2)
+    idx1, idx2 = pra_template_list_to_idx_dict(templates1), pra_template_list_to_idx_dict(templates2)
+    anchor_pairs = [(idx1[a], idx2[b]) for a, b in anchor_pairing]  # unknown id -> KeyError, like the reference
+
+    lchd = LoCoHD(assigner.all_primitive_types, WeightFunction(**args.weight_function_args),
+                  TagPairingRule(args.tag_pairing_rule_args), args.number_of_threads)
+    scores = lchd.from_primitives(list(map(prat_to_pra, templates1)), list(map(prat_to_pra, templates2)), anchor_pairs,
+                                  args.upper_distance_cutoff)
+    return [f"LoCoHD({s}) = {score}" for s, score in zip(pair_strs, scores)]
+
+
+def main(argv: Optional[Sequence[str]] = None) -> int:
+    for line in run(parse_cli_args(argv)):
+        print(line)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

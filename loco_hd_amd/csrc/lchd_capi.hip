@@ -135,6 +135,10 @@ struct lchd_cloud {
     int32_t cap_frames = 0;    // frames the arrays can hold
     double* d_raw = nullptr;   // device staging of the caller's [frames][atoms][3] block
     double* h_pinned = nullptr;
+    // frames given as float32 SOURCE atoms (lchd_frames_set_sources): CSR map primitive atom -> source atoms
+    int32_t *d_src_start = nullptr, *d_src_idx = nullptr;
+    int64_t n_src = 0;
+    float *d_raw32 = nullptr, *h_pinned32 = nullptr;
     unsigned long long* d_bbox = nullptr;  // [7]: order-preserving keys of min xyz, max xyz, non-finite flag
     hipEvent_t ev_ready = nullptr, ev_used = nullptr;
     bool bbox_pending = false, used_valid = false;
@@ -434,6 +438,10 @@ extern "C" void lchd_cloud_destroy(lchd_ctx* c, lchd_cloud* cl) {
     (void)hipFree(cl->sid);
     (void)hipFree(cl->d_raw);
     (void)hipFree(cl->d_bbox);
+    (void)hipFree(cl->d_src_start);
+    (void)hipFree(cl->d_src_idx);
+    (void)hipFree(cl->d_raw32);
+    if (cl->h_pinned32) (void)hipHostFree(cl->h_pinned32);
     if (cl->h_pinned) (void)hipHostFree(cl->h_pinned);
     if (cl->ev_ready) (void)hipEventDestroy(cl->ev_ready);
     if (cl->ev_used) (void)hipEventDestroy(cl->ev_used);
@@ -749,6 +757,78 @@ extern "C" int lchd_frames_load(lchd_ctx* c, lchd_cloud* fr, const double* xyz, 
     fr->n = total;
     fr->n_struct = n_frames;
     fr->bbox_pending = true;
+    return LCHD_OK;
+}
+
+extern "C" int lchd_frames_set_sources(lchd_ctx* c, lchd_cloud* fr, const int32_t* src_start, const int32_t* src_idx,
+                                       int64_t n_src_atoms) {
+    if (!c || !fr || !fr->cap_frames || !src_start || !src_idx) return fail(LCHD_EVALUE, "not a frames buffer / null map");
+    if (c->pend.active && (c->pend.a == fr || c->pend.b == fr))
+        return fail(LCHD_EVALUE, "this frames buffer is in use by an unfinished asynchronous call");
+    const int64_t np = fr->n_tmpl;
+    if (n_src_atoms < 1 || n_src_atoms * (int64_t)fr->cap_frames > ((int64_t)1 << 31))
+        return fail(LCHD_EUNSUPPORTED, "%lld source atoms x %d frames is out of range", (long long)n_src_atoms, fr->cap_frames);
+    if (src_start[0] != 0) return fail(LCHD_EVALUE, "src_start[0] must be 0");
+    for (int64_t p = 0; p < np; ++p)  // np.mean of an empty list is NaN in the reference (atom_converter_utils.py:126): refuse it here
+        if (src_start[p + 1] <= src_start[p]) return fail(LCHD_EVALUE, "primitive atom %lld has no source atoms", (long long)p);
+    const int64_t nnz = src_start[np];
+    for (int64_t k = 0; k < nnz; ++k)
+        if (src_idx[k] < 0 || src_idx[k] >= n_src_atoms)
+            return fail(LCHD_EVALUE, "source atom index %d at position %lld is outside [0, %lld)", src_idx[k], (long long)k, (long long)n_src_atoms);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (fr->ev_ready && fr->bbox_pending) HIP_TRY(hipEventSynchronize(fr->ev_ready));
+    (void)hipFree(fr->d_src_start); fr->d_src_start = nullptr;
+    (void)hipFree(fr->d_src_idx); fr->d_src_idx = nullptr;
+    (void)hipFree(fr->d_raw32); fr->d_raw32 = nullptr;
+    if (fr->h_pinned32) { (void)hipHostFree(fr->h_pinned32); fr->h_pinned32 = nullptr; }
+    fr->n_src = 0;
+    const size_t raw_elems = (size_t)3 * (size_t)n_src_atoms * (size_t)fr->cap_frames;
+    HIP_TRY(hipMalloc(&fr->d_src_start, sizeof(int32_t) * (size_t)(np + 1)));
+    HIP_TRY(hipMalloc(&fr->d_src_idx, sizeof(int32_t) * (size_t)nnz));
+    HIP_TRY(hipMalloc(&fr->d_raw32, sizeof(float) * raw_elems));
+    HIP_TRY(hipHostMalloc(&fr->h_pinned32, sizeof(float) * raw_elems));
+    HIP_TRY(hipMemcpy(fr->d_src_start, src_start, sizeof(int32_t) * (size_t)(np + 1), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(fr->d_src_idx, src_idx, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
+    fr->n_src = n_src_atoms;
+    return LCHD_OK;
+}
+
+extern "C" int lchd_frames_load_atoms(lchd_ctx* c, lchd_cloud* fr, const float* atom_xyz, int32_t n_frames, void* hip_stream) {
+    if (!c || !fr || !atom_xyz || !fr->cap_frames) return fail(LCHD_EVALUE, "not a frames buffer");
+    if (!fr->n_src) return fail(LCHD_EVALUE, "lchd_frames_set_sources has not been called on this frames buffer");
+    if (n_frames < 1 || n_frames > fr->cap_frames) return fail(LCHD_EVALUE, "%d frames do not fit a buffer of %d", n_frames, fr->cap_frames);
+    if (c->pend.active && (c->pend.a == fr || c->pend.b == fr))
+        return fail(LCHD_EVALUE, "this frames buffer is in use by an unfinished asynchronous call");
+    hipStream_t s = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->stream;
+    const size_t elems = (size_t)3 * (size_t)fr->n_src * (size_t)n_frames;
+    if (fr->ev_ready && fr->bbox_pending) HIP_TRY(hipEventSynchronize(fr->ev_ready));  // pinned block free again
+    memcpy(fr->h_pinned32, atom_xyz, sizeof(float) * elems);
+    if (fr->used_valid) HIP_TRY(hipStreamWaitEvent(s, fr->ev_used, 0));
+    HIP_TRY(hipMemcpyAsync(fr->d_raw32, fr->h_pinned32, sizeof(float) * elems, hipMemcpyHostToDevice, s));
+    launch_frames_centroids(s, fr->d_raw32, fr->n_src, fr->d_src_start, fr->d_src_idx, fr->n_tmpl, n_frames, fr->x, fr->y, fr->z, fr->d_bbox);
+    HIP_TRY(hipEventRecord(fr->ev_ready, s));
+    HIP_TRY(hipGetLastError());
+    fr->n = fr->n_tmpl * n_frames;
+    fr->n_struct = n_frames;
+    fr->bbox_pending = true;
+    return LCHD_OK;
+}
+
+/* Read back the primitive-atom coordinates of a frames buffer (or any cloud) as [n][3] f64: lets a caller check the device
+ * centroids against its own np.mean, and feeds generate_primitive_pdb for a frame. */
+extern "C" int lchd_cloud_get_coords(lchd_ctx* c, lchd_cloud* cl, double* xyz_out, int64_t n) {
+    if (!c || !cl || !xyz_out) return fail(LCHD_EVALUE, "null argument");
+    if (n != cl->n) return fail(LCHD_EVALUE, "the cloud holds %lld atoms, not %lld", (long long)cl->n, (long long)n);
+    if (cl->ev_ready && cl->bbox_pending) HIP_TRY(hipEventSynchronize(cl->ev_ready));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<double> soa((size_t)3 * (size_t)n);
+    if (n) {
+        HIP_TRY(hipMemcpy(soa.data(), cl->x, sizeof(double) * n, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(soa.data() + n, cl->y, sizeof(double) * n, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(soa.data() + 2 * n, cl->z, sizeof(double) * n, hipMemcpyDeviceToHost));
+    }
+    for (int64_t i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) xyz_out[3 * i + k] = soa[(size_t)k * n + i];
     return LCHD_OK;
 }
 

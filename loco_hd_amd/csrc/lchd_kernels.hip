@@ -18,7 +18,8 @@
 //                           statistical distance per breakpoint, CDF differences, wave64 shuffle reduce
 //                           (replaces stat_dist_integral :61-226, pmf.rs, statistical_distances.rs, cdfs.rs);
 //                           k_sweep_wide for 33..255 categories
-//       trajectory frames   k_frames_labels / k_frames_unpack: SoA unpack + bounding box of a block of frames
+//       trajectory frames   k_frames_labels / k_frames_unpack: SoA unpack + bounding box of a block of frames;
+//                           k_frames_centroids: primitive atoms of every frame from its float32 source atoms
 //
 // One wavefront owns one environment (K1: a 64-thread workgroup) or one anchor pair (K2: four pairs per
 // 256-thread workgroup); a launch has thousands of independent wavefronts, so all 256 CUs / 8 XCDs are
@@ -1712,5 +1713,50 @@ void launch_frames_unpack(hipStream_t s, const double* raw, int64_t n_atoms, dou
     (void)hipMemcpyAsync(bbox7, init, sizeof init, hipMemcpyHostToDevice, s);
     const int64_t nb = (n_atoms + 255) / 256;
     k_frames_unpack<<<(unsigned)(nb < 1024 ? nb : 1024), 256, 0, s>>>(raw, n_atoms, x, y, z, bbox7);
+}
+
+// Frames given as SOURCE atoms (float32, the precision of Bio.PDB Atom.coord / MDAnalysis Timestep.positions): primitive
+// atom p of every frame is the centroid of source atoms src_idx[src_start[p] .. src_start[p+1]) -- what
+// PrimitiveAssigner.assign_primitive_structure computes per frame on the host with np.mean(atom_coords, axis=0)
+// (/root/reference/loco_hd/atom_converter_utils.py:106-126, python_codes/trajectory_analyzer.py:55-72).  Same arithmetic
+// as that call: float32 accumulator seeded with the first member, members added in list order, one IEEE float32 division
+// by the member count; the result is widened to f64 exactly like PrimitiveAtom.coordinates.  One thread per
+// (frame, primitive atom); the member gathers hit L2 (a frame's source atoms are a few 100 KB).
+__global__ void k_frames_centroids(const float* __restrict__ raw, int64_t n_src, const int32_t* __restrict__ src_start,
+                                   const int32_t* __restrict__ src_idx, int64_t n_prim, int64_t total, double* __restrict__ x,
+                                   double* __restrict__ y, double* __restrict__ z, unsigned long long* bbox7) {
+    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    bool bad = false;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t f = i / n_prim, p = i - f * n_prim;
+        const float* fr = raw + 3 * f * n_src;
+        const int b = src_start[p], e = src_start[p + 1];
+        const float* a0 = fr + 3 * (int64_t)src_idx[b];
+        float sx = a0[0], sy = a0[1], sz = a0[2];
+        for (int k = b + 1; k < e; ++k) {
+            const float* a = fr + 3 * (int64_t)src_idx[k];
+            sx += a[0]; sy += a[1]; sz += a[2];
+        }
+        const float cnt = (float)(e - b);
+        const double vx = (double)__fdiv_rn(sx, cnt), vy = (double)__fdiv_rn(sy, cnt), vz = (double)__fdiv_rn(sz, cnt);
+        x[i] = vx; y[i] = vy; z[i] = vz;
+        bad = bad || !(fabs(vx) < INFINITY) || !(fabs(vy) < INFINITY) || !(fabs(vz) < INFINITY);
+        mn[0] = fmin(mn[0], vx); mn[1] = fmin(mn[1], vy); mn[2] = fmin(mn[2], vz);
+        mx[0] = fmax(mx[0], vx); mx[1] = fmax(mx[1], vy); mx[2] = fmax(mx[2], vz);
+    }
+    for (int m = 32; m > 0; m >>= 1)
+        for (int k = 0; k < 3; ++k) { mn[k] = fmin(mn[k], shfl_xor_f64(mn[k], m)); mx[k] = fmax(mx[k], shfl_xor_f64(mx[k], m)); }
+    const unsigned long long anybad = __ballot(bad);
+    if ((threadIdx.x & 63) == 0) {
+        for (int k = 0; k < 3; ++k) { atomicMin(&bbox7[k], ordered_key(mn[k])); atomicMax(&bbox7[3 + k], ordered_key(mx[k])); }
+        if (anybad) atomicOr(&bbox7[6], 1ull);
+    }
+}
+void launch_frames_centroids(hipStream_t s, const float* raw, int64_t n_src, const int32_t* src_start, const int32_t* src_idx,
+                             int64_t n_prim, int32_t n_frames, double* x, double* y, double* z, unsigned long long* bbox7) {
+    static const unsigned long long init[7] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull, 0ull};
+    (void)hipMemcpyAsync(bbox7, init, sizeof init, hipMemcpyHostToDevice, s);
+    const int64_t total = n_prim * n_frames, nb = (total + 255) / 256;
+    k_frames_centroids<<<(unsigned)(nb < 2048 ? nb : 2048), 256, 0, s>>>(raw, n_src, src_start, src_idx, n_prim, total, x, y, z, bbox7);
 }
 }  // namespace lchd

@@ -122,14 +122,49 @@ class DeviceSession:
         sp = None if stream is None else C.c_void_p(stream.cuda_stream)
         N.check(N.lib().lchd_frames_load(self._ctx, buf, N.dp(xyz), xyz.shape[0], sp))
 
-    def score_trajectory(self, ref_cloud, frames_xyz: np.ndarray, local_pairs, threshold_distance: float, chunk: int = 1024):
+    def set_frame_sources(self, buf, topology):
+        """Tell a frames buffer how its primitive atoms are made from SOURCE atoms (a `PrimitiveTopology` from
+        PrimitiveAssigner.compile_topology): afterwards `load_atom_frames` takes raw float32 atom coordinates and the
+        centroids are evaluated on the device."""
+        ss = np.ascontiguousarray(topology.src_start, dtype=np.int32)
+        si = np.ascontiguousarray(topology.src_idx, dtype=np.int32)
+        N.check(N.lib().lchd_frames_set_sources(self._ctx, buf, N.ip(ss), N.ip(si), int(topology.n_atoms)))
+
+    def load_atom_frames(self, buf, atom_xyz: np.ndarray, stream=None):
+        """Stage float32 SOURCE-atom coordinates [n_frames][n_src_atoms][3] (host); H2D copy and the centroid kernel run on
+        `stream` without waiting (same overlap rules as load_frames)."""
+        atom_xyz = np.ascontiguousarray(atom_xyz, dtype=np.float32)
+        assert atom_xyz.ndim == 3 and atom_xyz.shape[2] == 3
+        sp = None if stream is None else C.c_void_p(stream.cuda_stream)
+        N.check(N.lib().lchd_frames_load_atoms(self._ctx, buf, atom_xyz.ctypes.data_as(C.POINTER(C.c_float)), atom_xyz.shape[0], sp))
+
+    def coords_of(self, cloud, n: int) -> np.ndarray:
+        """Primitive-atom coordinates currently held by a cloud / frames buffer, as float64 [n][3] on the host."""
+        out = np.empty((int(n), 3), dtype=np.float64)
+        N.check(N.lib().lchd_cloud_get_coords(self._ctx, cloud, N.dp(out), int(n)))
+        return out
+
+    def score_trajectory(self, ref_cloud, frames_xyz: np.ndarray, local_pairs, threshold_distance: float, chunk: int = 1024,
+                         topology=None):
         """MD-trajectory mode (python_codes/trajectory_analyzer.py:97-119): score every frame of `frames_xyz`
         [n_frames][n_atoms][3] against the reference structure for the anchor pairs `local_pairs` [(atom in reference,
         atom in frame)].  Frames are streamed in chunks: while chunk k is scored, chunk k+1 is copied on a second
-        stream into the other of two buffers.  Returns a float64 array [n_frames][len(local_pairs)]."""
+        stream into the other of two buffers.  Returns a float64 array [n_frames][len(local_pairs)].
+
+        With `topology` (PrimitiveAssigner.compile_topology of the trajectory's structure) `frames_xyz` holds the float32
+        coordinates of the SOURCE atoms, [n_frames][topology.n_atoms][3], and the per-frame structure -> primitive-atom
+        conversion (trajectory_analyzer.py:37-74) runs on the device as well."""
         torch = self.torch
-        frames_xyz = np.ascontiguousarray(frames_xyz, dtype=np.float64)
-        n_frames, n_atoms = frames_xyz.shape[0], frames_xyz.shape[1]
+        if topology is not None:
+            frames_xyz = np.ascontiguousarray(frames_xyz, dtype=np.float32)
+            if frames_xyz.ndim != 3 or frames_xyz.shape[1:] != (topology.n_atoms, 3):
+                raise ValueError(f"expected [n_frames][{topology.n_atoms}][3] source-atom coordinates, got {frames_xyz.shape}")
+            n_frames, n_atoms = frames_xyz.shape[0], len(topology)
+            load = self.load_atom_frames
+        else:
+            frames_xyz = np.ascontiguousarray(frames_xyz, dtype=np.float64)
+            n_frames, n_atoms = frames_xyz.shape[0], frames_xyz.shape[1]
+            load = self.load_frames
         lp = np.ascontiguousarray(local_pairs, dtype=np.int64).reshape(-1, 2)
         chunk = max(1, min(int(chunk), n_frames))
         dev = torch.device("cuda", self.device)
@@ -139,16 +174,19 @@ class DeviceSession:
         anchors = anchors.contiguous()
         out = torch.empty(n_frames * len(lp), dtype=torch.float64, device=dev)
         bufs = [self.frames_buffer(ref_cloud, chunk), self.frames_buffer(ref_cloud, chunk)]
+        if topology is not None:
+            for b in bufs:
+                self.set_frame_sources(b, topology)
         copy_stream = torch.cuda.Stream(device=dev)
         starts = list(range(0, n_frames, chunk))
-        self.load_frames(bufs[0], frames_xyz[starts[0]:starts[0] + chunk], copy_stream)
+        load(bufs[0], frames_xyz[starts[0]:starts[0] + chunk], copy_stream)
         for k, f0 in enumerate(starts):
             nf = min(chunk, n_frames - f0)
             self.from_primitives_async(ref_cloud, bufs[k % 2], anchors[: nf * len(lp)], threshold_distance,
                                        out[f0 * len(lp):(f0 + nf) * len(lp)])
             if k + 1 < len(starts):
                 f1 = starts[k + 1]
-                self.load_frames(bufs[(k + 1) % 2], frames_xyz[f1:f1 + chunk], copy_stream)
+                load(bufs[(k + 1) % 2], frames_xyz[f1:f1 + chunk], copy_stream)
             self.finish()
         res = out.cpu().numpy().reshape(n_frames, len(lp))
         for b in bufs:
