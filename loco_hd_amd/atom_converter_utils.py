@@ -100,8 +100,8 @@ class PrimitiveTopology:
         lens = np.diff(self.src_start)
         if len(lens) and lens.min() < 1:
             raise ValueError("a primitive atom without source atoms has no centroid")
-        acc = xyz[..., self.src_idx[self.src_start[:-1]], :].astype(np.float32, copy=True)
-        for k in range(1, int(lens.max()) if len(lens) else 0):
+        acc = np.zeros(xyz.shape[:-2] + (len(lens), 3), dtype=np.float32)  # add.reduce starts from +0 (a lone -0.0 -> +0.0)
+        for k in range(int(lens.max()) if len(lens) else 0):
             sel = np.nonzero(lens > k)[0]
             acc[..., sel, :] += xyz[..., self.src_idx[self.src_start[sel] + k], :]
         return (acc / lens.astype(np.float32)[:, None]).astype(np.float32, copy=False)

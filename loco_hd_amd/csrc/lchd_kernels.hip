@@ -1719,7 +1719,7 @@ void launch_frames_unpack(hipStream_t s, const double* raw, int64_t n_atoms, dou
 // atom p of every frame is the centroid of source atoms src_idx[src_start[p] .. src_start[p+1]) -- what
 // PrimitiveAssigner.assign_primitive_structure computes per frame on the host with np.mean(atom_coords, axis=0)
 // (/root/reference/loco_hd/atom_converter_utils.py:106-126, python_codes/trajectory_analyzer.py:55-72).  Same arithmetic
-// as that call: float32 accumulator seeded with the first member, members added in list order, one IEEE float32 division
+// as that call: float32 accumulator starting from +0, members added in list order, one IEEE float32 division
 // by the member count; the result is widened to f64 exactly like PrimitiveAtom.coordinates.  One thread per
 // (frame, primitive atom); the member gathers hit L2 (a frame's source atoms are a few 100 KB).
 __global__ void k_frames_centroids(const float* __restrict__ raw, int64_t n_src, const int32_t* __restrict__ src_start,
@@ -1731,9 +1731,8 @@ __global__ void k_frames_centroids(const float* __restrict__ raw, int64_t n_src,
         const int64_t f = i / n_prim, p = i - f * n_prim;
         const float* fr = raw + 3 * f * n_src;
         const int b = src_start[p], e = src_start[p + 1];
-        const float* a0 = fr + 3 * (int64_t)src_idx[b];
-        float sx = a0[0], sy = a0[1], sz = a0[2];
-        for (int k = b + 1; k < e; ++k) {
+        float sx = 0.0f, sy = 0.0f, sz = 0.0f;  // NumPy's add.reduce starts from +0: a lone -0.0 member comes out as +0.0
+        for (int k = b; k < e; ++k) {
             const float* a = fr + 3 * (int64_t)src_idx[k];
             sx += a[0]; sy += a[1]; sz += a[2];
         }

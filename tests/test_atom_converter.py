@@ -113,6 +113,8 @@ def test_topology_centroids_for_many_frames(tmp_path):
     topo = pa.compile_topology(st)
     rng = np.random.default_rng(0)
     frames = (topo.atom_coords[None] + rng.normal(0, 0.5, (7,) + topo.atom_coords.shape)).astype(np.float32)
+    single = next(p for p in range(len(topo)) if topo.src_start[p + 1] - topo.src_start[p] == 1)
+    frames[3, topo.src_idx[topo.src_start[single]]] = -0.0  # np.mean([-0.0]) is +0.0: add.reduce starts from +0
     cen = topo.centroids(frames)
     assert cen.shape == (7, len(topo), 3) and cen.dtype == np.float32
     for f in range(7):
