@@ -125,12 +125,148 @@ def cpu_baseline(w, gpu_scores: np.ndarray, budget_s: float = 12.0):
                       f"{cores} pthreads over anchor pairs; reference Rust core not buildable in this image"}, err, m
 
 
+def run_c4(args, torch, dist, dev, rank, world, use_dist):
+    """BASELINE.json configs[3] (MD-trajectory mode) with the structure -> primitive-atom step on the device as well:
+    one reference structure vs F frames of the same system, per-residue "Cent" anchors, accept_same=False, uniform[3,10],
+    threshold 10 A (python_codes/trajectory_analyzer.py:76-119).  The frames are float32 SOURCE atoms resident in HBM
+    ([F][5336][3]); one step = for every chunk of frames: k_frames_centroids (2001 primitive atoms per frame from their
+    source atoms, np.mean arithmetic) + the full scoring pass (cell lists, environments, sweep) of the chunk's anchor pairs."""
+    import loco_hd_amd as lh
+    from loco_hd_amd.device import DeviceSession
+
+    n_res, per_res, n_frames, chunk = 667, 8, args.frames, args.chunk
+    n_src, n_prim = n_res * per_res, 3 * n_res
+    rng = np.random.default_rng(4 + 1000 * rank)
+    side = (n_prim / 0.023) ** (1.0 / 3.0)
+    centres = rng.uniform(0.0, side, (n_res, 3))
+    ref_atoms = (np.repeat(centres, per_res, 0) + rng.normal(0.0, 1.5, (n_src, 3))).astype(np.float32)
+    # CSR map: primitive 3r = centroid of the residue's 8 atoms, 3r+1 = atom 1, 3r+2 = centroid of atoms 4 and 5
+    src_start, src_idx = [0], []
+    for r in range(n_res):
+        for members in (range(per_res), (1,), (4, 5)):
+            src_idx += [per_res * r + m for m in members]
+            src_start.append(len(src_idx))
+    types = ["Cent", "AmideC", "OH", "Pos", "Neg", "Aro", "Ali", "Sulf"]
+    cat = np.zeros(n_prim, dtype=np.int32)
+    cat[1::3], cat[2::3] = rng.integers(1, 8, n_res), rng.integers(1, 8, n_res)
+    tag = np.repeat(np.arange(n_res, dtype=np.int32), 3)
+
+    class Topo:  # the fields DeviceSession.set_frame_sources reads (PrimitiveTopology of a synthetic structure)
+        pass
+    topo = Topo()
+    topo.src_start, topo.src_idx, topo.n_atoms = np.asarray(src_start, np.int32), np.asarray(src_idx, np.int32), n_src
+
+    def centroids(atoms):  # np.mean per primitive atom, float32 (what the reference computes per frame on the host)
+        return np.stack([np.mean(atoms[topo.src_idx[a:b]], axis=0) for a, b in zip(src_start[:-1], src_start[1:])]).astype(np.float64)
+
+    lchd = lh.LoCoHD(types, lh.WeightFunction("uniform", [3.0, 10.0]), lh.TagPairingRule({"accept_same": False}))
+    sess = DeviceSession(lchd, device=dev.index)
+    sess.enable_timing(True)
+    ref = sess.upload(centroids(ref_atoms), cat, tag)
+    gen = torch.Generator(device=dev).manual_seed(4 + rank)
+    d_ref = torch.from_numpy(ref_atoms).to(dev)
+    frames = (d_ref[None] + 0.5 * torch.randn((n_frames, n_src, 3), generator=gen, device=dev, dtype=torch.float32)).contiguous()
+    chunk = min(chunk, n_frames)
+    buf = sess.frames_buffer(ref, chunk)
+    sess.set_frame_sources(buf, topo)
+    la = torch.arange(0, n_prim, 3, dtype=torch.int64, device=dev)
+    offs = torch.arange(chunk, dtype=torch.int64, device=dev).repeat_interleave(len(la)) * n_prim
+    anchors = torch.stack([la.repeat(chunk), la.repeat(chunk) + offs], 1).contiguous()
+    p = n_frames * len(la)
+    out = torch.empty(p, dtype=torch.float64, device=dev)
+    starts = list(range(0, n_frames, chunk))
+    phase = {"convert": 0.0, "cells": 0.0, "anchors": 0.0, "env": 0.0, "sweep": 0.0}
+    env_points = [0]
+
+    def step(collect=False):
+        for f0 in starts:
+            nf = min(chunk, n_frames - f0)
+            sess.load_atom_frames_dev(buf, frames[f0:f0 + nf])
+            sess.from_primitives(ref, buf, anchors[: nf * len(la)], 10.0, out=out[f0 * len(la):(f0 + nf) * len(la)])
+            if collect:
+                phase["convert"] += sess.last_convert_ms(buf)
+                for k, v in sess.last_ms().items():
+                    phase[k] += v
+
+    for _ in range(args.warmup):
+        step()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(collect=True)
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    phase = {k: v / max(args.steps, 1) for k, v in phase.items()}
+    for f0 in starts:  # environment points of the whole job (outside the timed region)
+        nf = min(chunk, n_frames - f0)
+        sess.load_atom_frames_dev(buf, frames[f0:f0 + nf])
+        sess.from_primitives(ref, buf, anchors[: nf * len(la)], 10.0, out=out[f0 * len(la):(f0 + nf) * len(la)])
+        env_points[0] += sess.last_env_points()
+    scores = out.cpu().numpy().reshape(n_frames, len(la))
+    result = None
+    if rank == 0:
+        algo = env_points[0] * 32 + 16 * p  # SURVEY.md 8(d): 32 B per environment point when a tag rule is active
+        dom = max(("env", "sweep"), key=lambda k: phase[k])
+        achieved = algo / (phase[dom] * 1e-3) / 1e9
+        conv_bytes = n_frames * (n_src * 12 + n_prim * 24)  # every source atom read once (3 x f32), every primitive atom written (3 x f64)
+        label = (f"C4: 1 reference vs {n_frames} frames of a {n_prim}-primitive-atom system ({n_src} float32 source atoms/frame, "
+                 f"converted on the device), {len(la)} per-residue anchors/frame, accept_same=False, uniform[3,10], thr 10 A, "
+                 f"chunks of {chunk} frames")
+        result = {
+            "metric": "anchor-pair LoCoHD scores/sec", "value": p * world * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": label, "pairs_per_gpu": p, "mean_env_points_per_pair": env_points[0] / p},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": {"env": "k_env_cells (side A + side B)", "sweep": "k_sweep"}[dom],
+                         "algorithmic_bytes_per_launch": algo / len(starts), "avg_launch_ms": phase[dom] / len(starts)},
+            "kernel_ms": phase,
+            "extras": {"k_frames_centroids": {"ms_per_step": phase["convert"], "algorithmic_bytes_per_step": conv_bytes,
+                                              "GB_per_s": conv_bytes / max(phase["convert"], 1e-9) / 1e6,
+                                              "frac_of_hbm_peak": conv_bytes / max(phase["convert"], 1e-9) / 1e6 / HBM_PEAK_GBS}},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import oracle as orc  # checker / baseline only
+
+            cores = usable_cores()
+            lo = orc.LoCoHD(types, orc.WeightFunction("uniform", [3.0, 10.0]), orc.TagPairingRule({"accept_same": False}), n_of_threads=cores)
+            sample = sorted(set(np.linspace(0, n_frames - 1, min(n_frames, 24)).astype(int).tolist()))
+            host_frames = frames[torch.tensor(sample, device=dev)].cpu().numpy()
+            ref_xyz = centroids(ref_atoms)
+            pairs = np.stack([np.arange(0, n_prim, 3), np.arange(0, n_prim, 3)], 1).astype(np.int64)
+            t1 = time.perf_counter()
+            err = 0.0
+            for k, f in enumerate(sample):  # per frame, like the reference's loop: convert, then score
+                got = np.asarray(lo.from_arrays(ref_xyz, cat, tag, centroids(host_frames[k]), cat, tag, pairs, 10.0))
+                err = max(err, float(np.max(np.abs(got - scores[f]))))
+            dt = time.perf_counter() - t1
+            result["cpu_baseline"] = {"value": len(sample) * len(pairs) / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+                                      "sample": f"{len(sample)} frames spread over the trajectory ({len(sample) * len(pairs)} pairs), {dt:.1f} s: "
+                                                f"NumPy np.mean conversion per frame + C oracle with {cores} pthreads over anchor pairs"}
+            result["max_abs_err_vs_cpu"] = err
+            result["parity_sample_pairs"] = len(sample) * len(pairs)
+            if not (err <= 1e-6):
+                result["parity_failed"] = True
+    sess.close()
+    return result
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2a", choices=["c2a", "c5"])
+    ap.add_argument("--workload", default="c2a", choices=["c2a", "c5", "c4"])
+    ap.add_argument("--frames", type=int, default=5000, help="c4: frames of the trajectory")
+    ap.add_argument("--chunk", type=int, default=1250, help="c4: frames per scoring pass")
     ap.add_argument("--pairs", type=int, default=1_000_000, help="anchor pairs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg, the parity gate and the extras (profiling runs)")
     args = ap.parse_args()
@@ -151,6 +287,23 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    if args.workload == "c4":  # trajectory mode: frames shard across ranks with no exchange step (weak scaling: F frames per rank)
+        result = run_c4(args, torch, dist, dev, rank, world, use_dist)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            import ctypes
+
+            try:
+                ctypes.CDLL(None).fflush(None)
+            except OSError:
+                pass
+            print(json.dumps(result), flush=True)
+            if result.get("parity_failed"):
+                sys.exit(3)
+        return
 
     import loco_hd_amd as lh
     from loco_hd_amd.device import DeviceSession

@@ -167,6 +167,10 @@ int lchd_frames_load(lchd_ctx *ctx, lchd_cloud *frames, const double *xyz, int32
 int lchd_frames_set_sources(lchd_ctx *ctx, lchd_cloud *frames, const int32_t *src_start, const int32_t *src_idx,
                             int64_t n_src_atoms);
 int lchd_frames_load_atoms(lchd_ctx *ctx, lchd_cloud *frames, const float *atom_xyz, int32_t n_frames, void *hip_stream);
+/* The same with the source atoms already in HBM (d_atom_xyz is a DEVICE pointer; no staging copy), and the duration of
+ * the most recent conversion kernel of this buffer in ms (HIP events; <0 unless lchd_ctx_enable_timing is on). */
+int lchd_frames_load_atoms_dev(lchd_ctx *ctx, lchd_cloud *frames, const float *d_atom_xyz, int32_t n_frames, void *hip_stream);
+double lchd_frames_last_convert_ms(lchd_ctx *ctx, lchd_cloud *frames);
 /* Coordinates of a cloud / frames buffer back on the host as [n][3] f64 (n must equal the atoms it holds). */
 int lchd_cloud_get_coords(lchd_ctx *ctx, lchd_cloud *cloud, double *xyz_out, int64_t n);
 

@@ -79,6 +79,8 @@ _PROTOS = {
     "lchd_frames_load": (C.c_int, [_VP, _VP, _DP, _i32, _VP]),
     "lchd_frames_set_sources": (C.c_int, [_VP, _VP, _IP, _IP, _i64]),
     "lchd_frames_load_atoms": (C.c_int, [_VP, _VP, C.POINTER(C.c_float), _i32, _VP]),
+    "lchd_frames_load_atoms_dev": (C.c_int, [_VP, _VP, _VP, _i32, _VP]),
+    "lchd_frames_last_convert_ms": (C.c_double, [_VP, _VP]),
     "lchd_cloud_get_coords": (C.c_int, [_VP, _VP, _DP, _i64]),
     "lchd_ctx_enable_timing": (C.c_int, [_VP, _i32]),
     "lchd_ctx_last_ms": (C.c_double, [_VP, C.c_char_p]),

@@ -136,10 +136,14 @@ struct lchd_cloud {
     double* d_raw = nullptr;   // device staging of the caller's [frames][atoms][3] block
     double* h_pinned = nullptr;
     // frames given as float32 SOURCE atoms (lchd_frames_set_sources): CSR map primitive atom -> source atoms
-    int32_t *d_src_start = nullptr, *d_src_idx = nullptr;
+    int32_t *d_src_start = nullptr, *d_src_idx = nullptr, *d_tiles = nullptr;
+    int32_t n_tiles = 0;
     int64_t n_src = 0;
     float *d_raw32 = nullptr, *h_pinned32 = nullptr;
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // timing of the most recent load (only when the context's timing is on)
+    bool t_valid = false;
     unsigned long long* d_bbox = nullptr;  // [7]: order-preserving keys of min xyz, max xyz, non-finite flag
+    unsigned long long* d_bbox_part = nullptr;  // per-workgroup partials of the centroid kernel
     hipEvent_t ev_ready = nullptr, ev_used = nullptr;
     bool bbox_pending = false, used_valid = false;
     double bbmin[3] = {0, 0, 0}, bbmax[3] = {0, 0, 0};
@@ -438,13 +442,17 @@ extern "C" void lchd_cloud_destroy(lchd_ctx* c, lchd_cloud* cl) {
     (void)hipFree(cl->sid);
     (void)hipFree(cl->d_raw);
     (void)hipFree(cl->d_bbox);
+    (void)hipFree(cl->d_bbox_part);
     (void)hipFree(cl->d_src_start);
     (void)hipFree(cl->d_src_idx);
+    (void)hipFree(cl->d_tiles);
     (void)hipFree(cl->d_raw32);
     if (cl->h_pinned32) (void)hipHostFree(cl->h_pinned32);
     if (cl->h_pinned) (void)hipHostFree(cl->h_pinned);
     if (cl->ev_ready) (void)hipEventDestroy(cl->ev_ready);
     if (cl->ev_used) (void)hipEventDestroy(cl->ev_used);
+    if (cl->ev_t0) (void)hipEventDestroy(cl->ev_t0);
+    if (cl->ev_t1) (void)hipEventDestroy(cl->ev_t1);
     delete cl;
 }
 
@@ -775,10 +783,40 @@ extern "C" int lchd_frames_set_sources(lchd_ctx* c, lchd_cloud* fr, const int32_
     for (int64_t k = 0; k < nnz; ++k)
         if (src_idx[k] < 0 || src_idx[k] >= n_src_atoms)
             return fail(LCHD_EVALUE, "source atom index %d at position %lld is outside [0, %lld)", src_idx[k], (long long)k, (long long)n_src_atoms);
+    // Tiles: consecutive primitive atoms whose members span at most `span` consecutive source atoms (staged through LDS);
+    // spans are balanced so that the tiles of a frame carry similar byte counts.  A primitive atom that alone spans more
+    // becomes a tile of its own that gathers from global memory.
+    std::vector<int32_t> tiles;
+    {
+        const int cap = centroid_tile_span();
+        int64_t glo = n_src_atoms, ghi = 0;
+        for (int64_t k = 0; k < nnz; ++k) { glo = std::min<int64_t>(glo, src_idx[k]); ghi = std::max<int64_t>(ghi, src_idx[k] + 1); }
+        const int64_t pieces = std::max<int64_t>(1, (ghi - glo + cap - 1) / cap);
+        const int span = (int)std::min<int64_t>(cap, (ghi - glo + pieces - 1) / pieces + 64);
+        int64_t p0 = 0;
+        int lo = 0, hi = 0;
+        auto close = [&](int64_t p1) { if (p1 > p0) { tiles.push_back((int32_t)p0); tiles.push_back((int32_t)p1); tiles.push_back(lo); tiles.push_back(hi); } };
+        for (int64_t p = 0; p < np; ++p) {
+            int plo = src_idx[src_start[p]], phi = plo + 1;
+            for (int k = src_start[p]; k < src_start[p + 1]; ++k) { plo = std::min(plo, src_idx[k]); phi = std::max(phi, src_idx[k] + 1); }
+            if (phi - plo > span) {  // cannot be staged: its own global-gather tile
+                close(p);
+                tiles.push_back((int32_t)p); tiles.push_back((int32_t)p + 1); tiles.push_back(-1); tiles.push_back(-1);
+                p0 = p + 1;
+                continue;
+            }
+            if (p == p0) { lo = plo; hi = phi; continue; }
+            const int nlo = std::min(lo, plo), nhi = std::max(hi, phi);
+            if (nhi - nlo > span) { close(p); p0 = p; lo = plo; hi = phi; }
+            else { lo = nlo; hi = nhi; }
+        }
+        close(np);
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (fr->ev_ready && fr->bbox_pending) HIP_TRY(hipEventSynchronize(fr->ev_ready));
     (void)hipFree(fr->d_src_start); fr->d_src_start = nullptr;
     (void)hipFree(fr->d_src_idx); fr->d_src_idx = nullptr;
+    (void)hipFree(fr->d_tiles); fr->d_tiles = nullptr;
     (void)hipFree(fr->d_raw32); fr->d_raw32 = nullptr;
     if (fr->h_pinned32) { (void)hipHostFree(fr->h_pinned32); fr->h_pinned32 = nullptr; }
     fr->n_src = 0;
@@ -789,11 +827,16 @@ extern "C" int lchd_frames_set_sources(lchd_ctx* c, lchd_cloud* fr, const int32_
     HIP_TRY(hipHostMalloc(&fr->h_pinned32, sizeof(float) * raw_elems));
     HIP_TRY(hipMemcpy(fr->d_src_start, src_start, sizeof(int32_t) * (size_t)(np + 1), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(fr->d_src_idx, src_idx, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
+    if (!fr->d_bbox_part) HIP_TRY(hipMalloc(&fr->d_bbox_part, sizeof(unsigned long long) * 7 * (size_t)bbox_parts_capacity()));
+    HIP_TRY(hipMalloc(&fr->d_tiles, sizeof(int32_t) * tiles.size()));
+    HIP_TRY(hipMemcpy(fr->d_tiles, tiles.data(), sizeof(int32_t) * tiles.size(), hipMemcpyHostToDevice));
+    fr->n_tiles = (int32_t)(tiles.size() / 4);
     fr->n_src = n_src_atoms;
     return LCHD_OK;
 }
 
-extern "C" int lchd_frames_load_atoms(lchd_ctx* c, lchd_cloud* fr, const float* atom_xyz, int32_t n_frames, void* hip_stream) {
+// host_src: copy through the pinned block first; otherwise `atom_xyz` is already a DEVICE pointer
+static int frames_load_atoms(lchd_ctx* c, lchd_cloud* fr, const float* atom_xyz, int32_t n_frames, void* hip_stream, bool host_src) {
     if (!c || !fr || !atom_xyz || !fr->cap_frames) return fail(LCHD_EVALUE, "not a frames buffer");
     if (!fr->n_src) return fail(LCHD_EVALUE, "lchd_frames_set_sources has not been called on this frames buffer");
     if (n_frames < 1 || n_frames > fr->cap_frames) return fail(LCHD_EVALUE, "%d frames do not fit a buffer of %d", n_frames, fr->cap_frames);
@@ -801,17 +844,43 @@ extern "C" int lchd_frames_load_atoms(lchd_ctx* c, lchd_cloud* fr, const float* 
         return fail(LCHD_EVALUE, "this frames buffer is in use by an unfinished asynchronous call");
     hipStream_t s = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->stream;
     const size_t elems = (size_t)3 * (size_t)fr->n_src * (size_t)n_frames;
-    if (fr->ev_ready && fr->bbox_pending) HIP_TRY(hipEventSynchronize(fr->ev_ready));  // pinned block free again
-    memcpy(fr->h_pinned32, atom_xyz, sizeof(float) * elems);
+    const float* d_src = atom_xyz;
+    if (host_src) {
+        if (fr->ev_ready && fr->bbox_pending) HIP_TRY(hipEventSynchronize(fr->ev_ready));  // pinned block free again
+        memcpy(fr->h_pinned32, atom_xyz, sizeof(float) * elems);
+    }
     if (fr->used_valid) HIP_TRY(hipStreamWaitEvent(s, fr->ev_used, 0));
-    HIP_TRY(hipMemcpyAsync(fr->d_raw32, fr->h_pinned32, sizeof(float) * elems, hipMemcpyHostToDevice, s));
-    launch_frames_centroids(s, fr->d_raw32, fr->n_src, fr->d_src_start, fr->d_src_idx, fr->n_tmpl, n_frames, fr->x, fr->y, fr->z, fr->d_bbox);
+    if (host_src) {
+        HIP_TRY(hipMemcpyAsync(fr->d_raw32, fr->h_pinned32, sizeof(float) * elems, hipMemcpyHostToDevice, s));
+        d_src = fr->d_raw32;
+    }
+    fr->t_valid = false;
+    if (c->timing) {
+        if (!fr->ev_t0) { HIP_TRY(hipEventCreate(&fr->ev_t0)); HIP_TRY(hipEventCreate(&fr->ev_t1)); }
+        HIP_TRY(hipEventRecord(fr->ev_t0, s));
+    }
+    launch_frames_centroids(s, d_src, fr->n_src, fr->d_src_start, fr->d_src_idx, fr->d_tiles, fr->n_tiles, fr->n_tmpl, n_frames, fr->x,
+                            fr->y, fr->z, fr->d_bbox, fr->d_bbox_part);
+    if (c->timing) { HIP_TRY(hipEventRecord(fr->ev_t1, s)); fr->t_valid = true; }
     HIP_TRY(hipEventRecord(fr->ev_ready, s));
     HIP_TRY(hipGetLastError());
     fr->n = fr->n_tmpl * n_frames;
     fr->n_struct = n_frames;
     fr->bbox_pending = true;
     return LCHD_OK;
+}
+
+extern "C" int lchd_frames_load_atoms(lchd_ctx* c, lchd_cloud* fr, const float* atom_xyz, int32_t n_frames, void* hip_stream) {
+    return frames_load_atoms(c, fr, atom_xyz, n_frames, hip_stream, true);
+}
+extern "C" int lchd_frames_load_atoms_dev(lchd_ctx* c, lchd_cloud* fr, const float* d_atom_xyz, int32_t n_frames, void* hip_stream) {
+    return frames_load_atoms(c, fr, d_atom_xyz, n_frames, hip_stream, false);
+}
+extern "C" double lchd_frames_last_convert_ms(lchd_ctx* c, lchd_cloud* fr) {
+    if (!c || !fr || !fr->t_valid) return -1.0;
+    float t = -1.f;
+    if (hipEventSynchronize(fr->ev_t1) != hipSuccess || hipEventElapsedTime(&t, fr->ev_t0, fr->ev_t1) != hipSuccess) return -1.0;
+    return t;
 }
 
 /* Read back the primitive-atom coordinates of a frames buffer (or any cloud) as [n][3] f64: lets a caller check the device

@@ -117,8 +117,13 @@ void launch_frames_labels(hipStream_t s, const uint8_t* tcat, const int32_t* tta
 void launch_frames_unpack(hipStream_t s, const double* raw, int64_t n_atoms, double* x, double* y, double* z,
                           unsigned long long* bbox7);
 // primitive atoms of every frame = float32 centroids of their source atoms (CSR src_start / src_idx), widened to f64
+// tiles: [n_tiles][4] = {first primitive, end primitive, first source atom, end source atom} with a span of at most
+// centroid_tile_span() source atoms, or {p0, p1, -1, -1} for a primitive range that is gathered from global memory
 void launch_frames_centroids(hipStream_t s, const float* raw, int64_t n_src, const int32_t* src_start, const int32_t* src_idx,
-                             int64_t n_prim, int32_t n_frames, double* x, double* y, double* z, unsigned long long* bbox7);
+                             const int32_t* tiles, int n_tiles, int64_t n_prim, int32_t n_frames, double* x, double* y, double* z,
+                             unsigned long long* bbox7, unsigned long long* bbox_part /* [bbox_parts_capacity()][7] */);
+int centroid_tile_span();
+int bbox_parts_capacity();
 void launch_fill_sqrt_tables(hipStream_t s, double* sqrt_tab, double* rsqrt_tab);  // 65536 entries each
 void launch_env_points(hipStream_t s, const SweepArgs& a, unsigned long long* out);
 

@@ -1720,42 +1720,121 @@ void launch_frames_unpack(hipStream_t s, const double* raw, int64_t n_atoms, dou
 // PrimitiveAssigner.assign_primitive_structure computes per frame on the host with np.mean(atom_coords, axis=0)
 // (/root/reference/loco_hd/atom_converter_utils.py:106-126, python_codes/trajectory_analyzer.py:55-72).  Same arithmetic
 // as that call: float32 accumulator starting from +0, members added in list order, one IEEE float32 division
-// by the member count; the result is widened to f64 exactly like PrimitiveAtom.coordinates.  One thread per
-// (frame, primitive atom); the member gathers hit L2 (a frame's source atoms are a few 100 KB).
-__global__ void k_frames_centroids(const float* __restrict__ raw, int64_t n_src, const int32_t* __restrict__ src_start,
-                                   const int32_t* __restrict__ src_idx, int64_t n_prim, int64_t total, double* __restrict__ x,
-                                   double* __restrict__ y, double* __restrict__ z, unsigned long long* bbox7) {
+// by the member count; the result is widened to f64 exactly like PrimitiveAtom.coordinates.
+//
+// HBM-bound by construction: the host cuts the primitive atoms into tiles whose members span at most kCentroidSpan
+// consecutive source atoms (typing schemes walk residues in order, so the CSR map is local); a workgroup streams one
+// (frame, tile) slice of the source coordinates into LDS with 16-byte coalesced loads, gathers the members from LDS
+// (stride 3 floats: conflict-free) and writes x/y/z coalesced.  Every source atom is read once per frame, every
+// primitive atom written once: 12 B x n_src + 24 B x n_prim per frame.  A tile whose span does not fit (lo == hi == -1)
+// gathers straight from global memory.  The bounding box is reduced per workgroup before it touches the 7 global words.
+constexpr int kCentroidSpan = 4096;  // source atoms per tile: 48 KB of LDS
+constexpr int kBboxParts = 4096;     // capacity of a frames buffer's per-workgroup bounding-box partials
+__global__ __launch_bounds__(256) void k_frames_centroids(const float* __restrict__ raw, int64_t n_src, const int32_t* __restrict__ src_start,
+                                                          const int32_t* __restrict__ src_idx, const int4* __restrict__ tiles, int n_tiles,
+                                                          int64_t n_prim, int64_t n_items, double* __restrict__ x, double* __restrict__ y,
+                                                          double* __restrict__ z, unsigned long long* __restrict__ bbox_part) {
+    __shared__ __attribute__((aligned(16))) float s_xyz[kCentroidSpan * 3 + 8];
+    __shared__ double s_red[4][6];
+    __shared__ int s_bad;
+    const int tid = threadIdx.x;
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     bool bad = false;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t f = i / n_prim, p = i - f * n_prim;
+    for (int64_t w = blockIdx.x; w < n_items; w += gridDim.x) {
+        const int64_t f = w / n_tiles;
+        const int4 t = tiles[(int)(w - f * n_tiles)];  // {first primitive, end primitive, first source atom, end source atom}
         const float* fr = raw + 3 * f * n_src;
-        const int b = src_start[p], e = src_start[p + 1];
-        float sx = 0.0f, sy = 0.0f, sz = 0.0f;  // NumPy's add.reduce starts from +0: a lone -0.0 member comes out as +0.0
-        for (int k = b; k < e; ++k) {
-            const float* a = fr + 3 * (int64_t)src_idx[k];
-            sx += a[0]; sy += a[1]; sz += a[2];
+        const bool staged = t.z >= 0;
+        int head = 0;
+        if (staged) {
+            // floats [g0, g1) of the buffer = source atoms [lo, hi) of this frame.  LDS origin `base` = the 16-byte aligned
+            // ADDRESS at or below g0 (the caller's pointer need not be 16-byte aligned; base can be < 0 only for the very
+            // first floats of the buffer, which are then copied one by one).
+            const int64_t g0 = 3 * f * n_src + 3 * (int64_t)t.z, g1 = 3 * f * n_src + 3 * (int64_t)t.w;
+            const int m = (int)((reinterpret_cast<uintptr_t>(raw) >> 2) & 3);
+            const int64_t base = ((g0 + m) & ~(int64_t)3) - m;
+            const int64_t v0 = base < 0 ? base + 4 : base;  // first aligned float4 inside the buffer
+            head = (int)(g0 - base);
+            const int n4 = g1 > v0 ? (int)((g1 - v0) >> 2) : 0;
+            const float4* src4 = reinterpret_cast<const float4*>(raw + v0);
+            float4* dst4 = reinterpret_cast<float4*>(s_xyz) + ((v0 - base) >> 2);
+            for (int k = tid; k < n4; k += 256) dst4[k] = src4[k];
+            for (int64_t k = g0 + tid; k < v0; k += 256) s_xyz[k - base] = raw[k];
+            for (int64_t k = v0 + 4 * (int64_t)n4 + tid; k < g1; k += 256) s_xyz[k - base] = raw[k];
+            __syncthreads();
         }
-        const float cnt = (float)(e - b);
-        const double vx = (double)__fdiv_rn(sx, cnt), vy = (double)__fdiv_rn(sy, cnt), vz = (double)__fdiv_rn(sz, cnt);
-        x[i] = vx; y[i] = vy; z[i] = vz;
-        bad = bad || !(fabs(vx) < INFINITY) || !(fabs(vy) < INFINITY) || !(fabs(vz) < INFINITY);
-        mn[0] = fmin(mn[0], vx); mn[1] = fmin(mn[1], vy); mn[2] = fmin(mn[2], vz);
-        mx[0] = fmax(mx[0], vx); mx[1] = fmax(mx[1], vy); mx[2] = fmax(mx[2], vz);
+        for (int p = t.x + tid; p < t.y; p += 256) {
+            const int b = src_start[p], e = src_start[p + 1];
+            float sx = 0.0f, sy = 0.0f, sz = 0.0f;  // NumPy's add.reduce starts from +0: a lone -0.0 member comes out as +0.0
+            if (staged) {
+                for (int k = b; k < e; ++k) {
+                    const float* a = s_xyz + head + 3 * (src_idx[k] - t.z);
+                    sx += a[0]; sy += a[1]; sz += a[2];
+                }
+            } else {
+                for (int k = b; k < e; ++k) {
+                    const float* a = fr + 3 * (int64_t)src_idx[k];
+                    sx += a[0]; sy += a[1]; sz += a[2];
+                }
+            }
+            const float cnt = (float)(e - b);
+            const double vx = (double)__fdiv_rn(sx, cnt), vy = (double)__fdiv_rn(sy, cnt), vz = (double)__fdiv_rn(sz, cnt);
+            const int64_t o = f * n_prim + p;
+            x[o] = vx; y[o] = vy; z[o] = vz;
+            bad = bad || !(fabs(vx) < INFINITY) || !(fabs(vy) < INFINITY) || !(fabs(vz) < INFINITY);
+            mn[0] = fmin(mn[0], vx); mn[1] = fmin(mn[1], vy); mn[2] = fmin(mn[2], vz);
+            mx[0] = fmax(mx[0], vx); mx[1] = fmax(mx[1], vy); mx[2] = fmax(mx[2], vz);
+        }
+        if (staged) __syncthreads();  // the tile is consumed before the next one overwrites it
     }
     for (int m = 32; m > 0; m >>= 1)
         for (int k = 0; k < 3; ++k) { mn[k] = fmin(mn[k], shfl_xor_f64(mn[k], m)); mx[k] = fmax(mx[k], shfl_xor_f64(mx[k], m)); }
     const unsigned long long anybad = __ballot(bad);
-    if ((threadIdx.x & 63) == 0) {
-        for (int k = 0; k < 3; ++k) { atomicMin(&bbox7[k], ordered_key(mn[k])); atomicMax(&bbox7[3 + k], ordered_key(mx[k])); }
-        if (anybad) atomicOr(&bbox7[6], 1ull);
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    if ((tid & 63) == 0) {
+        for (int k = 0; k < 3; ++k) { s_red[tid >> 6][k] = mn[k]; s_red[tid >> 6][3 + k] = mx[k]; }
+        if (anybad) atomicOr(&s_bad, 1);
+    }
+    __syncthreads();
+    // per-workgroup partial result, no atomics: k_bbox_finish folds the partials into the 7 words the host reads
+    if (tid < 6) {
+        double v = s_red[0][tid];
+        for (int wv = 1; wv < 4; ++wv) v = tid < 3 ? fmin(v, s_red[wv][tid]) : fmax(v, s_red[wv][tid]);
+        bbox_part[(size_t)blockIdx.x * 7 + tid] = ordered_key(v);
+    }
+    if (tid == 6) bbox_part[(size_t)blockIdx.x * 7 + 6] = s_bad ? 1ull : 0ull;
+}
+__global__ __launch_bounds__(256) void k_bbox_finish(const unsigned long long* __restrict__ part, int n_parts, unsigned long long* bbox7) {
+    __shared__ unsigned long long red[4][7];
+    const int tid = threadIdx.x;
+    unsigned long long v[7] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull, 0ull};
+    for (int b = tid; b < n_parts; b += 256) {
+        for (int k = 0; k < 3; ++k) { v[k] = min(v[k], part[(size_t)b * 7 + k]); v[3 + k] = max(v[3 + k], part[(size_t)b * 7 + 3 + k]); }
+        v[6] |= part[(size_t)b * 7 + 6];
+    }
+    for (int m = 32; m > 0; m >>= 1)
+        for (int k = 0; k < 7; ++k) {
+            const unsigned long long o = shfl_u64(v[k], (tid & 63) ^ m);
+            v[k] = k < 3 ? min(v[k], o) : (k < 6 ? max(v[k], o) : (v[k] | o));
+        }
+    if ((tid & 63) == 0) for (int k = 0; k < 7; ++k) red[tid >> 6][k] = v[k];
+    __syncthreads();
+    if (tid < 7) {
+        unsigned long long r = red[0][tid];
+        for (int w = 1; w < 4; ++w) r = tid < 3 ? min(r, red[w][tid]) : (tid < 6 ? max(r, red[w][tid]) : (r | red[w][tid]));
+        bbox7[tid] = r;
     }
 }
 void launch_frames_centroids(hipStream_t s, const float* raw, int64_t n_src, const int32_t* src_start, const int32_t* src_idx,
-                             int64_t n_prim, int32_t n_frames, double* x, double* y, double* z, unsigned long long* bbox7) {
-    static const unsigned long long init[7] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull, 0ull};
-    (void)hipMemcpyAsync(bbox7, init, sizeof init, hipMemcpyHostToDevice, s);
-    const int64_t total = n_prim * n_frames, nb = (total + 255) / 256;
-    k_frames_centroids<<<(unsigned)(nb < 2048 ? nb : 2048), 256, 0, s>>>(raw, n_src, src_start, src_idx, n_prim, total, x, y, z, bbox7);
+                             const int32_t* tiles, int n_tiles, int64_t n_prim, int32_t n_frames, double* x, double* y, double* z,
+                             unsigned long long* bbox7, unsigned long long* bbox_part) {
+    const int64_t items = (int64_t)n_tiles * n_frames;
+    const int grid = (int)(items < kBboxParts ? items : kBboxParts);  // more workgroups than fit at once: the dispatcher balances them
+    k_frames_centroids<<<grid, 256, 0, s>>>(raw, n_src, src_start, src_idx, reinterpret_cast<const int4*>(tiles), n_tiles, n_prim, items, x, y,
+                                            z, bbox_part);
+    k_bbox_finish<<<1, 256, 0, s>>>(bbox_part, grid, bbox7);
 }
+int centroid_tile_span() { return kCentroidSpan; }
+int bbox_parts_capacity() { return kBboxParts; }
 }  // namespace lchd

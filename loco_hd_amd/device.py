@@ -138,6 +138,15 @@ class DeviceSession:
         sp = None if stream is None else C.c_void_p(stream.cuda_stream)
         N.check(N.lib().lchd_frames_load_atoms(self._ctx, buf, atom_xyz.ctypes.data_as(C.POINTER(C.c_float)), atom_xyz.shape[0], sp))
 
+    def load_atom_frames_dev(self, buf, atom_xyz, stream=None):
+        """As load_atom_frames with the float32 source atoms already on the device: a torch CUDA tensor [n_frames][n_src][3]."""
+        assert atom_xyz.is_cuda and atom_xyz.dtype == self.torch.float32 and atom_xyz.is_contiguous() and atom_xyz.dim() == 3
+        sp = None if stream is None else C.c_void_p(stream.cuda_stream)
+        N.check(N.lib().lchd_frames_load_atoms_dev(self._ctx, buf, C.c_void_p(atom_xyz.data_ptr()), atom_xyz.shape[0], sp))
+
+    def last_convert_ms(self, buf) -> float:
+        return float(N.lib().lchd_frames_last_convert_ms(self._ctx, buf))
+
     def coords_of(self, cloud, n: int) -> np.ndarray:
         """Primitive-atom coordinates currently held by a cloud / frames buffer, as float64 [n][3] on the host."""
         out = np.empty((int(n), 3), dtype=np.float64)

@@ -60,6 +60,53 @@ def test_device_centroids_bit_exact(lh, tmp_path):
     bad = type(topo)(topo.primitive_types, topo.sources, topo.src_start, topo.src_idx + 10 ** 6, topo.n_atoms, topo.atom_coords)
     with pytest.raises(ValueError):
         sess.set_frame_sources(buf, bad)
+    # source atoms already on the device, at every 4-byte misalignment of the frame block
+    import torch
+
+    sess.set_frame_sources(buf, topo)
+    flat = torch.zeros(frames.size + 8, dtype=torch.float32, device="cuda")
+    for shift in range(4):
+        view = flat[shift:shift + frames.size].view(n_frames, topo.n_atoms, 3)
+        view.copy_(torch.from_numpy(frames))
+        sess.load_atom_frames_dev(buf, view)
+        assert np.array_equal(sess.coords_of(buf, n_frames * len(topo)).reshape(n_frames, len(topo), 3), want.astype(np.float64)), shift
+    sess.close()
+
+
+def test_device_centroids_many_tiles_and_wide_groups(lh):
+    """A map whose members span more source atoms than one LDS tile holds (several tiles per frame), primitive atoms made of
+    far-apart atoms (global-gather tiles) and unsorted member lists, against np.mean."""
+    from loco_hd_amd.atom_converter_utils import PrimitiveTopology
+    from loco_hd_amd.device import DeviceSession
+
+    rng = np.random.default_rng(7)
+    n_atoms, n_prim = 20_000, 6_000
+    start, idx = [0], []
+    for p in range(n_prim):
+        k = int(rng.integers(1, 9))
+        if p % 997 == 0:      # spans (almost) the whole structure: cannot be staged
+            members = rng.integers(0, n_atoms, 5)
+        else:                 # local group, shuffled order
+            lo = int(p * (n_atoms - 40) / n_prim)
+            members = lo + rng.permutation(40)[:k]
+        idx += [int(v) for v in members]
+        start.append(len(idx))
+    topo = PrimitiveTopology(["X"] * n_prim, [], np.asarray(start, np.int32), np.asarray(idx, np.int32), n_atoms,
+                             rng.uniform(-50, 50, (n_atoms, 3)).astype(np.float32))
+    n_frames = 3
+    frames = (topo.atom_coords[None] + rng.normal(0, 1.0, (n_frames, n_atoms, 3))).astype(np.float32)
+    lchd = lh.LoCoHD(["X"])
+    sess = DeviceSession(lchd)
+    ref = sess.upload(topo.centroids().astype(np.float64), np.zeros(n_prim, np.int32))
+    buf = sess.frames_buffer(ref, n_frames)
+    sess.set_frame_sources(buf, topo)
+    sess.load_atom_frames(buf, frames)
+    got = sess.coords_of(buf, n_frames * n_prim).reshape(n_frames, n_prim, 3)
+    for f in range(n_frames):
+        for p in list(range(0, n_prim, 53)) + [0, 997, n_prim - 1]:
+            want = np.mean([frames[f, i] for i in idx[start[p]:start[p + 1]]], axis=0)
+            assert np.array_equal(got[f, p], want.astype(np.float64)), (f, p)
+    assert np.array_equal(got.astype(np.float32), topo.centroids(frames))
     sess.close()
 
 
