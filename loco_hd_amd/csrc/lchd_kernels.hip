@@ -888,6 +888,15 @@ __device__ __noinline__ double sd_generic(int kind, double p0, double p1, const 
     return sd_eval<0>(kind, p0, p1, [&](int c) { return p[c]; }, [&](int c) { return q[c]; }, C);
 }
 
+// Diagnostic build only (-DLCHD_SWEEP_STAMPS, never the shipped library): per-phase s_memtime deltas summed over all
+// wavefronts, read back with lchd_debug_sweep_stamps().
+#ifdef LCHD_SWEEP_STAMPS
+__device__ unsigned long long g_sweep_stamps[8];
+#define STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[i] += t_ - stamp_last; stamp_last = t_; } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 // register budget: 4 waves/SIMD (<= 128 VGPRs) up to 12 category slots, 3 (<= 168) up to 16, 2 beyond
 template <int CMAX, int MODE, int FMODE, bool LDSTAB>
 __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 12 ? 4 : (CMAX <= 16 ? 3 : 2)))) void k_sweep(SweepArgs args) {
@@ -931,6 +940,9 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
         else return sqrt_cnt(cnt);
     };
 
+#ifdef LCHD_SWEEP_STAMPS
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
+#endif
     for (int64_t p = (int64_t)blockIdx.x * WPB + wv; p < args.n_pairs; p += (int64_t)gridDim.x * WPB) {
         int64_t ea = p, eb = p;
         if (args.anchors) {
@@ -1107,6 +1119,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
         for (int k0 = 0; k0 < M; k0 += TILE) {
             const int T = min(TILE, M - k0);
             const int nAt = min(TILE, mA - ia), nBt = min(TILE, mB - ib);
+            STAMP(0);
             wave_sync_lds();  // previous tile fully consumed
             {   // stage the tile: all global loads of a list are issued before the first LDS write (one latency, not six)
                 uint64_t rk[EPL];
@@ -1135,6 +1148,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
                 }
             }
             wave_sync_lds();
+            STAMP(1);
             // lane l owns merged events [d0, d1); each lane searches the END of its chunk
             const int epl = (T + 63) >> 6;  // <= EPL (= 6): the 4-bit histogram fields hold up to 15
             const int d0 = min(lane * epl, T), d1 = min(d0 + epl, T);
@@ -1143,6 +1157,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
             if (lane == 0) i0 = 0;
             const int iend = __builtin_amdgcn_readlane(i1, 63);
             const int j0 = d0 - i0, j1 = d1 - i1;
+            STAMP(2);
 
             // pass 1: 4-bit-per-category histogram of this lane's chunk (at most 8 points per side)
             uint64_t hA[NH], hB[NH];
@@ -1160,6 +1175,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
 #pragma unroll
                 for (int k = 0; k < NH; ++k) hB[k] += ((ct >> 4) == k) ? (1ull << ((ct & 15) * 4)) : 0ull;
             }
+            STAMP(3);
             // widen to 16-bit fields and exclusive-scan across the wavefront
 #pragma unroll
             for (int k = 0; k < NW; ++k) {
@@ -1173,7 +1189,9 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
             }
             totA = 1 + ia + i0;
             totB = 1 + ib + j0;
+            STAMP(4);
             load_state();
+            STAMP(5);
 
             // pass 2: sequential sweep of this lane's events.  Branch-free: both list heads stay in registers and the one
             // that was consumed is refilled with a single (address-selected) LDS read.  The packed counts exA/exB stay
@@ -1259,6 +1277,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
                     Fp = F;
                 }
             }
+            STAMP(6);
             // stitch lane chunks: (F_first - F_last_of_previous_lane) * H_before_my_first_event
             double prevF = shfl_up_f64(Fp, 1), prevH = shfl_up_f64(Hp, 1);
             if (lane == 0) { prevF = F_carry; prevH = H_carry; }
@@ -1281,7 +1300,12 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
             if (anyzero) atomicOr(&args.st->flags, ST_ZERO_NORM);
             args.out[p] = acc;
         }
+        STAMP(7);
     }
+#ifdef LCHD_SWEEP_STAMPS
+    if (lane == 0)
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_sweep_stamps[k], stamp_acc[k]);
+#endif
 }
 
 constexpr int kWideMaxCat = 256;
@@ -1664,6 +1688,18 @@ __global__ void k_fill_sqrt_tables(double* sqrt_tab, double* rsqrt_tab) {
         rsqrt_tab[k] = 1.0 / r;
     }
 }
+#ifdef LCHD_SWEEP_STAMPS
+}  // namespace lchd
+extern "C" int lchd_debug_sweep_stamps(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(lchd::g_sweep_stamps), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(lchd::g_sweep_stamps), z, sizeof z) != hipSuccess) return 1;
+    }
+    return 0;
+}
+namespace lchd {
+#endif
 void launch_fill_sqrt_tables(hipStream_t s, double* sqrt_tab, double* rsqrt_tab) {
     k_fill_sqrt_tables<<<256, 256, 0, s>>>(sqrt_tab, rsqrt_tab);
 }
