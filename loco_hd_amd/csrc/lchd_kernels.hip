@@ -80,6 +80,34 @@ __device__ __forceinline__ uint64_t wave_incl_scan_fields(uint64_t x) {
     const uint32_t lo = wave_incl_scan_u32((uint32_t)x), hi = wave_incl_scan_u32((uint32_t)(x >> 32));
     return ((uint64_t)hi << 32) | lo;
 }
+// f64 across lanes without the LDS crossbar: DPP moves of the two halves (gfx9 DPP has whole-wave shifts)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov_f64_or_zero(double v) {  // lanes without a source (or masked rows) read +0.0
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// value of lane - 1 (lane 0 keeps its own value): wave_shr:1
+__device__ __forceinline__ double wave_shr1_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// sum over the 64 lanes, returned wave-uniform (same shape as wave_incl_scan_u32; lane 63 ends up with the total)
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    v += dpp_mov_f64_or_zero<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_mov_f64_or_zero<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_mov_f64_or_zero<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_mov_f64_or_zero<0x118, 0xf>(v);  // row_shr:8
+    v += dpp_mov_f64_or_zero<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_mov_f64_or_zero<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {  // l wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
     const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, l), hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
     return ((uint64_t)hi << 32) | lo;
@@ -1121,30 +1149,30 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
             const int nAt = min(TILE, mA - ia), nBt = min(TILE, mB - ib);
             STAMP(0);
             wave_sync_lds();  // previous tile fully consumed
-            {   // stage the tile: all global loads of a list are issued before the first LDS write (one latency, not six)
-                uint64_t rk[EPL];
-                uint8_t rc[EPL];
+            {   // stage the tile: the global loads of BOTH lists are issued before the first LDS write (one memory latency per tile)
+                uint64_t rkA[EPL], rkB[EPL];
+                uint8_t rcA[EPL], rcB[EPL];
 #pragma unroll
                 for (int u = 0; u < EPL; ++u) {
                     const int t = lane + 64 * u;
-                    rk[u] = t < nAt ? kA[1 + ia + t] : 0ull;
-                    rc[u] = t < nAt ? tA[1 + ia + t] : (uint8_t)0;
+                    rkA[u] = t < nAt ? kA[1 + ia + t] : 0ull;
+                    rcA[u] = t < nAt ? tA[1 + ia + t] : (uint8_t)0;
                 }
 #pragma unroll
                 for (int u = 0; u < EPL; ++u) {
                     const int t = lane + 64 * u;
-                    if (t < nAt) { sA[t] = rk[u]; cA[t] = rc[u]; }
+                    rkB[u] = t < nBt ? kB[1 + ib + t] : 0ull;
+                    rcB[u] = t < nBt ? tB[1 + ib + t] : (uint8_t)0;
                 }
 #pragma unroll
                 for (int u = 0; u < EPL; ++u) {
                     const int t = lane + 64 * u;
-                    rk[u] = t < nBt ? kB[1 + ib + t] : 0ull;
-                    rc[u] = t < nBt ? tB[1 + ib + t] : (uint8_t)0;
+                    if (t < nAt) { sA[t] = rkA[u]; cA[t] = rcA[u]; }
                 }
 #pragma unroll
                 for (int u = 0; u < EPL; ++u) {
                     const int t = lane + 64 * u;
-                    if (t < nBt) { sB[t] = rk[u]; cB[t] = rc[u]; }
+                    if (t < nBt) { sB[t] = rkB[u]; cB[t] = rcB[u]; }
                 }
             }
             wave_sync_lds();
@@ -1279,19 +1307,18 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
             }
             STAMP(6);
             // stitch lane chunks: (F_first - F_last_of_previous_lane) * H_before_my_first_event
-            double prevF = shfl_up_f64(Fp, 1), prevH = shfl_up_f64(Hp, 1);
+            double prevF = wave_shr1_f64(Fp), prevH = wave_shr1_f64(Hp);  // DPP, no LDS round trip
             if (lane == 0) { prevF = F_carry; prevH = H_carry; }
             if (d0 < d1) local += (firstF - prevF) * prevH;
             acc += local;
-            const int last = (T - 1) / epl;
-            F_carry = shfl_f64(Fp, last);
-            H_carry = shfl_f64(Hp, last);
+            const int last = (T - 1) / epl;  // wave-uniform
+            F_carry = readlane_f64(Fp, last);
+            H_carry = readlane_f64(Hp, last);
             ia += iend;
             ib += T - iend;
         }
-        // wave64 butterfly reduction + the last interval to +inf (:165-171,204-210,212-221)
-#pragma unroll
-        for (int m = 32; m > 0; m >>= 1) acc += shfl_xor_f64(acc, m);
+        // wave64 reduction + the last interval to +inf (:165-171,204-210,212-221)
+        acc = wave_sum_f64(acc);
         const double Finf = cfgp->wf_finf[wfi];
         acc += (Finf - F_carry) * H_carry;
         const unsigned long long anybad = __ballot(bad_cat), anyzero = __ballot(zero_norm);
@@ -1554,19 +1581,18 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
                 Fp = F;
             }
             // stitch lane chunks: (F_first - F_last_of_previous_lane) * H_before_my_first_event
-            double prevF = shfl_up_f64(Fp, 1), prevH = shfl_up_f64(Hp, 1);
+            double prevF = wave_shr1_f64(Fp), prevH = wave_shr1_f64(Hp);  // DPP, no LDS round trip
             if (lane == 0) { prevF = F_carry; prevH = H_carry; }
             if (d0 < d1) local += (firstF - prevF) * prevH;
             acc += local;
-            const int last = (T - 1) / epl;
-            F_carry = shfl_f64(Fp, last);
-            H_carry = shfl_f64(Hp, last);
+            const int last = (T - 1) / epl;  // wave-uniform
+            F_carry = readlane_f64(Fp, last);
+            H_carry = readlane_f64(Hp, last);
             ia += iend;
             ib += T - iend;
         }
-        // wave64 butterfly reduction + the last interval to +inf (:165-171,204-210,212-221)
-#pragma unroll
-        for (int m = 32; m > 0; m >>= 1) acc += shfl_xor_f64(acc, m);
+        // wave64 reduction + the last interval to +inf (:165-171,204-210,212-221)
+        acc = wave_sum_f64(acc);
         const double Finf = cfgp->wf_finf[wfi];
         acc += (Finf - F_carry) * H_carry;
         const unsigned long long anybad = __ballot(bad_cat), anyzero = __ballot(zero_norm);
