@@ -599,11 +599,13 @@ static int prims_enqueue(lchd_ctx* c) {
         Arena dry(nullptr, 0, true);
         carve_side(dry, a->n, ga.n_cells, max_env_a, cap, sa);
         carve_side(dry, b->n, gb.n_cells, max_env_b, cap, sb);
+        (void)dry.take<int4>((size_t)n_pairs);
         if (int rc = ensure_ws(c, dry.off + 4096)) return rc;
     }
     Arena ar(c->ws, c->ws_cap, false);
     carve_side(ar, a->n, ga.n_cells, max_env_a, cap, sa);
     carve_side(ar, b->n, gb.n_cells, max_env_b, cap, sb);
+    int4* pair_meta = ar.take<int4>((size_t)n_pairs);
     sa.env.cdf_keys = sb.env.cdf_keys = (c->h_cfg.n_wf == 1 && !getenv("LCHD_NO_CDF_KEYS")) ? 1 : 0;
 
     auto grid_view = [](const GridPlan& g, const SideBufs& s) {
@@ -648,6 +650,7 @@ static int prims_enqueue(lchd_ctx* c) {
     sw.st = c->d_status;
     sw.sqrt_tab = c->d_tabs;
     sw.rsqrt_tab = c->d_tabs + 65536;
+    sw.meta = pair_meta;
     launch_sweep(s, c->h_cfg.n_categories, c->hellinger2, c->unit_weights, c->wf_pow, sw);
     mark(c, 4);
     if (a->ev_used) { HIP_TRY(hipEventRecord(a->ev_used, s)); a->used_valid = true; }
@@ -948,7 +951,7 @@ extern "C" int lchd_from_primitives(lchd_ctx* c, const lchd_config* cfg, const d
 // Shared tail of from_anchors / from_dmxs / from_coords: environments are already sorted in `ea`/`eb`
 // (one per row), pair p = (row p, row p).
 static int sweep_rows(lchd_ctx* c, const EnvStore& ea, const EnvStore& eb, const int32_t* d_wf, int64_t rows, double* d_out,
-                      Driver drv) {
+                      int4* d_meta, Driver drv) {
     SweepArgs sw{};
     sw.cfg = c->d_cfg;
     sw.env_a = ea;
@@ -959,6 +962,7 @@ static int sweep_rows(lchd_ctx* c, const EnvStore& ea, const EnvStore& eb, const
     sw.st = c->d_status;
     sw.sqrt_tab = c->d_tabs;
     sw.rsqrt_tab = c->d_tabs + 65536;
+    sw.meta = d_meta;
     launch_sweep(c->stream, c->h_cfg.n_categories, c->hellinger2, c->unit_weights, c->wf_pow, sw);
     mark(c, 4);
     HIP_TRY(hipGetLastError());
@@ -989,6 +993,7 @@ static int dense_driver(lchd_ctx* c, const lchd_config* cfg, const int32_t* seq_
         EnvStore ea{}, eb{};
         double *d_ma = nullptr, *d_mb = nullptr, *d_out = nullptr;
         int32_t* d_wf = nullptr;
+        int4* d_meta = nullptr;
         for (int dry = 1; dry >= 0; --dry) {
             Arena ar(dry ? nullptr : c->ws, dry ? 0 : c->ws_cap, dry != 0);
             ea.key = ar.take<uint64_t>((size_t)rows * cap_a);
@@ -1002,6 +1007,7 @@ static int dense_driver(lchd_ctx* c, const lchd_config* cfg, const int32_t* seq_
             ea.cdf_keys = eb.cdf_keys = (c->h_cfg.n_wf == 1 && !getenv("LCHD_NO_CDF_KEYS")) ? 1 : 0;
             d_out = ar.take<double>((size_t)rows);
             d_wf = ar.take<int32_t>((size_t)rows);
+            d_meta = ar.take<int4>((size_t)rows);
             if (dmx_a) {
                 d_ma = ar.take<double>((size_t)rows * cols_a);
                 d_mb = ar.take<double>((size_t)rows * cols_b);
@@ -1020,7 +1026,7 @@ static int dense_driver(lchd_ctx* c, const lchd_config* cfg, const int32_t* seq_
             !launch_env_rows(s, cap_b, c->d_cfg, b->view(), d_mb, cols_b, rows, cols_b, eb, c->d_status))
             return fail(LCHD_EUNSUPPORTED, "no dense environment kernel for this row length");
         mark(c, 3);
-        if (int rc2 = sweep_rows(c, ea, eb, wf_index ? d_wf : nullptr, rows, d_out, DRV_DMXS)) return rc2;
+        if (int rc2 = sweep_rows(c, ea, eb, wf_index ? d_wf : nullptr, rows, d_out, d_meta, DRV_DMXS)) return rc2;
         HIP_TRY(hipMemcpy(out, d_out, sizeof(double) * rows, hipMemcpyDeviceToHost));
         return LCHD_OK;
     };
@@ -1073,6 +1079,7 @@ extern "C" int lchd_from_anchors(lchd_ctx* c, const lchd_config* cfg, const int3
     }
     EnvStore ea{}, eb{};
     double* d_out = nullptr;
+    int4* d_meta = nullptr;
     for (int dry = 1; dry >= 0; --dry) {
         Arena ar(dry ? nullptr : c->ws, dry ? 0 : c->ws_cap, dry != 0);
         ea.key = ar.take<uint64_t>((size_t)len_seq_a);
@@ -1084,6 +1091,7 @@ extern "C" int lchd_from_anchors(lchd_ctx* c, const lchd_config* cfg, const int3
         eb.len = ar.take<int32_t>(1);
         eb.stride = len_seq_b;
         d_out = ar.take<double>(1);
+        d_meta = ar.take<int4>(1);
         if (dry) if (int rc = ensure_ws(c, ar.off + 4096)) return rc;
     }
     hipStream_t s = c->stream;
@@ -1109,7 +1117,7 @@ extern "C" int lchd_from_anchors(lchd_ctx* c, const lchd_config* cfg, const int3
     }
     mark(c, 2);
     mark(c, 3);
-    int rc = sweep_rows(c, ea, eb, d_wf, 1, d_out, DRV_ANCHORS);
+    int rc = sweep_rows(c, ea, eb, d_wf, 1, d_out, d_meta, DRV_ANCHORS);
     if (!rc) {
         hipError_t e = hipMemcpy(out, d_out, sizeof(double), hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(LCHD_EDEVICE, "HIP error %d in D2H score", (int)e);

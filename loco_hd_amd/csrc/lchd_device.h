@@ -109,6 +109,7 @@ struct SweepArgs {
     DeviceStatus* st;
     const double* sqrt_tab;   // [65536] sqrt(k), context-owned
     const double* rsqrt_tab;  // [65536] 1/sqrt(k)
+    int4* meta;               // [P] workspace: per-pair records written by k_pair_meta, read by the sweep kernels
 };
 void launch_sweep(hipStream_t s, int n_categories, bool hellinger2, bool unit_weights, bool wf_pow, const SweepArgs& a);
 // trajectory frames: replicate the template's labels / unpack [frames][atoms][3] into SoA + bounding box keys

@@ -971,23 +971,21 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
 #ifdef LCHD_SWEEP_STAMPS
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
 #endif
-    for (int64_t p = (int64_t)blockIdx.x * WPB + wv; p < args.n_pairs; p += (int64_t)gridDim.x * WPB) {
-        int64_t ea = p, eb = p;
-        if (args.anchors) {
-            const int64_t ia_ = args.anchors[2 * p], ib_ = args.anchors[2 * p + 1];
-            // out-of-range anchors were flagged by k_mark_anchors; do not touch memory for them
-            if (ia_ < 0 || ib_ < 0 || ia_ >= args.n_slot_a || ib_ >= args.n_slot_b) {
-                if (lane == 0) args.out[p] = nan("");
-                continue;
-            }
-            ea = args.slot_a[ia_];
-            eb = args.slot_b[ib_];
-        }
-        const int nA = args.env_a.len[ea], nB = args.env_b.len[eb];
-        if (nA <= 0 || nB <= 0) {  // overflow / empty environment: already flagged by K1
+    // One 16-byte record per pair (k_pair_meta) replaces the dependent chain anchors -> slot -> len -> first category; the
+    // record of the wave's NEXT pair is requested before the current pair is processed.
+    const int64_t pstride = (int64_t)gridDim.x * WPB;
+    int64_t p = (int64_t)blockIdx.x * WPB + wv;
+    int4 m = args.meta[p < args.n_pairs ? p : 0], mn = m;
+    for (; p < args.n_pairs; p += pstride, m = mn) {
+        mn = args.meta[p + pstride < args.n_pairs ? p + pstride : p];
+        const int mz = __builtin_amdgcn_readfirstlane(m.z), mw = __builtin_amdgcn_readfirstlane(m.w);
+        const int nA = mz & 0xFFFFFF, nB = mw & 0xFFFFFF;
+        if (nA <= 0 || nB <= 0) {  // anchor out of range (flagged by k_mark_anchors) or overflow / empty environment (flagged by K1)
             if (lane == 0) args.out[p] = nan("");
             continue;
         }
+        const int64_t ea = __builtin_amdgcn_readfirstlane(m.x), eb = __builtin_amdgcn_readfirstlane(m.y);
+        const int c0a = (mz >> 24) & 255, c0b = (mw >> 24) & 255;  // categories of the two anchors
         const uint64_t* __restrict__ kA = args.env_a.key + ea * args.env_a.stride;
         const uint64_t* __restrict__ kB = args.env_b.key + eb * args.env_b.stride;
         const uint8_t* __restrict__ tA = args.env_a.cat + ea * args.env_a.stride;
@@ -1016,7 +1014,6 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
         // wave-uniform packed integer category counts (16-bit fields), seeded with the two anchors (:82-84)
         uint64_t cntA[NW], cntB[NW];
         {
-            const int c0a = tA[0], c0b = tB[0];
             if (c0a >= C || c0b >= C) bad_cat = true;
 #pragma unroll
             for (int k = 0; k < NW; ++k) {
@@ -1135,7 +1132,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
         double H_carry;
         if constexpr (H2) {
             // only the two anchors: both PMFs are point masses => H = 0 if they share the category, else 1 (exactly)
-            H_carry = (tA[0] == tB[0]) ? 0.0 : 1.0;
+            H_carry = (c0a == c0b) ? 0.0 : 1.0;
         } else {
             load_state();
             H_carry = bad_cat ? 0.0 : distance();
@@ -1381,23 +1378,21 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
     auto sqrt_cnt = [&](int k) -> double { if constexpr (LDSTAB) return t_sqrt[k]; else return g_sqrt[k]; };
     auto rsqrt_cnt = [&](int k) -> double { if constexpr (LDSTAB) return t_rsqrt[k]; else return g_rsqrt[k]; };
 
-    for (int64_t p = (int64_t)blockIdx.x * WPB + wv; p < args.n_pairs; p += (int64_t)gridDim.x * WPB) {
-        int64_t ea = p, eb = p;
-        if (args.anchors) {
-            const int64_t ia_ = args.anchors[2 * p], ib_ = args.anchors[2 * p + 1];
-            // out-of-range anchors were flagged by k_mark_anchors; do not touch memory for them
-            if (ia_ < 0 || ib_ < 0 || ia_ >= args.n_slot_a || ib_ >= args.n_slot_b) {
-                if (lane == 0) args.out[p] = nan("");
-                continue;
-            }
-            ea = args.slot_a[ia_];
-            eb = args.slot_b[ib_];
-        }
-        const int nA = args.env_a.len[ea], nB = args.env_b.len[eb];
-        if (nA <= 0 || nB <= 0) {  // overflow / empty environment: already flagged by K1
+    // One 16-byte record per pair (k_pair_meta) replaces the dependent chain anchors -> slot -> len -> first category; the
+    // record of the wave's NEXT pair is requested before the current pair is processed.
+    const int64_t pstride = (int64_t)gridDim.x * WPB;
+    int64_t p = (int64_t)blockIdx.x * WPB + wv;
+    int4 m = args.meta[p < args.n_pairs ? p : 0], mn = m;
+    for (; p < args.n_pairs; p += pstride, m = mn) {
+        mn = args.meta[p + pstride < args.n_pairs ? p + pstride : p];
+        const int mz = __builtin_amdgcn_readfirstlane(m.z), mw = __builtin_amdgcn_readfirstlane(m.w);
+        const int nA = mz & 0xFFFFFF, nB = mw & 0xFFFFFF;
+        if (nA <= 0 || nB <= 0) {  // anchor out of range (flagged by k_mark_anchors) or overflow / empty environment (flagged by K1)
             if (lane == 0) args.out[p] = nan("");
             continue;
         }
+        const int64_t ea = __builtin_amdgcn_readfirstlane(m.x), eb = __builtin_amdgcn_readfirstlane(m.y);
+        const int c0a = (mz >> 24) & 255, c0b = (mw >> 24) & 255;  // categories of the two anchors
         const uint64_t* __restrict__ kA = args.env_a.key + ea * args.env_a.stride;
         const uint64_t* __restrict__ kB = args.env_b.key + eb * args.env_b.stride;
         const uint8_t* __restrict__ tA = args.env_a.cat + ea * args.env_a.stride;
@@ -1467,7 +1462,6 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
         };
 
         // seed with the two anchors (:82-84): carry row and every lane's column
-        const int c0a = tA[0], c0b = tB[0];
         if (c0a >= C || c0b >= C) bad_cat = true;
         wave_sync_lds();
         for (int c = lane; c < C; c += 64) carry[c] = (c == c0a ? 1u : 0u) | (c == c0b ? 0x10000u : 0u);
@@ -1646,8 +1640,39 @@ static void launch_sweep_wide(hipStream_t s, int n_cat, int64_t n_pairs, int fmo
     }
 }
 
+// One record per anchor pair for the sweep kernels: {environment slot A, slot B, n_A | category of anchor A << 24,
+// n_B | category of anchor B << 24}; n = 0 marks a pair the sweep must answer with NaN (anchor index out of range -- already
+// flagged by k_mark_anchors -- or an environment that overflowed / is empty -- flagged by K1).
+__global__ void k_pair_meta(SweepArgs args) {
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < args.n_pairs; p += (int64_t)gridDim.x * blockDim.x) {
+        int64_t ea = p, eb = p;
+        bool ok = true;
+        if (args.anchors) {
+            const int64_t ia_ = args.anchors[2 * p], ib_ = args.anchors[2 * p + 1];
+            ok = !(ia_ < 0 || ib_ < 0 || ia_ >= args.n_slot_a || ib_ >= args.n_slot_b);
+            if (ok) { ea = args.slot_a[ia_]; eb = args.slot_b[ib_]; }
+        }
+        int nA = 0, nB = 0, c0a = 0, c0b = 0;
+        if (ok) {
+            nA = args.env_a.len[ea];
+            nB = args.env_b.len[eb];
+            if (nA > 0 && nB > 0) {
+                c0a = args.env_a.cat[ea * args.env_a.stride];
+                c0b = args.env_b.cat[eb * args.env_b.stride];
+            } else {
+                nA = nB = 0;
+            }
+        }
+        args.meta[p] = make_int4((int)ea, (int)eb, nA | (c0a << 24), nB | (c0b << 24));
+    }
+}
+
 void launch_sweep(hipStream_t s, int n_categories, bool hellinger2, bool unit_weights, bool wf_pow, const SweepArgs& a) {
     if (a.n_pairs <= 0) return;
+    {
+        const int64_t nb = (a.n_pairs + 255) / 256;
+        k_pair_meta<<<(unsigned)(nb < 4096 ? nb : 4096), 256, 0, s>>>(a);
+    }
     {
         bool wide = n_categories > 32;
         if (const char* f = getenv("LCHD_FORCE_WIDE")) wide = wide || atoi(f) != 0;  // test hook
