@@ -973,26 +973,43 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
 #endif
     // One 16-byte record per pair (k_pair_meta) replaces the dependent chain anchors -> slot -> len -> first category; the
     // record of the wave's NEXT pair is requested before the current pair is processed.
+    // configuration words the loop needs: read once (the compiler must assume the status atomics may alias *cfgp)
+    const int n_wf = cfgp->n_wf;
+    const double* __restrict__ finf_tab = cfgp->wf_finf;
+    const double Finf0 = finf_tab[0];
     const int64_t pstride = (int64_t)gridDim.x * WPB;
     int64_t p = (int64_t)blockIdx.x * WPB + wv;
-    int4 m = args.meta[p < args.n_pairs ? p : 0], mn = m;
-    for (; p < args.n_pairs; p += pstride, m = mn) {
-        mn = args.meta[p + pstride < args.n_pairs ? p + pstride : p];
-        const int mz = __builtin_amdgcn_readfirstlane(m.z), mw = __builtin_amdgcn_readfirstlane(m.w);
+    // the record lives in four scalar registers; the next one is moved there as soon as its (early) load has returned, so the
+    // loop's back edge never waits on vector memory (in particular not on the score store of the pair just finished)
+    int mx, my, mz, mw;
+    {
+        const int4 m0 = args.meta[p < args.n_pairs ? p : 0];
+        mx = __builtin_amdgcn_readfirstlane(m0.x); my = __builtin_amdgcn_readfirstlane(m0.y);
+        mz = __builtin_amdgcn_readfirstlane(m0.z); mw = __builtin_amdgcn_readfirstlane(m0.w);
+    }
+    int nx = mx, ny = my, nz = mz, nw = mw;
+    for (; p < args.n_pairs; p += pstride, mx = nx, my = ny, mz = nz, mw = nw) {
+        const int4 mn = args.meta[p + pstride < args.n_pairs ? p + pstride : p];
+        auto take_next = [&]() {
+            nx = __builtin_amdgcn_readfirstlane(mn.x); ny = __builtin_amdgcn_readfirstlane(mn.y);
+            nz = __builtin_amdgcn_readfirstlane(mn.z); nw = __builtin_amdgcn_readfirstlane(mn.w);
+        };
         const int nA = mz & 0xFFFFFF, nB = mw & 0xFFFFFF;
         if (nA <= 0 || nB <= 0) {  // anchor out of range (flagged by k_mark_anchors) or overflow / empty environment (flagged by K1)
             if (lane == 0) args.out[p] = nan("");
+            take_next();
             continue;
         }
-        const int64_t ea = __builtin_amdgcn_readfirstlane(m.x), eb = __builtin_amdgcn_readfirstlane(m.y);
+        const int64_t ea = mx, eb = my;
         const int c0a = (mz >> 24) & 255, c0b = (mw >> 24) & 255;  // categories of the two anchors
         const uint64_t* __restrict__ kA = args.env_a.key + ea * args.env_a.stride;
         const uint64_t* __restrict__ kB = args.env_b.key + eb * args.env_b.stride;
         const uint8_t* __restrict__ tA = args.env_a.cat + ea * args.env_a.stride;
         const uint8_t* __restrict__ tB = args.env_b.cat + eb * args.env_b.stride;
         const int wfi = args.wf_index ? args.wf_index[p] : 0;
-        if (wfi < 0 || wfi >= cfgp->n_wf) {
+        if (args.wf_index && (wfi < 0 || wfi >= n_wf)) {
             if (lane == 0) { atomicOr(&args.st->flags, ST_BAD_WF); args.out[p] = nan(""); }
+            take_next();
             continue;
         }
         constexpr bool WFANY = (FMODE == F_ANY);
@@ -1002,6 +1019,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
             wf = wf_load(wfe, cfgp->wf_params + wfe.offset);
             if (kA[0] != 0ull || kB[0] != 0ull) {  // src/locohd.rs:74-77 (F_KEY: checked by the environment kernels)
                 if (lane == 0) { atomicOr(&args.st->flags, ST_FIRST_NOT_ZERO); args.out[p] = nan(""); }
+                take_next();
                 continue;
             }
         }
@@ -1146,7 +1164,8 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
             const int nAt = min(TILE, mA - ia), nBt = min(TILE, mB - ib);
             STAMP(0);
             wave_sync_lds();  // previous tile fully consumed
-            {   // stage the tile: the global loads of BOTH lists are issued before the first LDS write (one memory latency per tile)
+            // stage the tile: the global loads of BOTH lists are issued before the first LDS write (one memory latency per tile)
+            {
                 uint64_t rkA[EPL], rkB[EPL];
                 uint8_t rcA[EPL], rcB[EPL];
 #pragma unroll
@@ -1314,9 +1333,10 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
             ia += iend;
             ib += T - iend;
         }
+        take_next();  // its load was issued before this pair's tile loads, which have all been waited for
         // wave64 reduction + the last interval to +inf (:165-171,204-210,212-221)
         acc = wave_sum_f64(acc);
-        const double Finf = cfgp->wf_finf[wfi];
+        const double Finf = args.wf_index ? finf_tab[wfi] : Finf0;
         acc += (Finf - F_carry) * H_carry;
         const unsigned long long anybad = __ballot(bad_cat), anyzero = __ballot(zero_norm);
         if (lane == 0) {
@@ -1380,26 +1400,43 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
 
     // One 16-byte record per pair (k_pair_meta) replaces the dependent chain anchors -> slot -> len -> first category; the
     // record of the wave's NEXT pair is requested before the current pair is processed.
+    // configuration words the loop needs: read once (the compiler must assume the status atomics may alias *cfgp)
+    const int n_wf = cfgp->n_wf;
+    const double* __restrict__ finf_tab = cfgp->wf_finf;
+    const double Finf0 = finf_tab[0];
     const int64_t pstride = (int64_t)gridDim.x * WPB;
     int64_t p = (int64_t)blockIdx.x * WPB + wv;
-    int4 m = args.meta[p < args.n_pairs ? p : 0], mn = m;
-    for (; p < args.n_pairs; p += pstride, m = mn) {
-        mn = args.meta[p + pstride < args.n_pairs ? p + pstride : p];
-        const int mz = __builtin_amdgcn_readfirstlane(m.z), mw = __builtin_amdgcn_readfirstlane(m.w);
+    // the record lives in four scalar registers; the next one is moved there as soon as its (early) load has returned, so the
+    // loop's back edge never waits on vector memory (in particular not on the score store of the pair just finished)
+    int mx, my, mz, mw;
+    {
+        const int4 m0 = args.meta[p < args.n_pairs ? p : 0];
+        mx = __builtin_amdgcn_readfirstlane(m0.x); my = __builtin_amdgcn_readfirstlane(m0.y);
+        mz = __builtin_amdgcn_readfirstlane(m0.z); mw = __builtin_amdgcn_readfirstlane(m0.w);
+    }
+    int nx = mx, ny = my, nz = mz, nw = mw;
+    for (; p < args.n_pairs; p += pstride, mx = nx, my = ny, mz = nz, mw = nw) {
+        const int4 mn = args.meta[p + pstride < args.n_pairs ? p + pstride : p];
+        auto take_next = [&]() {
+            nx = __builtin_amdgcn_readfirstlane(mn.x); ny = __builtin_amdgcn_readfirstlane(mn.y);
+            nz = __builtin_amdgcn_readfirstlane(mn.z); nw = __builtin_amdgcn_readfirstlane(mn.w);
+        };
         const int nA = mz & 0xFFFFFF, nB = mw & 0xFFFFFF;
         if (nA <= 0 || nB <= 0) {  // anchor out of range (flagged by k_mark_anchors) or overflow / empty environment (flagged by K1)
             if (lane == 0) args.out[p] = nan("");
+            take_next();
             continue;
         }
-        const int64_t ea = __builtin_amdgcn_readfirstlane(m.x), eb = __builtin_amdgcn_readfirstlane(m.y);
+        const int64_t ea = mx, eb = my;
         const int c0a = (mz >> 24) & 255, c0b = (mw >> 24) & 255;  // categories of the two anchors
         const uint64_t* __restrict__ kA = args.env_a.key + ea * args.env_a.stride;
         const uint64_t* __restrict__ kB = args.env_b.key + eb * args.env_b.stride;
         const uint8_t* __restrict__ tA = args.env_a.cat + ea * args.env_a.stride;
         const uint8_t* __restrict__ tB = args.env_b.cat + eb * args.env_b.stride;
         const int wfi = args.wf_index ? args.wf_index[p] : 0;
-        if (wfi < 0 || wfi >= cfgp->n_wf) {
+        if (args.wf_index && (wfi < 0 || wfi >= n_wf)) {
             if (lane == 0) { atomicOr(&args.st->flags, ST_BAD_WF); args.out[p] = nan(""); }
+            take_next();
             continue;
         }
         constexpr bool WFANY = (FMODE == F_ANY);
@@ -1409,6 +1446,7 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
             wf = wf_load(wfe, cfgp->wf_params + wfe.offset);
             if (kA[0] != 0ull || kB[0] != 0ull) {  // src/locohd.rs:74-77 (F_KEY: checked by the environment kernels)
                 if (lane == 0) { atomicOr(&args.st->flags, ST_FIRST_NOT_ZERO); args.out[p] = nan(""); }
+                take_next();
                 continue;
             }
         }
@@ -1585,9 +1623,10 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
             ia += iend;
             ib += T - iend;
         }
+        take_next();  // its load was issued before this pair's tile loads, which have all been waited for
         // wave64 reduction + the last interval to +inf (:165-171,204-210,212-221)
         acc = wave_sum_f64(acc);
-        const double Finf = cfgp->wf_finf[wfi];
+        const double Finf = args.wf_index ? finf_tab[wfi] : Finf0;
         acc += (Finf - F_carry) * H_carry;
         const unsigned long long anybad = __ballot(bad_cat), anyzero = __ballot(zero_norm);
         if (lane == 0) {
