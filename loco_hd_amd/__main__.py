@@ -41,28 +41,32 @@ def pra_template_list_to_idx_dict(pra_templates: Sequence[PrimitiveAtomTemplate]
     return out
 
 
+# (short flag, long flag, type, default, required, help) -- the flag names, types and defaults of __main__.py:49-134
+_DEFAULT_TPRA = '{"accept_same": false}'
+_DEFAULT_WFA = '{"function_name": "uniform", "parameters": [3.0, 10.0]}'
+_FLAGS = (
+    ("-s1", "--structure1", str, None, True, "first PDB file"),
+    ("-s2", "--structure2", str, None, True, "second PDB file"),
+    ("-pts", "--primitive_typing_scheme", str, None, True, "typing scheme (JSON: primitive type -> [[residue regex, atom regex, count]])"),
+    ("-apf", "--anchor_pairing_file", Path, None, True,
+     "text file with ';'-separated anchor pairs, each 'chain/resnum-RESNAME/atom,atom:chain/resnum-RESNAME/atom,...' "
+     "(left side: primitive atom of structure 1, right side: of structure 2); line breaks are dropped, blanks are not"),
+    ("-mn", "--model_number", int, 0, False, "model of both PDB files to use"),
+    ("-nt", "--number_of_threads", int, None, False, "kept for compatibility: scoring runs on the GPU, there is no CPU thread pool"),
+    ("-udc", "--upper_distance_cutoff", float, 10.0, False, "environment radius in angstrom"),
+    ("-tpra", "--tag_pairing_rule_args", str, _DEFAULT_TPRA, False, f"JSON dict for TagPairingRule (default {_DEFAULT_TPRA})"),
+    ("-wfa", "--weight_function_args", str, _DEFAULT_WFA, False, f"JSON dict for WeightFunction (default {_DEFAULT_WFA})"),
+)
+
+
 def parse_cli_args(argv: Optional[Sequence[str]] = None) -> Namespace:
-    p = ArgumentParser(prog="python -m loco_hd_amd")
-    p.add_argument("-s1", "--structure1", type=str, required=True, help="Path to the first pdb file to be compared.")
-    p.add_argument("-s2", "--structure2", type=str, required=True, help="Path to the second pdb file to be compared.")
-    p.add_argument("-pts", "--primitive_typing_scheme", type=str, required=True, help="Path to the primitive typing scheme json file.")
-    p.add_argument("-apf", "--anchor_pairing_file", type=Path, required=True,
-                   help="Text file of anchor pairs such as A/123-TYR/CG,CZ:B/45-ALA/CB (chain / residue / atom set of the "
-                        "primitive atom in structure 1 : the same for structure 2), separated by semicolons; newlines are ignored.")
-    p.add_argument("-mn", "--model_number", type=int, default=0, help="The model number in the pdb files to be compared (0 by default).")
-    p.add_argument("-nt", "--number_of_threads", type=int, default=None,
-                   help="Accepted for compatibility; the scoring runs on the GPU, not on a CPU thread pool.")
-    p.add_argument("-udc", "--upper_distance_cutoff", type=float, default=10.0, help="Upper distance cutoff of the environments.")
-    tpra_default = '{"accept_same": false}'
-    p.add_argument("-tpra", "--tag_pairing_rule_args", type=str, default=tpra_default,
-                   help=f"JSON dictionary that initializes the TagPairingRule ('{tpra_default}' by default).")
-    wfa_default = '{"function_name": "uniform", "parameters": [3.0, 10.0]}'
-    p.add_argument("-wfa", "--weight_function_args", type=str, default=wfa_default,
-                   help=f"JSON dictionary that initializes the WeightFunction ('{wfa_default}' by default).")
-    args = p.parse_args(argv)
-    args.tag_pairing_rule_args = json.loads(args.tag_pairing_rule_args)
-    args.weight_function_args = json.loads(args.weight_function_args)
-    return args
+    parser = ArgumentParser(prog="python -m loco_hd_amd", description="LoCoHD scores of anchor pairs of two PDB structures (MI355X)")
+    for short, long_, kind, default, required, text in _FLAGS:
+        parser.add_argument(short, long_, type=kind, default=default, required=required, help=text)
+    ns = parser.parse_args(argv)
+    for key in ("tag_pairing_rule_args", "weight_function_args"):
+        setattr(ns, key, json.loads(getattr(ns, key)))
+    return ns
 
 
 def run(args: Namespace) -> List[str]:

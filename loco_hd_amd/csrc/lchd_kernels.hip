@@ -363,6 +363,12 @@ __device__ __forceinline__ bool tag_pair_accepted(const DevConfig& cfg, int32_t 
 //   distance        sqrt(sum(diff^2)), same summation order as utils.rs:1-8                 (:537)
 //   sort            ascending distance                                                       (:541)
 // ------------------------------------------------------------------------------------------------
+#ifdef LCHD_SWEEP_STAMPS
+__device__ unsigned long long g_env_stamps[8];
+#define ESTAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && (blockIdx.x & 127) == 0) atomicAdd(&g_env_stamps[i], t_ - estamp_last); estamp_last = t_; } while (0)
+#else
+#define ESTAMP(i) do { } while (0)
+#endif
 template <int NT>
 __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ cfgp, CloudView c, GridView g,
                                                   const uint32_t* __restrict__ uniq, int side, double thr, int cap,
@@ -374,6 +380,9 @@ __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ 
     __shared__ int count_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t e = blockIdx.x;
+#ifdef LCHD_SWEEP_STAMPS
+    unsigned long long estamp_last = __builtin_amdgcn_s_memtime();
+#endif
     if (e >= (int64_t)st->n_unique[side]) return;
     const DevConfig cfg = *cfgp;
     const uint32_t anchor = uniq[e];
@@ -408,6 +417,7 @@ __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ 
         int maxlen = 0;
 #pragma unroll
         for (int k = 0; k < 9; ++k) maxlen = max(maxlen, re[k] - rb[k]);
+        ESTAMP(0);
         for (int c0 = 0; c0 < maxlen; c0 += 64) {
             double X[9], Y[9], Z[9];
 #pragma unroll
@@ -477,6 +487,7 @@ __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ 
         __syncthreads();
         count = count_s;
     }
+    ESTAMP(1);
     if (count > cap) {  // the host re-launches a larger variant
         if (tid == 0) {
             atomicOr(&st->flags, ST_ENV_OVERFLOW);
@@ -568,11 +579,14 @@ __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ 
         __syncthreads();
         bitonic_sort_lds<NT>(key, val, n2, tid);
     }
+    ESTAMP(2);
     if (env.cdf_keys) keys_to_cdf_lds<NT>(key, count, tid, cfgp);
+    ESTAMP(3);
     uint64_t* ok_ = env.key + e * env.stride;
     uint8_t* oc_ = env.cat + e * env.stride;
     for (int i = tid; i < count; i += NT) { ok_[i] = key[i]; oc_[i] = val[i]; }
     if (tid == 0) env.len[e] = count;
+    ESTAMP(4);
 }
 
 bool launch_env_cells(hipStream_t s, int cap, const DevConfig* cfg, const CloudView& c, const GridView& g,
@@ -1780,6 +1794,14 @@ __global__ void k_fill_sqrt_tables(double* sqrt_tab, double* rsqrt_tab) {
 }
 #ifdef LCHD_SWEEP_STAMPS
 }  // namespace lchd
+extern "C" int lchd_debug_env_stamps(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(lchd::g_env_stamps), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(lchd::g_env_stamps), z, sizeof z) != hipSuccess) return 1;
+    }
+    return 0;
+}
 extern "C" int lchd_debug_sweep_stamps(unsigned long long* out8, int reset) {
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(lchd::g_sweep_stamps), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
     if (reset) {
