@@ -388,7 +388,7 @@ def main():
     if rank == 0:
         algo_bytes = env_points * 28 + 16 * p  # B_pair = (n_A + n_B) * 28 B + 8 B + 8 B
         dom = max(("env", "sweep"), key=lambda k: phase_ms[k])
-        dom_name = {"env": "k_env_cells (2 launches: side A + side B)", "sweep": "k_sweep"}[dom]
+        dom_name = {"env": "k_env_cells (2 launches: side A + side B)", "sweep": "k_sweep (its launch and the 18 us k_pair_meta record pass in front of it)"}[dom]
         achieved = algo_bytes / (phase_ms[dom] * 1e-3) / 1e9
         traffic, traffic_src = measured_traffic(dom_name, w["label"]) if p == 1_000_000 else (None, None)
         result = {

@@ -337,11 +337,10 @@ class LoCoHD:
     def pack(self, prims: Sequence[PrimitiveAtom], interner: Optional[Dict[str, int]] = None) -> _Packed:
         interner = {} if interner is None else interner
         n = len(prims)
-        xyz = np.empty((n, 3))
-        for i, p in enumerate(prims):
-            xyz[i] = p._coordinates if isinstance(p, PrimitiveAtom) else p.coordinates
+        xyz = np.array([p._coordinates if type(p) is PrimitiveAtom else p.coordinates for p in prims], dtype=np.float64).reshape(n, 3)
         cat = self._cats([p.primitive_type for p in prims])
-        tag = np.fromiter((interner.setdefault(p.tag, len(interner)) for p in prims), dtype=np.int32, count=n)
+        intern = interner.setdefault
+        tag = np.fromiter((intern(p.tag, len(interner)) for p in prims), dtype=np.int32, count=n)
         return _Packed(xyz, cat, tag)
 
     def from_packed(self, pa: _Packed, pb: _Packed, pairs, threshold_distance: float, wf_index: Optional[np.ndarray] = None,
