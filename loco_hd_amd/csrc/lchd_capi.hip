@@ -536,10 +536,8 @@ static GridPlan plan_grid(const lchd_cloud* cl, double thr) {
 }
 
 struct SideBufs {
-    uint32_t *cell_of, *cell_count, *cursor, *cell_start, *porig, *slot, *uniq, *scan_tmp;
-    double *px, *py, *pz;
-    uint8_t* pcat;
-    int32_t* ptag;
+    uint32_t *cell_of, *cell_count, *cursor, *cell_start, *pos_of, *slot, *uniq, *scan_tmp;
+    CellRec* rec;
     EnvStore env;
 };
 
@@ -549,12 +547,8 @@ static void carve_side(Arena& a, int64_t n, int n_cells, int64_t max_envs, int c
     b.cell_count = a.take<uint32_t>((size_t)n_cells + 1);
     b.cursor = a.take<uint32_t>((size_t)n_cells + 1);
     b.cell_start = a.take<uint32_t>((size_t)n_cells + 1);
-    b.px = a.take<double>(m);
-    b.py = a.take<double>(m);
-    b.pz = a.take<double>(m);
-    b.pcat = a.take<uint8_t>(m);
-    b.ptag = a.take<int32_t>(m);
-    b.porig = a.take<uint32_t>(m);
+    b.rec = a.take<CellRec>(m);
+    b.pos_of = a.take<uint32_t>(m);
     b.slot = a.take<uint32_t>(m + 1);
     b.uniq = a.take<uint32_t>(m);
     b.scan_tmp = a.take<uint32_t>(std::max<size_t>(m, (size_t)n_cells) / 4096 + 4);
@@ -613,8 +607,8 @@ static int prims_enqueue(lchd_ctx* c) {
         for (int k = 0; k < 3; ++k) { v.min[k] = g.min[k]; v.inv[k] = g.inv[k]; v.dim[k] = g.dim[k]; }
         v.n_cells = g.n_cells;
         v.cell_start = s.cell_start;
-        v.px = s.px; v.py = s.py; v.pz = s.pz;
-        v.pcat = s.pcat; v.ptag = s.ptag; v.porig = s.porig;
+        v.rec = s.rec;
+        v.pos_of = s.pos_of;
         return v;
     };
     const GridView gva = grid_view(ga, sa), gvb = grid_view(gb, sb);
@@ -625,8 +619,8 @@ static int prims_enqueue(lchd_ctx* c) {
     if (b->ev_ready && b->cap_frames) HIP_TRY(hipStreamWaitEvent(s, b->ev_ready, 0));
     HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(DeviceStatus), s));
     mark(c, 0);
-    launch_cell_build(s, cva, gva, sa.cell_of, sa.cell_count, sa.cursor, sa.px, sa.py, sa.pz, sa.pcat, sa.ptag, sa.porig, sa.cell_start, sa.scan_tmp);
-    launch_cell_build(s, cvb, gvb, sb.cell_of, sb.cell_count, sb.cursor, sb.px, sb.py, sb.pz, sb.pcat, sb.ptag, sb.porig, sb.cell_start, sb.scan_tmp);
+    launch_cell_build(s, cva, gva, sa.cell_of, sa.cell_count, sa.cursor, sa.rec, sa.pos_of, sa.cell_start, sa.scan_tmp);
+    launch_cell_build(s, cvb, gvb, sb.cell_of, sb.cell_count, sb.cursor, sb.rec, sb.pos_of, sb.cell_start, sb.scan_tmp);
     mark(c, 1);
     launch_anchor_dedupe(s, P.anchors, n_pairs, 0, (int32_t)a->n, sa.slot, sa.uniq, c->d_status, sa.scan_tmp);
     launch_anchor_dedupe(s, P.anchors, n_pairs, 1, (int32_t)b->n, sb.slot, sb.uniq, c->d_status, sb.scan_tmp);

@@ -58,17 +58,23 @@ struct CloudView {
     int32_t n_struct;     // >= 1
 };
 
+struct __attribute__((aligned(16))) CellRec {
+    double x, y, z;
+    uint32_t tag;   // interned tag
+    uint32_t cat;   // category id (255 = not in the category map)
+};
+static_assert(sizeof(CellRec) == 32, "CellRec is read as two 16-byte words");
+
 // Uniform grid over one cloud (replaces KdTree::build_by_ordered_float, src/locohd.rs:504-510).
 struct GridView {
     double min[3], inv[3];   // cell index = clamp(floor((p - min) * inv), 0, dim-1)
     int32_t dim[3];          // per structure; cell = ((sid * dim[2] + cz) * dim[1] + cy) * dim[0] + cx
     int32_t n_cells;         // n_struct * dim[0] * dim[1] * dim[2]
     const uint32_t* cell_start;  // [n_cells + 1]
-    // points permuted into cell order
-    const double *px, *py, *pz;
-    const uint8_t* pcat;
-    const int32_t* ptag;
-    const uint32_t* porig;
+    // points permuted into cell order, one 32-byte record each (two 16-byte loads fetch everything the radius search,
+    // the tag filter and the environment need: no dependent second round of loads for the survivors)
+    const CellRec* rec;
+    const uint32_t* pos_of;      // atom -> its position in cell order (an anchor recognises itself by position)
 };
 
 // Sorted environments: env e occupies [e*stride, e*stride + len[e]).
@@ -82,8 +88,7 @@ struct EnvStore {
 
 // `scan_tmp` holds (n / 4096 + 2) u32 of scratch for the multi-block scan
 void launch_cell_build(hipStream_t s, const CloudView& c, GridView g, uint32_t* cell_of, uint32_t* cell_count,
-                       uint32_t* cell_cursor, double* px, double* py, double* pz, uint8_t* pcat, int32_t* ptag,
-                       uint32_t* porig, uint32_t* cell_start, uint32_t* scan_tmp);
+                       uint32_t* cell_cursor, CellRec* rec, uint32_t* pos_of, uint32_t* cell_start, uint32_t* scan_tmp);
 
 void launch_anchor_dedupe(hipStream_t s, const int64_t* anchors, int64_t n_pairs, int side, int32_t n_points,
                           uint32_t* flag_then_slot, uint32_t* uniq, DeviceStatus* st, uint32_t* scan_tmp);

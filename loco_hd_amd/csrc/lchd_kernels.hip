@@ -162,16 +162,18 @@ __global__ __launch_bounds__(1024) void k_exclusive_scan(const uint32_t* in, uin
 }
 
 __global__ void k_cell_scatter(CloudView c, const uint32_t* cell_of, const uint32_t* cell_start, uint32_t* cursor,
-                               double* px, double* py, double* pz, uint8_t* pcat, int32_t* ptag, uint32_t* porig) {
+                               CellRec* __restrict__ rec, uint32_t* __restrict__ pos_of) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < c.n; i += gridDim.x * blockDim.x) {
         const uint32_t cell = cell_of[i];
         const uint32_t pos = cell_start[cell] + atomicAdd(&cursor[cell], 1u);
-        px[pos] = c.x[i];
-        py[pos] = c.y[i];
-        pz[pos] = c.z[i];
-        pcat[pos] = c.cat[i];
-        ptag[pos] = c.tag[i];
-        porig[pos] = (uint32_t)i;
+        CellRec r;
+        r.x = c.x[i];
+        r.y = c.y[i];
+        r.z = c.z[i];
+        r.tag = (uint32_t)c.tag[i];
+        r.cat = c.cat[i];
+        rec[pos] = r;
+        pos_of[i] = pos;
     }
 }
 
@@ -221,14 +223,13 @@ static void launch_exclusive_scan(hipStream_t s, const uint32_t* in, uint32_t* o
 }
 
 void launch_cell_build(hipStream_t s, const CloudView& c, GridView g, uint32_t* cell_of, uint32_t* cell_count,
-                       uint32_t* cell_cursor, double* px, double* py, double* pz, uint8_t* pcat, int32_t* ptag,
-                       uint32_t* porig, uint32_t* cell_start, uint32_t* scan_tmp) {
+                       uint32_t* cell_cursor, CellRec* rec, uint32_t* pos_of, uint32_t* cell_start, uint32_t* scan_tmp) {
     (void)hipMemsetAsync(cell_count, 0, sizeof(uint32_t) * (size_t)(g.n_cells + 1), s);
     (void)hipMemsetAsync(cell_cursor, 0, sizeof(uint32_t) * (size_t)(g.n_cells + 1), s);
     const int nb = (c.n + 255) / 256 > 4096 ? 4096 : (c.n + 255) / 256;
     if (c.n > 0) k_cell_count<<<nb, 256, 0, s>>>(c, g, cell_of, cell_count);
     launch_exclusive_scan(s, cell_count, cell_start, g.n_cells, nullptr, scan_tmp);
-    if (c.n > 0) k_cell_scatter<<<nb, 256, 0, s>>>(c, cell_of, cell_start, cell_cursor, px, py, pz, pcat, ptag, porig);
+    if (c.n > 0) k_cell_scatter<<<nb, 256, 0, s>>>(c, cell_of, cell_start, cell_cursor, rec, pos_of);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -388,6 +389,7 @@ __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ 
     const uint32_t anchor = uniq[e];
     const double ax = c.x[anchor], ay = c.y[anchor], az = c.z[anchor];
     const int32_t atag = c.tag[anchor];
+    const uint32_t apos = g.pos_of[anchor];  // the anchor's own record in cell order
     const int asid = c.sid ? c.sid[anchor] : 0;
     const double thr2 = thr * thr;
     const int cx = cell_coord(ax, g.min[0], g.inv[0], g.dim[0]);
@@ -418,32 +420,33 @@ __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ 
 #pragma unroll
         for (int k = 0; k < 9; ++k) maxlen = max(maxlen, re[k] - rb[k]);
         ESTAMP(0);
+        const double2* __restrict__ rec2 = reinterpret_cast<const double2*>(g.rec);  // record i = words 2i (x, y) and 2i+1 (z, tag|cat)
         for (int c0 = 0; c0 < maxlen; c0 += 64) {
-            double X[9], Y[9], Z[9];
+            double2 R0[9], R1[9];
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
                 const int idx = rb[k] + c0 + lane;
                 const bool v = idx < re[k];
-                X[k] = v ? g.px[idx] : 0.0;
-                Y[k] = v ? g.py[idx] : 0.0;
-                Z[k] = v ? g.pz[idx] : 0.0;
+                R0[k] = v ? rec2[2 * (int64_t)idx] : make_double2(0.0, 0.0);
+                R1[k] = v ? rec2[2 * (int64_t)idx + 1] : make_double2(0.0, 0.0);
             }
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
                 if (rb[k] + c0 < re[k]) {  // wave-uniform: this row still has atoms at this step
                     const int idx = rb[k] + c0 + lane;
-                    const double dx = X[k] - ax, dy = Y[k] - ay, dz = Z[k] - az;
+                    const double dx = R0[k].x - ax, dy = R0[k].y - ay, dz = R1[k].x - az;
                     double d2 = dx * dx;   // TU is built with -ffp-contract=off: same roundings as the
                     d2 = d2 + dy * dy;     // reference's `distance += diff * diff`
                     d2 = d2 + dz * dz;
+                    const uint64_t tc = d2u(R1[k].y);  // tag | cat << 32
                     bool ok = false;
-                    if (idx < re[k] && d2 < thr2) ok = (g.porig[idx] == anchor) || tag_pair_accepted(cfg, atag, g.ptag[idx]);
+                    if (idx < re[k] && d2 < thr2) ok = ((uint32_t)idx == apos) || tag_pair_accepted(cfg, atag, (int32_t)(uint32_t)tc);
                     const unsigned long long m = __ballot(ok);
                     if (ok) {
                         const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
                         if (pos < cap) {
                             key[pos] = d2u(d2);  // the square root is taken after compaction (a sixth of the candidates survive)
-                            val[pos] = g.pcat[idx];
+                            val[pos] = (uint8_t)(tc >> 32);
                         }
                     }
                     count += __popcll(m);
@@ -460,12 +463,15 @@ __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ 
                 const int idx = base + lane;
                 bool ok = false;
                 double d2 = 0.0;
+                uint32_t ccat = 0;
                 if (idx < end) {
-                    const double dx = g.px[idx] - ax, dy = g.py[idx] - ay, dz = g.pz[idx] - az;
+                    const CellRec r = g.rec[idx];
+                    const double dx = r.x - ax, dy = r.y - ay, dz = r.z - az;
                     d2 = dx * dx;
                     d2 = d2 + dy * dy;
                     d2 = d2 + dz * dz;
-                    if (d2 < thr2) ok = (g.porig[idx] == anchor) || tag_pair_accepted(cfg, atag, g.ptag[idx]);
+                    ccat = r.cat;
+                    if (d2 < thr2) ok = ((uint32_t)idx == apos) || tag_pair_accepted(cfg, atag, (int32_t)r.tag);
                 }
                 const unsigned long long m = __ballot(ok);
                 int wbase = 0;
@@ -476,7 +482,7 @@ __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ 
                     const int pos = wbase + __popcll(m & ((1ull << lane) - 1ull));
                     if (pos < cap) {
                         key[pos] = d2u(sqrt(d2));
-                        val[pos] = g.pcat[idx];
+                        val[pos] = (uint8_t)ccat;
                     }
                 }
             }
