@@ -7,7 +7,7 @@
 //                           structure id as the slowest grid dimension
 //   K0' anchor de-dup       k_mark_anchors / scan / k_compact_anchors
 //                           (an anchor that occurs in many pairs gets its environment built once)
-//   K1  environment build   k_env_cells<NT>: radius search + tag filter + distances, then an O(n) bucket sort
+//   K1  environment build   k_env_cells<NT>: radius search over 32-byte cell records + tag filter + distances, then an O(n) bucket sort
 //                           (d^3 buckets, LDS histogram + scan + scatter + per-lane insertion sort) for environments
 //                           of <= 512 points, LDS bitonic network otherwise; optional CDF keying
 //                           (replaces env_from_idx :514-542, utils::sort_together utils.rs:25-39)
@@ -29,6 +29,10 @@
 
 #include "lchd_device.h"
 #include "lchd_math.h"
+
+#ifndef LCHD_ENV_FLAT
+#define LCHD_ENV_FLAT 4   // steps of 64 candidates whose record loads are issued together in the radius search
+#endif
 
 namespace lchd {
 
@@ -403,44 +407,53 @@ __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ 
 
     int count = 0;  // NT == 64: the wave's running count; NT > 64: unused (count_s is the shared cursor)
     if constexpr (NT == 64) {
-        // One wavefront: the latency of the dependent loads (cell_start -> atoms) dominates, so fetch the bounds of all
-        // nine (y,z) rows first and then walk the rows 64 atoms at a time with the coordinate loads of all rows of a
-        // step issued together.
-        int rb[9], re[9];
+        // One wavefront.  The (up to) nine (y,z) rows of neighbour cells are contiguous runs of the cell-ordered records; their
+        // bounds are fetched first (one dependent-load latency), then the runs are walked as ONE concatenated candidate list,
+        // 64 candidates per step (every step is a full wavefront, however short the individual runs are); the record loads
+        // of U steps are issued together.
+        int rb[9], roff[10];
+        roff[0] = 0;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             const int zz = cz - 1 + k / 3, yy = cy - 1 + k % 3;
             const bool in = zz >= 0 && zz < g.dim[2] && yy >= 0 && yy < g.dim[1];
             const int row = in ? (int)((((int64_t)asid * g.dim[2] + zz) * g.dim[1] + yy) * g.dim[0]) : 0;
             const int b_ = (int)g.cell_start[row + x0], e_ = (int)g.cell_start[row + x1 + 1];
-            rb[k] = in ? b_ : 0;
-            re[k] = in ? e_ : 0;
+            rb[k] = b_;
+            roff[k + 1] = roff[k] + (in ? e_ - b_ : 0);
         }
-        int maxlen = 0;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) maxlen = max(maxlen, re[k] - rb[k]);
+        const int total = __builtin_amdgcn_readfirstlane(roff[9]);
         ESTAMP(0);
-        const double2* __restrict__ rec2 = reinterpret_cast<const double2*>(g.rec);  // record i = words 2i (x, y) and 2i+1 (z, tag|cat)
-        for (int c0 = 0; c0 < maxlen; c0 += 64) {
-            double2 R0[9], R1[9];
+        auto index_of = [&](int t) -> int {  // candidate t of the concatenated list -> record index
+            int d = rb[0];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                const int idx = rb[k] + c0 + lane;
-                const bool v = idx < re[k];
-                R0[k] = v ? rec2[2 * (int64_t)idx] : make_double2(0.0, 0.0);
-                R1[k] = v ? rec2[2 * (int64_t)idx + 1] : make_double2(0.0, 0.0);
+            for (int k = 1; k < 9; ++k) d = (t >= roff[k]) ? rb[k] - roff[k] : d;
+            return t + d;
+        };
+        const double2* __restrict__ rec2 = reinterpret_cast<const double2*>(g.rec);
+        constexpr int U = LCHD_ENV_FLAT;
+        for (int c0 = 0; c0 < total; c0 += 64 * U) {
+            int idx[U];
+            double2 R0[U], R1[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = c0 + 64 * u + lane;
+                idx[u] = index_of(t);
+                const bool v = t < total;
+                R0[u] = v ? rec2[2 * (int64_t)idx[u]] : make_double2(0.0, 0.0);
+                R1[u] = v ? rec2[2 * (int64_t)idx[u] + 1] : make_double2(0.0, 0.0);
             }
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                if (rb[k] + c0 < re[k]) {  // wave-uniform: this row still has atoms at this step
-                    const int idx = rb[k] + c0 + lane;
-                    const double dx = R0[k].x - ax, dy = R0[k].y - ay, dz = R1[k].x - az;
+            for (int u = 0; u < U; ++u) {
+                if (c0 + 64 * u < total) {  // wave-uniform
+                    const bool v = c0 + 64 * u + lane < total;
+                    const double dx = R0[u].x - ax, dy = R0[u].y - ay, dz = R1[u].x - az;
                     double d2 = dx * dx;   // TU is built with -ffp-contract=off: same roundings as the
                     d2 = d2 + dy * dy;     // reference's `distance += diff * diff`
                     d2 = d2 + dz * dz;
-                    const uint64_t tc = d2u(R1[k].y);  // tag | cat << 32
+                    const uint64_t tc = d2u(R1[u].y);  // tag | cat << 32
                     bool ok = false;
-                    if (idx < re[k] && d2 < thr2) ok = ((uint32_t)idx == apos) || tag_pair_accepted(cfg, atag, (int32_t)(uint32_t)tc);
+                    if (v && d2 < thr2) ok = ((uint32_t)idx[u] == apos) || tag_pair_accepted(cfg, atag, (int32_t)(uint32_t)tc);
                     const unsigned long long m = __ballot(ok);
                     if (ok) {
                         const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
