@@ -536,7 +536,8 @@ static GridPlan plan_grid(const lchd_cloud* cl, double thr) {
 }
 
 struct SideBufs {
-    uint32_t *cell_of, *cell_count, *cursor, *cell_start, *pos_of, *slot, *uniq, *scan_tmp;
+    uint32_t *cell_of, *cell_count, *cursor, *cell_start, *pos_of, *slot, *scan_tmp;
+    AnchorRec* uniq;
     CellRec* rec;
     EnvStore env;
 };
@@ -550,7 +551,7 @@ static void carve_side(Arena& a, int64_t n, int n_cells, int64_t max_envs, int c
     b.rec = a.take<CellRec>(m);
     b.pos_of = a.take<uint32_t>(m);
     b.slot = a.take<uint32_t>(m + 1);
-    b.uniq = a.take<uint32_t>(m);
+    b.uniq = a.take<AnchorRec>((size_t)std::max<int64_t>(max_envs, 1));
     b.scan_tmp = a.take<uint32_t>(std::max<size_t>(m, (size_t)n_cells) / 4096 + 4);
     const size_t ne = (size_t)std::max<int64_t>(max_envs, 1);
     b.env.key = a.take<uint64_t>(ne * (size_t)cap);
@@ -622,8 +623,8 @@ static int prims_enqueue(lchd_ctx* c) {
     launch_cell_build(s, cva, gva, sa.cell_of, sa.cell_count, sa.cursor, sa.rec, sa.pos_of, sa.cell_start, sa.scan_tmp);
     launch_cell_build(s, cvb, gvb, sb.cell_of, sb.cell_count, sb.cursor, sb.rec, sb.pos_of, sb.cell_start, sb.scan_tmp);
     mark(c, 1);
-    launch_anchor_dedupe(s, P.anchors, n_pairs, 0, (int32_t)a->n, sa.slot, sa.uniq, c->d_status, sa.scan_tmp);
-    launch_anchor_dedupe(s, P.anchors, n_pairs, 1, (int32_t)b->n, sb.slot, sb.uniq, c->d_status, sb.scan_tmp);
+    launch_anchor_dedupe(s, P.anchors, n_pairs, 0, (int32_t)a->n, sa.slot, sa.uniq, cva, sa.pos_of, c->d_status, sa.scan_tmp);
+    launch_anchor_dedupe(s, P.anchors, n_pairs, 1, (int32_t)b->n, sb.slot, sb.uniq, cvb, sb.pos_of, c->d_status, sb.scan_tmp);
     mark(c, 2);
     if (!launch_env_cells(s, cap, c->d_cfg, cva, gva, sa.uniq, 0, max_env_a, thr, sa.env, c->d_status) ||
         !launch_env_cells(s, cap, c->d_cfg, cvb, gvb, sb.uniq, 1, max_env_b, thr, sb.env, c->d_status))

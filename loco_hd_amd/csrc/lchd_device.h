@@ -65,6 +65,16 @@ struct __attribute__((aligned(16))) CellRec {
 };
 static_assert(sizeof(CellRec) == 32, "CellRec is read as two 16-byte words");
 
+// One unique anchor, written by k_compact_anchors so that the environment kernel starts from ONE record instead of the
+// chain slot -> atom -> coordinates / tag / position.
+struct __attribute__((aligned(8))) AnchorRec {
+    double x, y, z;
+    uint32_t tag;    // interned tag of the anchor
+    uint32_t apos;   // its position in cell order
+    int32_t sid;     // structure of a batch (0 otherwise)
+    uint32_t atom;   // index in the cloud
+};
+
 // Uniform grid over one cloud (replaces KdTree::build_by_ordered_float, src/locohd.rs:504-510).
 struct GridView {
     double min[3], inv[3];   // cell index = clamp(floor((p - min) * inv), 0, dim-1)
@@ -91,11 +101,12 @@ void launch_cell_build(hipStream_t s, const CloudView& c, GridView g, uint32_t* 
                        uint32_t* cell_cursor, CellRec* rec, uint32_t* pos_of, uint32_t* cell_start, uint32_t* scan_tmp);
 
 void launch_anchor_dedupe(hipStream_t s, const int64_t* anchors, int64_t n_pairs, int side, int32_t n_points,
-                          uint32_t* flag_then_slot, uint32_t* uniq, DeviceStatus* st, uint32_t* scan_tmp);
+                          uint32_t* flag_then_slot, AnchorRec* uniq, const CloudView& c, const uint32_t* pos_of, DeviceStatus* st,
+                          uint32_t* scan_tmp);
 
 // returns false if `cap` is not an available variant
 bool launch_env_cells(hipStream_t s, int cap, const DevConfig* cfg, const CloudView& c, const GridView& g,
-                      const uint32_t* uniq, int side, int64_t max_envs, double thr, EnvStore env, DeviceStatus* st);
+                      const AnchorRec* uniq, int side, int64_t max_envs, double thr, EnvStore env, DeviceStatus* st);
 
 // dense rows: either distances from coordinates (dmx == nullptr) or given rows (dmx != nullptr, leading dim ld)
 bool launch_env_rows(hipStream_t s, int cap, const DevConfig* cfg, const CloudView& c, const double* dmx, int64_t ld,

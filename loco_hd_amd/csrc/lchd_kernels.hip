@@ -238,7 +238,7 @@ void launch_cell_build(hipStream_t s, const CloudView& c, GridView g, uint32_t* 
 
 // ------------------------------------------------------------------------------------------------
 // K0': anchor de-duplication.  flag[i] = 1 if atom i is an anchor of some pair; exclusive scan turns the
-// flags into environment slots; uniq[slot] = atom index.
+// flags into environment slots; uniq[slot] = the anchor's record (coordinates, tag, position in cell order, structure).
 // ------------------------------------------------------------------------------------------------
 __global__ void k_mark_anchors(const int64_t* anchors, int64_t n_pairs, int side, int32_t n_points, uint32_t* flag,
                                DeviceStatus* st) {
@@ -248,13 +248,22 @@ __global__ void k_mark_anchors(const int64_t* anchors, int64_t n_pairs, int side
         else flag[a] = 1u;
     }
 }
-__global__ void k_compact_anchors(const uint32_t* slot, int32_t n_points, uint32_t* uniq) {
+__global__ void k_compact_anchors(const uint32_t* slot, int32_t n_points, AnchorRec* uniq, CloudView c, const uint32_t* pos_of) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_points; i += gridDim.x * blockDim.x)
-        if (slot[i + 1] != slot[i]) uniq[slot[i]] = (uint32_t)i;
+        if (slot[i + 1] != slot[i]) {
+            AnchorRec r;
+            r.x = c.x[i]; r.y = c.y[i]; r.z = c.z[i];
+            r.tag = (uint32_t)c.tag[i];
+            r.apos = pos_of[i];
+            r.sid = c.sid ? c.sid[i] : 0;
+            r.atom = (uint32_t)i;
+            uniq[slot[i]] = r;
+        }
 }
 
 void launch_anchor_dedupe(hipStream_t s, const int64_t* anchors, int64_t n_pairs, int side, int32_t n_points,
-                          uint32_t* flag_then_slot, uint32_t* uniq, DeviceStatus* st, uint32_t* scan_tmp) {
+                          uint32_t* flag_then_slot, AnchorRec* uniq, const CloudView& c, const uint32_t* pos_of, DeviceStatus* st,
+                          uint32_t* scan_tmp) {
     (void)hipMemsetAsync(flag_then_slot, 0, sizeof(uint32_t) * (size_t)(n_points + 1), s);
     if (n_pairs > 0) {
         const int64_t nbp = (n_pairs + 255) / 256;
@@ -263,7 +272,7 @@ void launch_anchor_dedupe(hipStream_t s, const int64_t* anchors, int64_t n_pairs
     launch_exclusive_scan(s, flag_then_slot, flag_then_slot, n_points, &st->n_unique[side], scan_tmp);
     if (n_points > 0) {
         const int nb = (n_points + 255) / 256;
-        k_compact_anchors<<<nb > 4096 ? 4096 : nb, 256, 0, s>>>(flag_then_slot, n_points, uniq);
+        k_compact_anchors<<<nb > 4096 ? 4096 : nb, 256, 0, s>>>(flag_then_slot, n_points, uniq, c, pos_of);
     }
 }
 
@@ -337,6 +346,25 @@ __device__ __forceinline__ void keys_to_cdf_lds(uint64_t* key, int n, int tid, c
     __syncthreads();
 }
 
+// The same for one wavefront: every lane converts its (strided) keys, then the wave checks that the result is still
+// non-decreasing; the running maximum is only needed when the floating-point CDF produced a last-bit inversion, which a
+// single lane then repairs in place (rare enough not to matter).
+__device__ __forceinline__ void keys_to_cdf_wave(uint64_t* key, int n, int lane, const DevConfig* __restrict__ cfg) {
+    const WfEntry wf = cfg->wf[0];
+    const double* __restrict__ prm = cfg->wf_params + wf.offset;
+    for (int i = lane; i < n; i += 64) key[i] = d2u(cdf_lean(wf.kind, prm, wf.n_params, u2d(key[i])) + 0.0);
+    __syncthreads();
+    bool inv = false;
+    for (int i = lane; i < n; i += 64) inv = inv || (i > 0 && key[i] < key[i - 1]);
+    if (__ballot(inv)) {
+        if (lane == 0) {
+            uint64_t m = 0;
+            for (int i = 0; i < n; ++i) { m = key[i] > m ? key[i] : m; key[i] = m; }
+        }
+        __syncthreads();
+    }
+}
+
 __device__ __forceinline__ int next_pow2(int n) {
     int p = 1;
     while (p < n) p <<= 1;
@@ -376,7 +404,7 @@ __device__ unsigned long long g_env_stamps[8];
 #endif
 template <int NT>
 __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ cfgp, CloudView c, GridView g,
-                                                  const uint32_t* __restrict__ uniq, int side, double thr, int cap,
+                                                  const AnchorRec* __restrict__ uniq, int side, double thr, int cap,
                                                   EnvStore env, DeviceStatus* st) {
     // dynamic LDS: cap * 9 bytes (u64 keys, then u8 categories)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -390,11 +418,11 @@ __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ 
 #endif
     if (e >= (int64_t)st->n_unique[side]) return;
     const DevConfig cfg = *cfgp;
-    const uint32_t anchor = uniq[e];
-    const double ax = c.x[anchor], ay = c.y[anchor], az = c.z[anchor];
-    const int32_t atag = c.tag[anchor];
-    const uint32_t apos = g.pos_of[anchor];  // the anchor's own record in cell order
-    const int asid = c.sid ? c.sid[anchor] : 0;
+    const AnchorRec arec = uniq[e];
+    const double ax = arec.x, ay = arec.y, az = arec.z;
+    const int32_t atag = (int32_t)arec.tag;
+    const uint32_t apos = arec.apos;  // the anchor's own record in cell order
+    const int asid = arec.sid;
     const double thr2 = thr * thr;
     const int cx = cell_coord(ax, g.min[0], g.inv[0], g.dim[0]);
     const int cy = cell_coord(ay, g.min[1], g.inv[1], g.dim[1]);
@@ -599,7 +627,10 @@ __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ 
         bitonic_sort_lds<NT>(key, val, n2, tid);
     }
     ESTAMP(2);
-    if (env.cdf_keys) keys_to_cdf_lds<NT>(key, count, tid, cfgp);
+    if (env.cdf_keys) {
+        if constexpr (NT == 64) keys_to_cdf_wave(key, count, lane, cfgp);
+        else keys_to_cdf_lds<NT>(key, count, tid, cfgp);
+    }
     ESTAMP(3);
     uint64_t* ok_ = env.key + e * env.stride;
     uint8_t* oc_ = env.cat + e * env.stride;
@@ -609,7 +640,7 @@ __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ 
 }
 
 bool launch_env_cells(hipStream_t s, int cap, const DevConfig* cfg, const CloudView& c, const GridView& g,
-                      const uint32_t* uniq, int side, int64_t max_envs, double thr, EnvStore env, DeviceStatus* st) {
+                      const AnchorRec* uniq, int side, int64_t max_envs, double thr, EnvStore env, DeviceStatus* st) {
     if (max_envs <= 0) return true;
     if (cap < 64 || cap > 16384 || (cap & (cap - 1))) return false;
     const dim3 grid((unsigned)max_envs);
