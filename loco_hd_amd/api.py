@@ -333,6 +333,49 @@ class LoCoHD:
         pa, pb = self.pack(prim_a, interner), self.pack(prim_b, interner)
         return self.from_packed(pa, pb, pairs, threshold_distance, wf_index=idx, interner=interner).tolist()
 
+    def from_primitives_batch(self, structures: Sequence[Sequence[PrimitiveAtom]],
+                              jobs: Sequence[Tuple[int, int, Sequence[Tuple[int, int]]]],
+                              threshold_distance: float) -> List[List[float]]:
+        """Additive: many `from_primitives` calls in one device pass.  `structures` are lists of
+        PrimitiveAtoms; a job `(a, b, anchor_pairs)` asks for `from_primitives(structures[a], structures[b],
+        anchor_pairs, threshold_distance)`.  Returns one score list per job, each bit-identical to the single call.
+        Replaces loops such as python_codes/casp14/casp14_extend_with_locohd.py:42-88 (every decoy against the native
+        structure) or python_codes/ensembles/compare_ensembles.py:277-296: all structures are uploaded once as one batch
+        object, the anchor pairs of all jobs are scored by one kernel sequence."""
+        from .device import DeviceSession  # torch is only needed on this path
+
+        if isinstance(self._w_func, dict):
+            raise ValueError("from_primitives_batch needs a single weight function (no per-pair keys)")
+        interner: Dict[str, int] = {}
+        packed = [self.pack(st, interner) for st in structures]
+        sizes = [len(pk.cat) for pk in packed]
+        flat, spans = [], []
+        offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        for a, b, pairs in jobs:
+            if not (0 <= int(a) < len(packed) and 0 <= int(b) < len(packed)):
+                raise IndexError(f"job refers to structure {a} / {b} of {len(packed)}")
+            pr = np.ascontiguousarray(pairs, dtype=np.int64).reshape(-1, 2)
+            if len(pr) and (pr.min() < 0 or pr[:, 0].max() >= sizes[int(a)] or pr[:, 1].max() >= sizes[int(b)]):
+                raise N.PanicException("index out of bounds: an anchor index is outside its structure (src/locohd.rs:521)")
+            spans.append((len(flat), len(pr)))
+            flat.extend([pr + np.asarray([offsets[int(a)], offsets[int(b)]], dtype=np.int64)] if len(pr) else [])
+        total = sum(n for _, n in spans)
+        if total == 0:
+            return [[] for _ in jobs]
+        sess = DeviceSession(self, device=None if self._device < 0 else self._device, interner=interner)
+        try:
+            torch = sess.torch
+            batch, _ = sess.upload_batch([(pk.xyz, pk.cat, pk.tag) for pk in packed])
+            anchors = torch.from_numpy(np.concatenate(flat)).to(torch.device("cuda", sess.device))
+            scores = sess.from_primitives(batch, batch, anchors, float(threshold_distance)).cpu().numpy()
+        finally:
+            sess.close()
+        out, pos = [], 0
+        for _, n in spans:
+            out.append(scores[pos:pos + n].tolist())
+            pos += n
+        return out
+
     # ---- additive array-level entry (no per-atom Python objects; used by bench.py and batch callers) --------
     def pack(self, prims: Sequence[PrimitiveAtom], interner: Optional[Dict[str, int]] = None) -> _Packed:
         interner = {} if interner is None else interner

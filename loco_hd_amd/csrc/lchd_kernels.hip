@@ -885,6 +885,9 @@ enum { F_KEY = 0, F_FAST = 1, F_ANY = 2 };
 #ifndef LCHD_SWEEP_WAVES
 #define LCHD_SWEEP_WAVES 4
 #endif
+#ifndef LCHD_SWEEP_W3MAX
+#define LCHD_SWEEP_W3MAX 16   // largest category-slot count that is compiled for 3 waves per SIMD (above: 2)
+#endif
 #ifndef LCHD_SWEEP_MINW
 #define LCHD_SWEEP_MINW 2
 #endif
@@ -991,7 +994,7 @@ __device__ unsigned long long g_sweep_stamps[8];
 
 // register budget: 4 waves/SIMD (<= 128 VGPRs) up to 12 category slots, 3 (<= 168) up to 16, 2 beyond
 template <int CMAX, int MODE, int FMODE, bool LDSTAB>
-__global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 12 ? 4 : (CMAX <= 16 ? 3 : 2)))) void k_sweep(SweepArgs args) {
+__global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 12 ? 4 : (CMAX <= LCHD_SWEEP_W3MAX ? 3 : 2)))) void k_sweep(SweepArgs args) {
     constexpr int EPL = kSweepEPL, TILE = kSweepTile, WPB = kSweepWaves;
     constexpr int NW = CMAX / 4;          // u64 words of 16-bit count fields per side
     constexpr int NH = (CMAX + 15) / 16;  // u64 words of 4-bit histogram fields per side

@@ -257,3 +257,38 @@ def test_dense_rows_beyond_lds_capacity(lh, oracle):
         assert abs(got[i] - want) < TIGHT, i
     same = np.asarray(lchd.from_coords(sa, sa, xa, xa))
     assert np.max(np.abs(same)) == 0.0
+
+
+def test_from_primitives_batch_matches_single_calls(lh, oracle):
+    """LoCoHD.from_primitives_batch (additive): several structure pairs in one device pass, bit-identical to
+    the per-pair calls and equal to the oracle."""
+    rng = np.random.default_rng(12)
+    n_res = 60
+    side = (3 * n_res / 0.023) ** (1 / 3)
+    base = cg_structure(rng, n_res, side)
+    sts = [(base[0], base[1] + rng.normal(0.0, 1.0, base[1].shape), base[2]) for _ in range(4)]
+    # a structure of another size with its own labels
+    other = cg_structure(rng, 41, side)
+    sts.append(other)
+    rule = {"accept_same": False}
+    lchd = lh.LoCoHD(CG_TYPES, lh.WeightFunction("uniform", [3.0, 10.0]), lh.TagPairingRule(rule))
+    ps = [prims(lh, *s) for s in sts]
+    cent = [(i, i) for i in range(0, 3 * n_res, 3)]
+    jobs = [(0, 1, cent), (0, 2, cent), (3, 0, cent[::2]), (1, 1, cent), (4, 0, [(0, 0), (3, 9), (120, 177)]), (2, 4, [])]
+    got = lchd.from_primitives_batch(ps, jobs, 10.0)
+    assert [len(g) for g in got] == [len(j[2]) for j in jobs]
+    lo = oracle.LoCoHD(CG_TYPES, oracle.WeightFunction("uniform", [3.0, 10.0]), oracle.TagPairingRule(rule))
+    po = [prims(oracle, *s) for s in sts]
+    for (a, b, pairs), g in zip(jobs, got):
+        if not pairs:
+            assert g == []
+            continue
+        single = lchd.from_primitives(ps[a], ps[b], pairs, 10.0)
+        assert g == single  # bitwise
+        want = np.asarray(lo.from_primitives(po[a], po[b], pairs, 10.0))
+        assert np.max(np.abs(np.asarray(g) - want)) < TIGHT
+    assert np.max(np.abs(np.asarray(got[3]))) == 0.0  # a structure against itself
+    with pytest.raises(lh.PanicException):
+        lchd.from_primitives_batch(ps, [(0, 4, [(0, 500)])], 10.0)
+    with pytest.raises(IndexError):
+        lchd.from_primitives_batch(ps, [(0, 9, cent)], 10.0)
