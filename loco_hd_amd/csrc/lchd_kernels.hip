@@ -885,6 +885,9 @@ enum { F_KEY = 0, F_FAST = 1, F_ANY = 2 };
 #ifndef LCHD_SWEEP_WAVES
 #define LCHD_SWEEP_WAVES 4
 #endif
+#ifndef LCHD_BIG_SQRT_COMPUTE
+#define LCHD_BIG_SQRT_COMPUTE 1
+#endif
 #ifndef LCHD_SWEEP_W3MAX
 #define LCHD_SWEEP_W3MAX 16   // largest category-slot count that is compiled for 3 waves per SIMD (above: 2)
 #endif
@@ -1027,8 +1030,24 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
     uint8_t* cA = cA_[wv];
     uint8_t* cB = cB_[wv];
 
+#if LCHD_BIG_SQRT_COMPUTE
+    // environments beyond the LDS tables: sqrt(count) is computed (rsq seed + Goldschmidt, <= 1 ulp from the table value)
+    // instead of being fetched from the 65536-entry global tables -- four dependent L2 round trips per event otherwise
+    auto sqrt_cnt = [&](int cnt) -> double { if constexpr (LDSTAB) return t_sqrt[cnt]; else return sqrt_unit((double)cnt); };
+    auto rsqrt_cnt = [&](int cnt) -> double {
+        if constexpr (LDSTAB) return t_rsqrt[cnt];
+        else {
+            const double x = (double)cnt;
+            double y = __builtin_amdgcn_rsq(x);
+            y = y * fma(-0.5 * x, y * y, 1.5);
+            y = y * fma(-0.5 * x, y * y, 1.5);
+            return y;
+        }
+    };
+#else
     auto sqrt_cnt = [&](int cnt) -> double { if constexpr (LDSTAB) return t_sqrt[cnt]; else return g_sqrt[cnt]; };
     auto rsqrt_cnt = [&](int cnt) -> double { if constexpr (LDSTAB) return t_rsqrt[cnt]; else return g_rsqrt[cnt]; };
+#endif
     // sqrt of the weighted count of category c (c may be dynamic)
     auto root_of = [&](int c, int cnt) -> double {
         if constexpr (MODE == MODE_H2W) return sqrt_cnt(cnt) * sw_s[c & 31];
