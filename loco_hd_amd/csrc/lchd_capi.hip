@@ -169,6 +169,7 @@ struct lchd_ctx {
     DeviceStatus* h_status = nullptr;  // pinned
     unsigned long long* d_points = nullptr;
     double* d_tabs = nullptr;  // sqrt(k) | 1/sqrt(k), 65536 entries each
+    uint32_t* d_partials = nullptr;  // scratch of k_pair_meta (kMetaPartials words)
     int cap_hint = 512;
     // timing
     bool timing = false;
@@ -232,6 +233,7 @@ extern "C" int lchd_ctx_create(int32_t device, lchd_ctx** out) {
     HIP_TRY(hipMalloc(&c->d_points, sizeof(unsigned long long)));
     HIP_TRY(hipHostMalloc(&c->h_status, sizeof(DeviceStatus)));
     HIP_TRY(hipMalloc(&c->d_tabs, sizeof(double) * 2 * 65536));
+    HIP_TRY(hipMalloc(&c->d_partials, sizeof(uint32_t) * kMetaPartials));
     launch_fill_sqrt_tables(c->stream, c->d_tabs, c->d_tabs + 65536);
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (auto& ev : c->ev) HIP_TRY(hipEventCreate(&ev));
@@ -248,6 +250,7 @@ extern "C" void lchd_ctx_destroy(lchd_ctx* c) {
     (void)hipFree(c->d_status);
     (void)hipFree(c->d_points);
     (void)hipFree(c->d_tabs);
+    (void)hipFree(c->d_partials);
     (void)hipHostFree(c->h_status);
     for (auto& ev : c->ev) (void)hipEventDestroy(ev);
     delete c;
@@ -646,6 +649,7 @@ static int prims_enqueue(lchd_ctx* c) {
     sw.sqrt_tab = c->d_tabs;
     sw.rsqrt_tab = c->d_tabs + 65536;
     sw.meta = pair_meta;
+    sw.partials = c->d_partials;
     launch_sweep(s, c->h_cfg.n_categories, c->hellinger2, c->unit_weights, c->wf_pow, sw);
     mark(c, 4);
     if (a->ev_used) { HIP_TRY(hipEventRecord(a->ev_used, s)); a->used_valid = true; }
@@ -958,6 +962,7 @@ static int sweep_rows(lchd_ctx* c, const EnvStore& ea, const EnvStore& eb, const
     sw.sqrt_tab = c->d_tabs;
     sw.rsqrt_tab = c->d_tabs + 65536;
     sw.meta = d_meta;
+    sw.partials = c->d_partials;
     launch_sweep(c->stream, c->h_cfg.n_categories, c->hellinger2, c->unit_weights, c->wf_pow, sw);
     mark(c, 4);
     HIP_TRY(hipGetLastError());

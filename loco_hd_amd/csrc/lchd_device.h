@@ -9,6 +9,7 @@ namespace lchd {
 constexpr int kMaxCategories = 255;   // categories travel as u8 on the device
 constexpr int kSweepEPL = 6;          // merged events per lane per tile in the sweep kernel
 constexpr int kSweepTile = 64 * kSweepEPL;
+constexpr int kMetaPartials = 4096;   // workgroups of k_pair_meta (one partial count each)
 constexpr uint64_t kPadKey = ~0ull;   // sorts after every valid (non-negative, non-NaN) f64 bit pattern
 
 // status word written by kernels (device memory, zeroed per call)
@@ -27,6 +28,7 @@ struct DeviceStatus {
     uint32_t max_env;        // largest environment seen (for the overflow retry)
     uint32_t n_unique[2];    // unique anchors per side
     unsigned long long env_points;  // sum over pairs of n_A + n_B
+    unsigned long long n_small;     // pairs with at most kDuoTile merged events (k_pair_meta): who sweeps them is decided on the device
 };
 
 struct WfEntry {
@@ -126,6 +128,8 @@ struct SweepArgs {
     const double* sqrt_tab;   // [65536] sqrt(k), context-owned
     const double* rsqrt_tab;  // [65536] 1/sqrt(k)
     int4* meta;               // [P] workspace: per-pair records written by k_pair_meta, read by the sweep kernels
+    uint32_t* partials;       // [kMetaPartials] context-owned scratch of k_pair_meta
+    int32_t duo_enabled;      // set by launch_sweep: k_sweep_duo was launched too and sweeps the small pairs when they are the majority
 };
 void launch_sweep(hipStream_t s, int n_categories, bool hellinger2, bool unit_weights, bool wf_pow, const SweepArgs& a);
 // trajectory frames: replicate the template's labels / unpack [frames][atoms][3] into SoA + bounding box keys

@@ -894,6 +894,7 @@ enum { F_KEY = 0, F_FAST = 1, F_ANY = 2 };
 #ifndef LCHD_SWEEP_MINW
 #define LCHD_SWEEP_MINW 2
 #endif
+constexpr int kDuoTileFwd = 224;  // = kDuoTile (k_sweep_duo, below)
 constexpr int kSqrtTab = 512;  // LDSTAB kernels: environments of at most 512 points, sqrt tables entirely in LDS
 constexpr int kSweepWaves = LCHD_SWEEP_WAVES;  // anchor pairs (wavefronts) per workgroup
 
@@ -996,7 +997,7 @@ __device__ unsigned long long g_sweep_stamps[8];
 #endif
 
 // register budget: 4 waves/SIMD (<= 128 VGPRs) up to 12 category slots, 3 (<= 168) up to 16, 2 beyond
-template <int CMAX, int MODE, int FMODE, bool LDSTAB>
+template <int CMAX, int MODE, int FMODE, bool LDSTAB, bool INDIRECT = false>
 __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 12 ? 4 : (CMAX <= LCHD_SWEEP_W3MAX ? 3 : 2)))) void k_sweep(SweepArgs args) {
     constexpr int EPL = kSweepEPL, TILE = kSweepTile, WPB = kSweepWaves;
     constexpr int NW = CMAX / 4;          // u64 words of 16-bit count fields per side
@@ -1008,6 +1009,14 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
     __shared__ double w_s[32], sw_s[32];
     __shared__ uint64_t sA_[WPB][TILE], sB_[WPB][TILE];
     __shared__ uint8_t cA_[WPB][TILE], cB_[WPB][TILE];
+    // When pairs with at most kDuoTile merged events are the majority of a launch, k_sweep_duo sweeps them two per wavefront
+    // and the INDIRECT instantiation of this kernel picks the remaining ones out of the pair records; otherwise the plain
+    // instantiation sweeps everything.  All three decide from the same word (k_pair_meta: DeviceStatus::n_small).
+    {
+        const bool duo_active = 2 * args.st->n_small >= (unsigned long long)args.n_pairs;
+        if constexpr (INDIRECT) { if (!duo_active) return; }
+        else { if (args.duo_enabled && duo_active) return; }
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform => everything derived from it stays scalar
     const DevConfig* __restrict__ cfgp = args.cfg;
@@ -1064,21 +1073,50 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
     const double* __restrict__ finf_tab = cfgp->wf_finf;
     const double Finf0 = finf_tab[0];
     const int64_t pstride = (int64_t)gridDim.x * WPB;
-    int64_t p = (int64_t)blockIdx.x * WPB + wv;
+    const int64_t total = args.n_pairs;
+    int64_t q = (int64_t)blockIdx.x * WPB + wv;
     // the record lives in four scalar registers; the next one is moved there as soon as its (early) load has returned, so the
     // loop's back edge never waits on vector memory (in particular not on the score store of the pair just finished)
     int mx, my, mz, mw;
     {
-        const int4 m0 = args.meta[p < args.n_pairs ? p : 0];
+        const int4 m0 = args.meta[q < total ? q : 0];
         mx = __builtin_amdgcn_readfirstlane(m0.x); my = __builtin_amdgcn_readfirstlane(m0.y);
         mz = __builtin_amdgcn_readfirstlane(m0.z); mw = __builtin_amdgcn_readfirstlane(m0.w);
     }
     int nx = mx, ny = my, nz = mz, nw = mw;
-    for (; p < args.n_pairs; p += pstride, mx = nx, my = ny, mz = nz, mw = nw) {
-        const int4 mn = args.meta[p + pstride < args.n_pairs ? p + pstride : p];
+    // INDIRECT: the wave walks blocks of 64 consecutive pairs, every lane holding one record; the pairs that are too large for
+    // k_sweep_duo are picked out of a block with a ballot and swept one after the other (the plain instantiation folds all of
+    // this away and keeps its one-record-ahead loop)
+    int64_t blk = (int64_t)blockIdx.x * WPB + wv, p_cur = 0;
+    unsigned long long todo = 0;
+    int4 mm = make_int4(0, 0, 0, 0);
+    bool ok = true;
+    auto advance = [&]() -> bool {
+        while (todo == 0) {
+            if (blk * 64 >= total) return false;
+            const int64_t pp = blk * 64 + lane;
+            mm = pp < total ? args.meta[pp] : make_int4(0, 0, 0, 0);
+            todo = __ballot((mm.z & 0xFFFFFF) > 0 && (mm.z & 0xFFFFFF) + (mm.w & 0xFFFFFF) - 2 > kDuoTileFwd);
+            p_cur = blk * 64;
+            blk += pstride;
+        }
+        const int b = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        p_cur = (p_cur & ~(int64_t)63) + b;
+        mx = __builtin_amdgcn_readlane(mm.x, b); my = __builtin_amdgcn_readlane(mm.y, b);
+        mz = __builtin_amdgcn_readlane(mm.z, b); mw = __builtin_amdgcn_readlane(mm.w, b);
+        return true;
+    };
+    if constexpr (INDIRECT) ok = advance();
+    for (; INDIRECT ? ok : (q < total);
+         INDIRECT ? (void)(ok = advance()) : (void)(q += pstride, mx = nx, my = ny, mz = nz, mw = nw)) {
+        const int64_t p = INDIRECT ? p_cur : q;
+        const int4 mn = INDIRECT ? make_int4(0, 0, 0, 0) : args.meta[q + pstride < total ? q + pstride : q];
         auto take_next = [&]() {
-            nx = __builtin_amdgcn_readfirstlane(mn.x); ny = __builtin_amdgcn_readfirstlane(mn.y);
-            nz = __builtin_amdgcn_readfirstlane(mn.z); nw = __builtin_amdgcn_readfirstlane(mn.w);
+            if constexpr (!INDIRECT) {
+                nx = __builtin_amdgcn_readfirstlane(mn.x); ny = __builtin_amdgcn_readfirstlane(mn.y);
+                nz = __builtin_amdgcn_readfirstlane(mn.z); nw = __builtin_amdgcn_readfirstlane(mn.w);
+            }
         };
         const int nA = mz & 0xFFFFFF, nB = mw & 0xFFFFFF;
         if (nA <= 0 || nB <= 0) {  // anchor out of range (flagged by k_mark_anchors) or overflow / empty environment (flagged by K1)
@@ -1438,6 +1476,234 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// K2 for small environments: TWO anchor pairs per wavefront, 32 lanes each.
+//
+// With environments of ~70-100 points per side (coarse-grained typing, the reference's main use) a pair has ~150 merged
+// events: one wavefront per pair spends most of its instructions on the per-tile prologue (staging, merge path, scan, state
+// reload, reduction), all of them executed for 64 lanes of which a third idle.  Here every wave-wide instruction serves two
+// pairs.  A pair qualifies if it has at most kDuoTile merged events (exactly one tile, no carries between tiles); the
+// configuration must be Hellinger-2 with unit category weights, CDF-keyed environments, at most 16 category slots.  The
+// host launches this kernel AND k_sweep; k_pair_meta counts the qualifying pairs (DeviceStatus::n_small): when they are
+// the majority this kernel sweeps them and k_sweep only the rest, otherwise this kernel returns at once.
+// ------------------------------------------------------------------------------------------------
+constexpr int kDuoTile = 224;  // merged events per pair: 32 lanes x 7 (two teams x four waves + the tables = 40 704 B: 4 workgroups/CU)
+__device__ __forceinline__ uint32_t half_incl_scan_u32(uint32_t x) {  // inclusive scan inside each 32-lane half
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    return (uint32_t)v;
+}
+__device__ __forceinline__ uint64_t half_incl_scan_fields(uint64_t x) {
+    const uint32_t lo = half_incl_scan_u32((uint32_t)x), hi = half_incl_scan_u32((uint32_t)(x >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ double half_sum_f64(double v) {  // lanes 31 and 63 end up with the sum of their half
+    v += dpp_mov_f64_or_zero<0x111, 0xf>(v);
+    v += dpp_mov_f64_or_zero<0x112, 0xf>(v);
+    v += dpp_mov_f64_or_zero<0x114, 0xf>(v);
+    v += dpp_mov_f64_or_zero<0x118, 0xf>(v);
+    v += dpp_mov_f64_or_zero<0x142, 0xa>(v);
+    return v;
+}
+
+template <int CMAX>
+__global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs args) {
+    constexpr int EPL = kDuoTile / 32, TILE = kDuoTile, WPB = kSweepWaves;
+    constexpr int NW = CMAX / 4;  // u64 words of 16-bit count fields per side (CMAX <= 16: one word of 4-bit fields)
+    static_assert(kDuoTile == kDuoTileFwd && EPL <= 15, "4-bit chunk-local counters");
+    constexpr int NT = kSqrtTab + 8;
+    __shared__ double t_sqrt[NT], t_rsqrt[NT];
+    __shared__ uint64_t sA_[WPB][2][TILE], sB_[WPB][2][TILE];
+    __shared__ uint8_t cA_[WPB][2][TILE], cB_[WPB][2][TILE];
+    if (2 * args.st->n_small < (unsigned long long)args.n_pairs) return;  // mostly larger pairs: k_sweep sweeps everything
+    const int tid = threadIdx.x, lane = tid & 63, tl = lane & 31, team = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const DevConfig* __restrict__ cfgp = args.cfg;
+    const int C = cfgp->n_categories;
+    const double Finf0 = cfgp->wf_finf[0];
+    for (int k = tid; k < NT; k += 64 * WPB) {
+        t_sqrt[k] = args.sqrt_tab[k];
+        t_rsqrt[k] = args.rsqrt_tab[k];
+    }
+    __syncthreads();
+    uint64_t* sA = sA_[wv][team];
+    uint64_t* sB = sB_[wv][team];
+    uint8_t* cA = cA_[wv][team];
+    uint8_t* cB = cB_[wv][team];
+    auto field = [&](const uint64_t (&ex)[NW], int c) -> int { return (int)((ex[c >> 2] >> ((c & 3) * 16)) & 0xFFFFull); };
+
+    const int64_t pstride = (int64_t)gridDim.x * WPB * 2;
+    for (int64_t pb = ((int64_t)blockIdx.x * WPB + wv) * 2; pb < args.n_pairs; pb += pstride) {
+        const int64_t p = pb + team;
+        const bool live = p < args.n_pairs;
+        const int4 m = args.meta[live ? p : pb];
+        const bool usable = live && (m.z & 0xFFFFFF) > 0 && (m.w & 0xFFFFFF) > 0;
+        const bool mine = !usable || (m.z & 0xFFFFFF) + (m.w & 0xFFFFFF) - 2 <= TILE;  // larger pairs belong to k_sweep
+        const bool valid = usable && mine;
+        const int mA = valid ? (m.z & 0xFFFFFF) - 1 : 0, mB = valid ? (m.w & 0xFFFFFF) - 1 : 0, T = mA + mB;  // non-anchor events
+        const int c0a = (m.z >> 24) & 255, c0b = (m.w >> 24) & 255;
+        const uint64_t* __restrict__ kA = args.env_a.key + (int64_t)m.x * args.env_a.stride;
+        const uint64_t* __restrict__ kB = args.env_b.key + (int64_t)m.y * args.env_b.stride;
+        const uint8_t* __restrict__ tA = args.env_a.cat + (int64_t)m.x * args.env_a.stride;
+        const uint8_t* __restrict__ tB = args.env_b.cat + (int64_t)m.y * args.env_b.stride;
+        bool bad_cat = valid && (c0a >= C || c0b >= C);
+        const double F0 = valid ? u2d(kA[0]) : 0.0;            // F(0): both anchors sit at distance 0
+        const double H0 = (c0a == c0b) ? 0.0 : 1.0;            // two point masses
+
+        wave_sync_lds();  // the previous pairs' tiles are fully consumed
+        {
+            uint64_t rkA[EPL], rkB[EPL];
+            uint8_t rcA[EPL], rcB[EPL];
+#pragma unroll
+            for (int u = 0; u < EPL; ++u) {
+                const int t = tl + 32 * u;
+                rkA[u] = t < mA ? kA[1 + t] : 0ull;
+                rcA[u] = t < mA ? tA[1 + t] : (uint8_t)0;
+            }
+#pragma unroll
+            for (int u = 0; u < EPL; ++u) {
+                const int t = tl + 32 * u;
+                rkB[u] = t < mB ? kB[1 + t] : 0ull;
+                rcB[u] = t < mB ? tB[1 + t] : (uint8_t)0;
+            }
+#pragma unroll
+            for (int u = 0; u < EPL; ++u) {
+                const int t = tl + 32 * u;
+                if (t < mA) { sA[t] = rkA[u]; cA[t] = rcA[u]; }
+            }
+#pragma unroll
+            for (int u = 0; u < EPL; ++u) {
+                const int t = tl + 32 * u;
+                if (t < mB) { sB[t] = rkB[u]; cB[t] = rcB[u]; }
+            }
+        }
+        wave_sync_lds();
+
+        // lane tl of a team owns merged events [d0, d1) of its pair
+        const int epl = (T + 31) >> 5;  // <= EPL
+        const int d0 = min(tl * epl, T), d1 = min(d0 + epl, T);
+        const int i1 = merge_path(sA, mA, sB, mB, d1);
+        int i0 = __builtin_amdgcn_update_dpp(i1, i1, 0x138, 0xf, 0xf, false);  // wave_shr:1
+        if (tl == 0) i0 = 0;
+        const int j0 = d0 - i0, j1 = d1 - i1;
+
+        // pass 1: 4-bit-per-category histogram of the lane's chunk
+        uint64_t hA = 0, hB = 0;
+        for (int i = i0; i < i1; ++i) {
+            const int ct = cA[i];
+            if (ct >= C) bad_cat = true;
+            hA += 1ull << ((ct & 15) * 4);
+        }
+        for (int j = j0; j < j1; ++j) {
+            const int ct = cB[j];
+            if (ct >= C) bad_cat = true;
+            hB += 1ull << ((ct & 15) * 4);
+        }
+        // packed counts at the start of the chunk: the anchors + an exclusive scan over the team's lanes
+        uint64_t exA[NW], exB[NW];
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const uint64_t va_ = spread4(hA >> (16 * k)), vb_ = spread4(hB >> (16 * k));
+            const uint64_t sa_ = half_incl_scan_fields(va_), sb_ = half_incl_scan_fields(vb_);
+            exA[k] = (((c0a >> 2) == k) ? (1ull << ((c0a & 3) * 16)) : 0ull) + sa_ - va_;
+            exB[k] = (((c0b >> 2) == k) ? (1ull << ((c0b & 3) * 16)) : 0ull) + sb_ - vb_;
+        }
+        int totA = 1 + i0, totB = 1 + j0;
+        double D = 0.0;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const int c = 4 * k + f;
+                D += t_sqrt[field(exA, c)] * t_sqrt[field(exB, c)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        double ra = t_rsqrt[totA], rb = t_rsqrt[totB];
+
+        // pass 2 (same scheme as k_sweep): both list heads in registers, chunk-local additions in 4-bit fields
+        int i = i0, j = j0;
+        uint64_t ka = (i < i1) ? sA[i] : kPadKey, kb = (j < j1) ? sB[j] : kPadKey;
+        uint64_t dA = 0, dB = 0;
+        double Fp = 0.0, Hp = 0.0, firstF = 0.0, local = 0.0;
+        const int epl_w = max(__builtin_amdgcn_readlane(epl, 0), __builtin_amdgcn_readlane(epl, 32));  // wave-uniform trip count
+        for (int e = 0; e < epl_w; ++e) {
+            if (d0 + e < d1) {
+                const bool takeA = (ka <= kb);
+                const uint64_t key = takeA ? ka : kb;
+                const int ct = (takeA ? cA : cB)[takeA ? i : j];
+                i += takeA ? 1 : 0;
+                j += takeA ? 0 : 1;
+                {
+                    const int nidx = takeA ? i : j, nend = takeA ? i1 : j1;
+                    const uint64_t nk = (takeA ? sA : sB)[min(nidx, TILE - 1)];
+                    const uint64_t nh = nidx < nend ? nk : kPadKey;
+                    ka = takeA ? nh : ka;
+                    kb = takeA ? kb : nh;
+                }
+                const double F = u2d(key);
+                if (e == 0) firstF = F; else local += (F - Fp) * Hp;
+                totA += takeA ? 1 : 0;
+                totB += takeA ? 0 : 1;
+                const int sh = (ct & 3) * 16, sh4 = (ct & 15) * 4;
+                uint64_t wA = 0, wB = 0;
+#pragma unroll
+                for (int k = 0; k < NW; ++k) {
+                    const bool hit = ((ct >> 2) == k);
+                    wA = hit ? exA[k] : wA;
+                    wB = hit ? exB[k] : wB;
+                }
+                const int cntA_ = (int)((wA >> sh) & 0xFFFFull) + (int)((dA >> sh4) & 15ull);  // before the update
+                const int cntB_ = (int)((wB >> sh) & 0xFFFFull) + (int)((dB >> sh4) & 15ull);
+                const uint64_t inc4 = (ct < C) ? (1ull << sh4) : 0ull;
+                dA += takeA ? inc4 : 0ull;
+                dB += takeA ? 0ull : inc4;
+                const int mine = takeA ? cntA_ : cntB_, other = takeA ? cntB_ : cntA_;
+                D += (t_sqrt[mine + 1] - t_sqrt[mine]) * t_sqrt[other];
+                const double r = t_rsqrt[takeA ? totA : totB];
+                ra = takeA ? r : ra;
+                rb = takeA ? rb : r;
+                double h2 = 1.0 - (ra * rb) * D;
+                if (h2 < 1e-3) {  // literal difference-of-roots form where the cancellation form loses accuracy (k_sweep::exact_h2)
+                    double acc2 = 0.0;
+#pragma unroll
+                    for (int k = 0; k < NW; ++k) {
+#pragma unroll
+                        for (int f = 0; f < 4; ++f) {
+                            const int c = 4 * k + f;
+                            const int ca = field(exA, c) + (int)((dA >> (c * 4)) & 15ull);
+                            const int cb = field(exB, c) + (int)((dB >> (c * 4)) & 15ull);
+                            const double dd = t_sqrt[ca] * ra - t_sqrt[cb] * rb;
+                            acc2 = fma(dd, dd, acc2);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    h2 = 0.5 * acc2;
+                }
+                Hp = sqrt_unit(h2);
+                Fp = F;
+            }
+        }
+        // stitch the lane chunks of a team, add the last interval to +inf, reduce over the team
+        double prevF = wave_shr1_f64(Fp), prevH = wave_shr1_f64(Hp);
+        if (tl == 0) { prevF = F0; prevH = H0; }
+        if (d0 < d1) local += (firstF - prevF) * prevH;
+        const int last = T > 0 ? (T - 1) / epl : 0;  // the team lane that holds the last event (lane 0 if there is none)
+        if (tl == last) local += (T > 0) ? (Finf0 - Fp) * Hp : (Finf0 - F0) * H0;
+        const double acc = half_sum_f64(local);
+        const unsigned long long anybad = __ballot(bad_cat);
+        const bool team_bad = ((team ? (anybad >> 32) : anybad) & 0xFFFFFFFFull) != 0;
+        if (tl == 31 && live && mine) {
+            if (team_bad) atomicOr(&args.st->flags, ST_BAD_CATEGORY);
+            args.out[p] = (valid && !team_bad) ? acc : nan("");
+        }
+    }
+}
+
 constexpr int kWideMaxCat = 256;
 
 // Many-categories variant (32 < C <= 255): the per-lane category counts live in LDS columns instead of registers, all
@@ -1769,6 +2035,7 @@ static void launch_sweep_wide(hipStream_t s, int n_cat, int64_t n_pairs, int fmo
 // n_B | category of anchor B << 24}; n = 0 marks a pair the sweep must answer with NaN (anchor index out of range -- already
 // flagged by k_mark_anchors -- or an environment that overflowed / is empty -- flagged by K1).
 __global__ void k_pair_meta(SweepArgs args) {
+    int n_small = 0;
     for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < args.n_pairs; p += (int64_t)gridDim.x * blockDim.x) {
         int64_t ea = p, eb = p;
         bool ok = true;
@@ -1789,14 +2056,36 @@ __global__ void k_pair_meta(SweepArgs args) {
             }
         }
         args.meta[p] = make_int4((int)ea, (int)eb, nA | (c0a << 24), nB | (c0b << 24));
+        // pairs k_sweep_duo takes: everything that fits its tile, and the unusable ones (it writes their NaN)
+        n_small += (nA + nB - 2 <= kDuoTileFwd) ? 1 : 0;
     }
+    // pairs that fit one 32-lane tile: if they are the majority, k_sweep_duo sweeps them and k_sweep only the rest.  One
+    // partial count per workgroup, summed by k_pair_meta_sum: thousands of atomics on one word would cost more than this kernel
+    __shared__ int part_s[4];
+    for (int m = 32; m > 0; m >>= 1) n_small += __shfl_xor(n_small, m);
+    if ((threadIdx.x & 63) == 0) part_s[threadIdx.x >> 6] = n_small;
+    __syncthreads();
+    if (threadIdx.x == 0) args.partials[blockIdx.x] = (uint32_t)(part_s[0] + part_s[1] + part_s[2] + part_s[3]);
+}
+__global__ __launch_bounds__(256) void k_pair_meta_sum(const uint32_t* __restrict__ partials, int n, DeviceStatus* st) {
+    __shared__ unsigned long long red[4];
+    unsigned long long v = 0;
+    for (int i = threadIdx.x; i < n; i += 256) v += partials[i];
+    for (int m = 32; m > 0; m >>= 1) v += shfl_u64(v, (threadIdx.x & 63) ^ m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) st->n_small = red[0] + red[1] + red[2] + red[3];
 }
 
-void launch_sweep(hipStream_t s, int n_categories, bool hellinger2, bool unit_weights, bool wf_pow, const SweepArgs& a) {
-    if (a.n_pairs <= 0) return;
+void launch_sweep(hipStream_t s, int n_categories, bool hellinger2, bool unit_weights, bool wf_pow, const SweepArgs& a_in) {
+    if (a_in.n_pairs <= 0) return;
+    SweepArgs a = a_in;
+    a.duo_enabled = 0;
     {
         const int64_t nb = (a.n_pairs + 255) / 256;
-        k_pair_meta<<<(unsigned)(nb < 4096 ? nb : 4096), 256, 0, s>>>(a);
+        const int mgrid = (int)(nb < kMetaPartials ? nb : kMetaPartials);
+        k_pair_meta<<<mgrid, 256, 0, s>>>(a);
+        k_pair_meta_sum<<<1, 256, 0, s>>>(a.partials, mgrid, a.st);
     }
     {
         bool wide = n_categories > 32;
@@ -1819,6 +2108,18 @@ void launch_sweep(hipStream_t s, int n_categories, bool hellinger2, bool unit_we
     bool small = a.env_a.stride <= kSqrtTab && a.env_b.stride <= kSqrtTab;  // every count fits the LDS tables
     if (const char* f = getenv("LCHD_FORCE_BIGENV")) small = small && atoi(f) == 0;  // test hook
     const int fmode = (a.env_a.cdf_keys && a.env_b.cdf_keys) ? F_KEY : (wf_pow ? F_ANY : F_FAST);
+    if (hellinger2 && unit_weights && small && fmode == F_KEY && cmax <= 16 && !a.wf_index && !getenv("LCHD_NO_DUO")) {
+        // small environments: two pairs per wavefront; both kernels are launched, the device-side maximum of merged events
+        // per pair (k_pair_meta) decides which of them does the work
+        a.duo_enabled = 1;
+        const int64_t dblocks = (a.n_pairs + 2 * kSweepWaves - 1) / (2 * kSweepWaves);
+        const unsigned dgrid = (unsigned)(dblocks < 4096 ? dblocks : 4096);
+        const unsigned bgrid = grid < 1024 ? grid : 1024;  // the listed (larger) pairs are a minority whenever this launch does anything
+        constexpr int NTH = 64 * kSweepWaves;
+        if (cmax <= 8) { k_sweep_duo<8><<<dgrid, NTH, 0, s>>>(a); k_sweep<8, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+        else if (cmax <= 12) { k_sweep_duo<12><<<dgrid, NTH, 0, s>>>(a); k_sweep<12, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+        else { k_sweep_duo<16><<<dgrid, NTH, 0, s>>>(a); k_sweep<16, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+    }
     if (!hellinger2) launch_sweep_f<MODE_GEN, false>(s, cmax, grid, fmode, a);
     else if (unit_weights) {
         if (small) launch_sweep_f<MODE_H2U, true>(s, cmax, grid, fmode, a);
