@@ -292,3 +292,43 @@ def test_from_primitives_batch_matches_single_calls(lh, oracle):
         lchd.from_primitives_batch(ps, [(0, 4, [(0, 500)])], 10.0)
     with pytest.raises(IndexError):
         lchd.from_primitives_batch(ps, [(0, 9, cent)], 10.0)
+
+
+def test_small_pair_kernel_with_a_minority_of_large_pairs(lh, oracle, monkeypatch):
+    """k_sweep_duo (two pairs per wavefront) takes the pairs with <= 224 merged events when they are the majority; the
+    INDIRECT instantiation of k_sweep picks the larger ones out of the pair records.  A sparse cloud with one dense blob gives
+    both kinds in one call; a second cloud (mostly dense) makes the small pairs a minority, where the plain kernel must do
+    everything.  Checked against the oracle and against the same call with the small-pair kernel disabled."""
+    rng = np.random.default_rng(21)
+    cats = ["a", "b", "c", "d", "e", "f"]
+
+    def cloud(n_sparse, n_dense):
+        pts = np.concatenate([rng.uniform(0, 60, (n_sparse, 3)), rng.normal(30, 3.0, (n_dense, 3))])
+        return [cats[i] for i in rng.integers(0, 6, len(pts))], pts
+
+    for n_sparse, n_dense, expect_small_majority in ((3000, 260, True), (300, 900, False)):
+        sa, xa = cloud(n_sparse, n_dense)
+        sb, xb = cloud(n_sparse, n_dense)
+        n = len(xa)
+        anchors = [(i, int(j)) for i, j in zip(range(n), rng.permutation(n))] + [(5, 5), (n - 1, n - 1)]
+
+        def run(mod):
+            lchd = mod.LoCoHD(cats, mod.WeightFunction("hyper_exp", [1.0, 0.25]))
+            pa = [mod.PrimitiveAtom(t, "", c) for t, c in zip(sa, xa)]
+            pb = [mod.PrimitiveAtom(t, "", c) for t, c in zip(sb, xb)]
+            if mod is oracle:
+                out, sizes = lchd.from_primitives(pa, pb, anchors, 8.0, return_env_sizes=True)
+                return np.asarray(out), np.asarray(sizes)
+            return np.asarray(lchd.from_primitives(pa, pb, anchors, 8.0)), None
+
+        want, sizes = run(oracle)
+        events = sizes.sum(axis=1) - 2 if sizes.ndim == 2 else None
+        if events is not None:  # the intended mix of pair sizes
+            small = np.mean(events <= 224)
+            assert (small >= 0.5) == expect_small_majority and 0.02 < small < 0.98, small
+        got, _ = run(lh)
+        assert np.max(np.abs(got - want)) < TIGHT
+        monkeypatch.setenv("LCHD_NO_DUO", "1")
+        plain, _ = run(lh)
+        monkeypatch.delenv("LCHD_NO_DUO")
+        assert np.max(np.abs(got - plain)) < 1e-13
