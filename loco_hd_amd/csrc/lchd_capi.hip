@@ -129,6 +129,7 @@ struct lchd_cloud {
     int32_t* tag = nullptr;
     int32_t* sid = nullptr;  // batch of structures: structure id per atom (nullptr = one structure)
     int32_t n_struct = 1;
+    int32_t struct_size = 0;  // > 0: structure k is atoms [k * struct_size, (k + 1) * struct_size)
     int64_t n = 0;
     // trajectory-frames buffer (lchd_frames_create): capacity, staging and cross-stream hand-off
     int64_t n_tmpl = 0;        // atoms per frame
@@ -147,7 +148,7 @@ struct lchd_cloud {
     hipEvent_t ev_ready = nullptr, ev_used = nullptr;
     bool bbox_pending = false, used_valid = false;
     double bbmin[3] = {0, 0, 0}, bbmax[3] = {0, 0, 0};
-    CloudView view() const { return CloudView{x, y, z, cat, tag, (int32_t)n, sid, n_struct}; }
+    CloudView view() const { return CloudView{x, y, z, cat, tag, (int32_t)n, sid, n_struct, sid ? struct_size : 0}; }
 };
 
 enum { PH_CELLS = 0, PH_ANCHORS = 1, PH_ENV = 2, PH_SWEEP = 3, PH_N = 4 };
@@ -420,6 +421,12 @@ extern "C" int lchd_cloud_create_batch(lchd_ctx* c, const double* xyz, const int
     lchd_cloud* cl = nullptr;
     if (int rc = lchd_cloud_create(c, xyz, cat, tag, n, &cl)) return rc;
     cl->n_struct = n_struct;
+    if (n && n % n_struct == 0 && n / n_struct <= INT32_MAX) {  // regular batch: equal-sized structures stored one after the other?
+        const int64_t k = n / n_struct;
+        bool regular = true;
+        for (int64_t i = 0; i < n && regular; ++i) regular = sid[i] == (int32_t)(i / k);
+        cl->struct_size = regular ? (int32_t)k : 0;
+    }
     if (n) {
         hipError_t e = hipMalloc(&cl->sid, sizeof(int32_t) * n);
         if (e == hipSuccess) e = hipMemcpy(cl->sid, sid, sizeof(int32_t) * n, hipMemcpyHostToDevice);
@@ -724,6 +731,7 @@ extern "C" int lchd_frames_create(lchd_ctx* c, const lchd_cloud* tmpl, int32_t c
     if (nt < 1 || total > ((int64_t)1 << 30)) return fail(LCHD_EUNSUPPORTED, "frames buffer of %lld atoms is out of range", (long long)total);
     lchd_cloud* cl = new lchd_cloud();
     cl->n_tmpl = nt;
+    cl->struct_size = (int32_t)nt;
     cl->cap_frames = capacity_frames;
     cl->n = 0;
     cl->n_struct = 1;

@@ -58,6 +58,7 @@ struct CloudView {
     int32_t n;
     const int32_t* sid;   // structure id per atom for a batch of structures (nullptr = one structure)
     int32_t n_struct;     // >= 1
+    int32_t struct_size;  // > 0: every structure is exactly this many CONSECUTIVE atoms (frames buffers, regular batches)
 };
 
 struct __attribute__((aligned(16))) CellRec {

@@ -226,8 +226,72 @@ static void launch_exclusive_scan(hipStream_t s, const uint32_t* in, uint32_t* o
     k_scan_apply<<<nb, 1024, 0, s>>>(in, out, n, tmp, nb, total_out);
 }
 
+// Batches of equal-sized structures (trajectory frames, regular batches): one workgroup builds the cell list of one structure
+// entirely in LDS -- histogram with returned ranks, scan, scatter -- instead of the five global passes (two of them with one
+// global atomic per atom) of the generic path.  Structure k owns cells [k * cps, (k + 1) * cps) and records
+// [k * size, (k + 1) * size).
+constexpr int kStructCellsMax = 4096, kStructAtomsMax = 12288;
+__global__ __launch_bounds__(256) void k_cell_build_struct(CloudView c, GridView g, int cps, CellRec* __restrict__ rec,
+                                                          uint32_t* __restrict__ pos_of, uint32_t* __restrict__ cell_start) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_cb[];  // hist[cps] u32 | cid[size] u16 | rank[size] u16
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem_cb);
+    uint16_t* cid = reinterpret_cast<uint16_t*>(smem_cb + (size_t)cps * 4);
+    uint16_t* rank_ = cid + c.struct_size;
+    __shared__ uint32_t wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int size = c.struct_size;
+    const int64_t base = (int64_t)blockIdx.x * size;
+    for (int k = tid; k < cps; k += 256) hist[k] = 0u;
+    __syncthreads();
+    for (int a = tid; a < size; a += 256) {
+        const int64_t i = base + a;
+        const int cx = cell_coord(c.x[i], g.min[0], g.inv[0], g.dim[0]);
+        const int cy = cell_coord(c.y[i], g.min[1], g.inv[1], g.dim[1]);
+        const int cz = cell_coord(c.z[i], g.min[2], g.inv[2], g.dim[2]);
+        const int cell = (cz * g.dim[1] + cy) * g.dim[0] + cx;
+        cid[a] = (uint16_t)cell;
+        rank_[a] = (uint16_t)atomicAdd(&hist[cell], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of hist[0 .. cps): thread t owns the cps/256 consecutive entries [t * per, (t + 1) * per)
+    const int per = (cps + 255) / 256, lo = min(tid * per, cps), hi = min(lo + per, cps);
+    uint32_t sum = 0;
+    for (int k = lo; k < hi; ++k) sum += hist[k];
+    const uint32_t incl = wave_incl_scan_u32(sum);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t pre = incl - sum;
+    for (int w = 0; w < wave; ++w) pre += wsum[w];
+    for (int k = lo; k < hi; ++k) {
+        const uint32_t h = hist[k];
+        hist[k] = pre;
+        cell_start[(int64_t)blockIdx.x * cps + k] = (uint32_t)base + pre;
+        pre += h;
+    }
+    if (blockIdx.x == gridDim.x - 1 && tid == 255) cell_start[(int64_t)gridDim.x * cps] = (uint32_t)(base + size);
+    __syncthreads();
+    for (int a = tid; a < size; a += 256) {
+        const int64_t i = base + a;
+        const uint32_t pos = (uint32_t)base + hist[cid[a]] + rank_[a];
+        CellRec r;
+        r.x = c.x[i];
+        r.y = c.y[i];
+        r.z = c.z[i];
+        r.tag = (uint32_t)c.tag[i];
+        r.cat = c.cat[i];
+        rec[pos] = r;
+        pos_of[i] = pos;
+    }
+}
+
 void launch_cell_build(hipStream_t s, const CloudView& c, GridView g, uint32_t* cell_of, uint32_t* cell_count,
                        uint32_t* cell_cursor, CellRec* rec, uint32_t* pos_of, uint32_t* cell_start, uint32_t* scan_tmp) {
+    const int cps = g.dim[0] * g.dim[1] * g.dim[2];
+    if (c.struct_size > 0 && c.n_struct >= 64 && c.struct_size <= kStructAtomsMax && cps <= kStructCellsMax &&
+        (int64_t)c.n_struct * c.struct_size == c.n && !getenv("LCHD_NO_STRUCT_CELLS")) {
+        k_cell_build_struct<<<c.n_struct, 256, (size_t)cps * 4 + (size_t)c.struct_size * 4, s>>>(c, g, cps, rec, pos_of, cell_start);
+        return;
+    }
     (void)hipMemsetAsync(cell_count, 0, sizeof(uint32_t) * (size_t)(g.n_cells + 1), s);
     (void)hipMemsetAsync(cell_cursor, 0, sizeof(uint32_t) * (size_t)(g.n_cells + 1), s);
     const int nb = (c.n + 255) / 256 > 4096 ? 4096 : (c.n + 255) / 256;
