@@ -636,8 +636,9 @@ static int prims_enqueue(lchd_ctx* c) {
     launch_anchor_dedupe(s, P.anchors, n_pairs, 0, (int32_t)a->n, sa.slot, sa.uniq, cva, sa.pos_of, c->d_status, sa.scan_tmp);
     launch_anchor_dedupe(s, P.anchors, n_pairs, 1, (int32_t)b->n, sb.slot, sb.uniq, cvb, sb.pos_of, c->d_status, sb.scan_tmp);
     mark(c, 2);
-    if (!launch_env_cells(s, cap, c->d_cfg, cva, gva, sa.uniq, 0, max_env_a, thr, sa.env, c->d_status) ||
-        !launch_env_cells(s, cap, c->d_cfg, cvb, gvb, sb.uniq, 1, max_env_b, thr, sb.env, c->d_status))
+    const bool tag_list = c->h_cfg.tag_mode != 0;
+    if (!launch_env_cells(s, cap, c->d_cfg, tag_list, cva, gva, sa.uniq, 0, max_env_a, thr, sa.env, c->d_status) ||
+        !launch_env_cells(s, cap, c->d_cfg, tag_list, cvb, gvb, sb.uniq, 1, max_env_b, thr, sb.env, c->d_status))
         return fail(LCHD_EUNSUPPORTED, "no environment kernel variant with capacity %d", cap);
     mark(c, 3);
     SweepArgs sw{};

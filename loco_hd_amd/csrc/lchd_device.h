@@ -108,7 +108,7 @@ void launch_anchor_dedupe(hipStream_t s, const int64_t* anchors, int64_t n_pairs
                           uint32_t* scan_tmp);
 
 // returns false if `cap` is not an available variant
-bool launch_env_cells(hipStream_t s, int cap, const DevConfig* cfg, const CloudView& c, const GridView& g,
+bool launch_env_cells(hipStream_t s, int cap, const DevConfig* cfg, bool tag_list, const CloudView& c, const GridView& g,
                       const AnchorRec* uniq, int side, int64_t max_envs, double thr, EnvStore env, DeviceStatus* st);
 
 // dense rows: either distances from coordinates (dmx == nullptr) or given rows (dmx != nullptr, leading dim ld)

@@ -466,7 +466,7 @@ __device__ unsigned long long g_env_stamps[8];
 #else
 #define ESTAMP(i) do { } while (0)
 #endif
-template <int NT>
+template <int NT, bool TAGLIST>  // TAGLIST: the tag rule is a pair list (binary searches); otherwise one comparison, no branch
 __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ cfgp, CloudView c, GridView g,
                                                   const AnchorRec* __restrict__ uniq, int side, double thr, int cap,
                                                   EnvStore env, DeviceStatus* st) {
@@ -488,6 +488,11 @@ __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ 
     const uint32_t apos = arec.apos;  // the anchor's own record in cell order
     const int asid = arec.sid;
     const double thr2 = thr * thr;
+    const bool accept_same = cfg.tag_accept_same != 0;
+    auto tag_ok = [&](int32_t t_other) -> bool {  // tag_pairing_rule.rs:49-75
+        if constexpr (TAGLIST) return tag_pair_accepted(cfg, atag, t_other);
+        else return (atag == t_other) == accept_same;
+    };
     const int cx = cell_coord(ax, g.min[0], g.inv[0], g.dim[0]);
     const int cy = cell_coord(ay, g.min[1], g.inv[1], g.dim[1]);
     const int cz = cell_coord(az, g.min[2], g.inv[2], g.dim[2]);
@@ -545,7 +550,7 @@ __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ 
                     d2 = d2 + dz * dz;
                     const uint64_t tc = d2u(R1[u].y);  // tag | cat << 32
                     bool ok = false;
-                    if (v && d2 < thr2) ok = ((uint32_t)idx[u] == apos) || tag_pair_accepted(cfg, atag, (int32_t)(uint32_t)tc);
+                    if (v && d2 < thr2) ok = ((uint32_t)idx[u] == apos) || tag_ok((int32_t)(uint32_t)tc);
                     const unsigned long long m = __ballot(ok);
                     if (ok) {
                         const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
@@ -576,7 +581,7 @@ __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ 
                     d2 = d2 + dy * dy;
                     d2 = d2 + dz * dz;
                     ccat = r.cat;
-                    if (d2 < thr2) ok = ((uint32_t)idx == apos) || tag_pair_accepted(cfg, atag, (int32_t)r.tag);
+                    if (d2 < thr2) ok = ((uint32_t)idx == apos) || tag_ok((int32_t)r.tag);
                 }
                 const unsigned long long m = __ballot(ok);
                 int wbase = 0;
@@ -703,24 +708,33 @@ __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ 
     ESTAMP(4);
 }
 
-bool launch_env_cells(hipStream_t s, int cap, const DevConfig* cfg, const CloudView& c, const GridView& g,
+template <int NT>
+static void launch_env_cells_nt(hipStream_t s, dim3 grid, size_t lds, bool tag_list, const DevConfig* cfg, const CloudView& c,
+                                const GridView& g, const AnchorRec* uniq, int side, double thr, int cap, EnvStore env, DeviceStatus* st) {
+    if (tag_list) k_env_cells<NT, true><<<grid, NT, lds, s>>>(cfg, c, g, uniq, side, thr, cap, env, st);
+    else k_env_cells<NT, false><<<grid, NT, lds, s>>>(cfg, c, g, uniq, side, thr, cap, env, st);
+}
+
+bool launch_env_cells(hipStream_t s, int cap, const DevConfig* cfg, bool tag_list, const CloudView& c, const GridView& g,
                       const AnchorRec* uniq, int side, int64_t max_envs, double thr, EnvStore env, DeviceStatus* st) {
     if (max_envs <= 0) return true;
     if (cap < 64 || cap > 16384 || (cap & (cap - 1))) return false;
     const dim3 grid((unsigned)max_envs);
     const size_t lds = (size_t)cap * 9;
     if (cap <= 2048) {
-        k_env_cells<64><<<grid, 64, lds + 16 + 257 * sizeof(uint32_t), s>>>(cfg, c, g, uniq, side, thr, cap, env, st);
+        launch_env_cells_nt<64>(s, grid, lds + 16 + 257 * sizeof(uint32_t), tag_list, cfg, c, g, uniq, side, thr, cap, env, st);
     } else if (cap <= 4096) {
-        k_env_cells<256><<<grid, 256, lds, s>>>(cfg, c, g, uniq, side, thr, cap, env, st);
+        launch_env_cells_nt<256>(s, grid, lds, tag_list, cfg, c, g, uniq, side, thr, cap, env, st);
     } else {
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_cells<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_cells<1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      16384 * 9);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_cells<1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       16384 * 9);
             attr_set = true;
         }
-        k_env_cells<1024><<<grid, 1024, lds, s>>>(cfg, c, g, uniq, side, thr, cap, env, st);
+        launch_env_cells_nt<1024>(s, grid, lds, tag_list, cfg, c, g, uniq, side, thr, cap, env, st);
     }
     return true;
 }
