@@ -287,10 +287,16 @@ __global__ __launch_bounds__(256) void k_cell_build_struct(CloudView c, GridView
 void launch_cell_build(hipStream_t s, const CloudView& c, GridView g, uint32_t* cell_of, uint32_t* cell_count,
                        uint32_t* cell_cursor, CellRec* rec, uint32_t* pos_of, uint32_t* cell_start, uint32_t* scan_tmp) {
     const int cps = g.dim[0] * g.dim[1] * g.dim[2];
-    if (c.struct_size > 0 && c.n_struct >= 64 && c.struct_size <= kStructAtomsMax && cps <= kStructCellsMax &&
-        (int64_t)c.n_struct * c.struct_size == c.n && !getenv("LCHD_NO_STRUCT_CELLS")) {
-        k_cell_build_struct<<<c.n_struct, 256, (size_t)cps * 4 + (size_t)c.struct_size * 4, s>>>(c, g, cps, rec, pos_of, cell_start);
-        return;
+    {   // one workgroup per structure: many structures of any (supported) size, or a few small ones -- a single structure of a
+        // few thousand atoms included, where one launch replaces two memsets and four to six small kernels
+        CloudView cs = c;
+        if (!c.sid) { cs.struct_size = c.n; cs.n_struct = 1; }
+        const bool fits = cs.struct_size > 0 && cs.struct_size <= kStructAtomsMax && cps <= kStructCellsMax &&
+                          (int64_t)cs.n_struct * cs.struct_size == c.n;
+        if (fits && (cs.n_struct >= 64 || cs.struct_size <= 4096) && !getenv("LCHD_NO_STRUCT_CELLS")) {
+            k_cell_build_struct<<<cs.n_struct, 256, (size_t)cps * 4 + (size_t)cs.struct_size * 4, s>>>(cs, g, cps, rec, pos_of, cell_start);
+            return;
+        }
     }
     (void)hipMemsetAsync(cell_count, 0, sizeof(uint32_t) * (size_t)(g.n_cells + 1), s);
     (void)hipMemsetAsync(cell_cursor, 0, sizeof(uint32_t) * (size_t)(g.n_cells + 1), s);
