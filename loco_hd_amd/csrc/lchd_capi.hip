@@ -633,12 +633,14 @@ static int prims_enqueue(lchd_ctx* c) {
     launch_cell_build(s, cva, gva, sa.cell_of, sa.cell_count, sa.cursor, sa.rec, sa.pos_of, sa.cell_start, sa.scan_tmp);
     launch_cell_build(s, cvb, gvb, sb.cell_of, sb.cell_count, sb.cursor, sb.rec, sb.pos_of, sb.cell_start, sb.scan_tmp);
     mark(c, 1);
-    launch_anchor_dedupe(s, P.anchors, n_pairs, 0, (int32_t)a->n, sa.slot, sa.uniq, cva, sa.pos_of, c->d_status, sa.scan_tmp);
-    launch_anchor_dedupe(s, P.anchors, n_pairs, 1, (int32_t)b->n, sb.slot, sb.uniq, cvb, sb.pos_of, c->d_status, sb.scan_tmp);
+    if (!launch_anchor_dedupe_small(s, P.anchors, n_pairs, cva, cvb, sa.pos_of, sb.pos_of, sa.slot, sb.slot, sa.uniq, sb.uniq, c->d_status)) {
+        launch_anchor_dedupe(s, P.anchors, n_pairs, 0, (int32_t)a->n, sa.slot, sa.uniq, cva, sa.pos_of, c->d_status, sa.scan_tmp);
+        launch_anchor_dedupe(s, P.anchors, n_pairs, 1, (int32_t)b->n, sb.slot, sb.uniq, cvb, sb.pos_of, c->d_status, sb.scan_tmp);
+    }
     mark(c, 2);
     const bool tag_list = c->h_cfg.tag_mode != 0;
-    if (!launch_env_cells(s, cap, c->d_cfg, tag_list, cva, gva, sa.uniq, 0, max_env_a, thr, sa.env, c->d_status) ||
-        !launch_env_cells(s, cap, c->d_cfg, tag_list, cvb, gvb, sb.uniq, 1, max_env_b, thr, sb.env, c->d_status))
+    const EnvSide esa{cva, gva, sa.uniq, sa.env, max_env_a}, esb{cvb, gvb, sb.uniq, sb.env, max_env_b};
+    if (!launch_env_cells(s, cap, c->d_cfg, tag_list, esa, esb, thr, c->d_status))
         return fail(LCHD_EUNSUPPORTED, "no environment kernel variant with capacity %d", cap);
     mark(c, 3);
     SweepArgs sw{};

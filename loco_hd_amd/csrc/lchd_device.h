@@ -107,9 +107,25 @@ void launch_anchor_dedupe(hipStream_t s, const int64_t* anchors, int64_t n_pairs
                           uint32_t* flag_then_slot, AnchorRec* uniq, const CloudView& c, const uint32_t* pos_of, DeviceStatus* st,
                           uint32_t* scan_tmp);
 
+// both sides in one launch when the inputs are small; returns false (nothing launched) otherwise
+bool launch_anchor_dedupe_small(hipStream_t s, const int64_t* anchors, int64_t n_pairs, const CloudView& ca, const CloudView& cb,
+                                const uint32_t* pos_a, const uint32_t* pos_b, uint32_t* slot_a, uint32_t* slot_b, AnchorRec* uniq_a,
+                                AnchorRec* uniq_b, DeviceStatus* st);
+
 // returns false if `cap` is not an available variant
-bool launch_env_cells(hipStream_t s, int cap, const DevConfig* cfg, bool tag_list, const CloudView& c, const GridView& g,
-                      const AnchorRec* uniq, int side, int64_t max_envs, double thr, EnvStore env, DeviceStatus* st);
+// one side of an environment-build launch (both structures are built by ONE launch: workgroups [0, a.max_envs) side A, the rest B)
+struct EnvSide {
+    CloudView c;
+    GridView g;
+    const AnchorRec* uniq;
+    EnvStore env;
+    int64_t max_envs;   // upper bound of the side's unique anchors (the kernel stops at DeviceStatus::n_unique[side])
+};
+struct EnvSides {
+    EnvSide s[2];
+};
+bool launch_env_cells(hipStream_t s, int cap, const DevConfig* cfg, bool tag_list, const EnvSide& a, const EnvSide& b, double thr,
+                      DeviceStatus* st);
 
 // dense rows: either distances from coordinates (dmx == nullptr) or given rows (dmx != nullptr, leading dim ld)
 bool launch_env_rows(hipStream_t s, int cap, const DevConfig* cfg, const CloudView& c, const double* dmx, int64_t ld,

@@ -331,6 +331,67 @@ __global__ void k_compact_anchors(const uint32_t* slot, int32_t n_points, Anchor
         }
 }
 
+// Small inputs (both structures <= kDedupeSmallPoints atoms, <= kDedupeSmallPairs pairs): one launch does flags, scan and
+// compaction of BOTH sides -- workgroup 0 side A, workgroup 1 side B, the flags never leave LDS -- instead of four operations
+// per side.  For a 1 000-atom structure pair the eight small launches cost more than the environment build.
+constexpr int kDedupeSmallPoints = 8192, kDedupeSmallPairs = 1 << 16;
+__global__ __launch_bounds__(1024) void k_anchor_dedupe_small(const int64_t* __restrict__ anchors, int64_t n_pairs, CloudView ca, CloudView cb,
+                                                              const uint32_t* pos_a, const uint32_t* pos_b, uint32_t* slot_a, uint32_t* slot_b,
+                                                              AnchorRec* uniq_a, AnchorRec* uniq_b, DeviceStatus* st) {
+    __shared__ uint32_t flag[kDedupeSmallPoints];
+    __shared__ uint32_t wsum[16];
+    const int side = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const CloudView c = side ? cb : ca;
+    const uint32_t* pos_of = side ? pos_b : pos_a;
+    uint32_t* slot = side ? slot_b : slot_a;
+    AnchorRec* uniq = side ? uniq_b : uniq_a;
+    const int n = c.n;
+    for (int i = tid; i < kDedupeSmallPoints; i += 1024) flag[i] = 0u;
+    __syncthreads();
+    for (int64_t p = tid; p < n_pairs; p += 1024) {
+        const int64_t a = anchors[2 * p + side];
+        if (a < 0 || a >= n) atomicOr(&st->flags, ST_BAD_ANCHOR);
+        else flag[a] = 1u;
+    }
+    __syncthreads();
+    // exclusive scan: thread t owns items [8t, 8t + 8)
+    uint32_t v[8], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { v[k] = flag[8 * tid + k]; sum += v[k]; }
+    const uint32_t incl = wave_incl_scan_u32(sum);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t pre = incl - sum;
+    for (int w = 0; w < wave; ++w) pre += wsum[w];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = 8 * tid + k;
+        if (i < n) {
+            slot[i] = pre;
+            if (v[k]) {
+                AnchorRec r;
+                r.x = c.x[i]; r.y = c.y[i]; r.z = c.z[i];
+                r.tag = (uint32_t)c.tag[i];
+                r.apos = pos_of[i];
+                r.sid = c.sid ? c.sid[i] : 0;
+                r.atom = (uint32_t)i;
+                uniq[pre] = r;
+            }
+        }
+        pre += v[k];
+    }
+    if (tid == 1023) { slot[n] = pre; st->n_unique[side] = pre; }
+}
+bool launch_anchor_dedupe_small(hipStream_t s, const int64_t* anchors, int64_t n_pairs, const CloudView& ca, const CloudView& cb,
+                                const uint32_t* pos_a, const uint32_t* pos_b, uint32_t* slot_a, uint32_t* slot_b, AnchorRec* uniq_a,
+                                AnchorRec* uniq_b, DeviceStatus* st) {
+    if (ca.n > kDedupeSmallPoints || cb.n > kDedupeSmallPoints || n_pairs > kDedupeSmallPairs || n_pairs <= 0 || ca.n <= 0 || cb.n <= 0 ||
+        getenv("LCHD_NO_SMALL_DEDUPE"))
+        return false;
+    k_anchor_dedupe_small<<<2, 1024, 0, s>>>(anchors, n_pairs, ca, cb, pos_a, pos_b, slot_a, slot_b, uniq_a, uniq_b, st);
+    return true;
+}
+
 void launch_anchor_dedupe(hipStream_t s, const int64_t* anchors, int64_t n_pairs, int side, int32_t n_points,
                           uint32_t* flag_then_slot, AnchorRec* uniq, const CloudView& c, const uint32_t* pos_of, DeviceStatus* st,
                           uint32_t* scan_tmp) {
@@ -473,16 +534,22 @@ __device__ unsigned long long g_env_stamps[8];
 #define ESTAMP(i) do { } while (0)
 #endif
 template <int NT, bool TAGLIST>  // TAGLIST: the tag rule is a pair list (binary searches); otherwise one comparison, no branch
-__global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ cfgp, CloudView c, GridView g,
-                                                  const AnchorRec* __restrict__ uniq, int side, double thr, int cap,
-                                                  EnvStore env, DeviceStatus* st) {
+__global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ cfgp, EnvSides sides, double thr, int cap, DeviceStatus* st) {
+    // both structures in one launch: workgroups [0, sides.s[0].max_envs) build side A, the rest side B; the side's block of
+    // kernel arguments is read with a wave-uniform index (scalar loads from the kernarg segment, no per-field selects)
+    const int side = (int64_t)blockIdx.x >= sides.s[0].max_envs ? 1 : 0;
+    const EnvSide& S = sides.s[side];
+    const CloudView c = S.c;
+    const GridView g = S.g;
+    const AnchorRec* __restrict__ uniq = S.uniq;
+    const EnvStore env = S.env;
     // dynamic LDS: cap * 9 bytes (u64 keys, then u8 categories)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* key = reinterpret_cast<uint64_t*>(smem);
     uint8_t* val = smem + (size_t)cap * 8;
     __shared__ int count_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t e = blockIdx.x;
+    const int64_t e = (int64_t)blockIdx.x - (side ? sides.s[0].max_envs : 0);
 #ifdef LCHD_SWEEP_STAMPS
     unsigned long long estamp_last = __builtin_amdgcn_s_memtime();
 #endif
@@ -715,22 +782,25 @@ __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ 
 }
 
 template <int NT>
-static void launch_env_cells_nt(hipStream_t s, dim3 grid, size_t lds, bool tag_list, const DevConfig* cfg, const CloudView& c,
-                                const GridView& g, const AnchorRec* uniq, int side, double thr, int cap, EnvStore env, DeviceStatus* st) {
-    if (tag_list) k_env_cells<NT, true><<<grid, NT, lds, s>>>(cfg, c, g, uniq, side, thr, cap, env, st);
-    else k_env_cells<NT, false><<<grid, NT, lds, s>>>(cfg, c, g, uniq, side, thr, cap, env, st);
+static void launch_env_cells_nt(hipStream_t s, dim3 grid, size_t lds, bool tag_list, const DevConfig* cfg, const EnvSide& a, const EnvSide& b,
+                                double thr, int cap, DeviceStatus* st) {
+    EnvSides sides;
+    sides.s[0] = a;
+    sides.s[1] = b;
+    if (tag_list) k_env_cells<NT, true><<<grid, NT, lds, s>>>(cfg, sides, thr, cap, st);
+    else k_env_cells<NT, false><<<grid, NT, lds, s>>>(cfg, sides, thr, cap, st);
 }
 
-bool launch_env_cells(hipStream_t s, int cap, const DevConfig* cfg, bool tag_list, const CloudView& c, const GridView& g,
-                      const AnchorRec* uniq, int side, int64_t max_envs, double thr, EnvStore env, DeviceStatus* st) {
-    if (max_envs <= 0) return true;
+bool launch_env_cells(hipStream_t s, int cap, const DevConfig* cfg, bool tag_list, const EnvSide& a, const EnvSide& b, double thr,
+                      DeviceStatus* st) {
+    if (a.max_envs + b.max_envs <= 0) return true;
     if (cap < 64 || cap > 16384 || (cap & (cap - 1))) return false;
-    const dim3 grid((unsigned)max_envs);
+    const dim3 grid((unsigned)(a.max_envs + b.max_envs));
     const size_t lds = (size_t)cap * 9;
     if (cap <= 2048) {
-        launch_env_cells_nt<64>(s, grid, lds + 16 + 257 * sizeof(uint32_t), tag_list, cfg, c, g, uniq, side, thr, cap, env, st);
+        launch_env_cells_nt<64>(s, grid, lds + 16 + 257 * sizeof(uint32_t), tag_list, cfg, a, b, thr, cap, st);
     } else if (cap <= 4096) {
-        launch_env_cells_nt<256>(s, grid, lds, tag_list, cfg, c, g, uniq, side, thr, cap, env, st);
+        launch_env_cells_nt<256>(s, grid, lds, tag_list, cfg, a, b, thr, cap, st);
     } else {
         static bool attr_set = false;
         if (!attr_set) {
@@ -740,7 +810,7 @@ bool launch_env_cells(hipStream_t s, int cap, const DevConfig* cfg, bool tag_lis
                                       16384 * 9);
             attr_set = true;
         }
-        launch_env_cells_nt<1024>(s, grid, lds, tag_list, cfg, c, g, uniq, side, thr, cap, env, st);
+        launch_env_cells_nt<1024>(s, grid, lds, tag_list, cfg, a, b, thr, cap, st);
     }
     return true;
 }
