@@ -50,6 +50,21 @@ ms = timed(lambda: sess.from_primitives(batch, batch, anchors, 10.0, out=out))
 res["c3_all_vs_all"] = {"pairs": len(pairs), "ms_per_call": ms, "pairs_per_s": len(pairs) / ms * 1e3, "kernel_ms": sess.last_ms()}
 sess.close()
 
+# ---- one structure pair per call (what a reference user does): device-resident inputs, latency per call -----------------
+for nn in (1000, 3000):
+    rs = np.random.default_rng(0)
+    sd = (nn / 0.023) ** (1 / 3)
+    xa, xb = rs.uniform(0, sd, (nn, 3)), rs.uniform(0, sd, (nn, 3))
+    ct = rs.integers(0, 8, nn).astype(np.int32)
+    tg = (np.arange(nn) // 3).astype(np.int32)
+    s1 = DeviceSession(lchd)
+    ha, hb = s1.upload(xa, ct, tg), s1.upload(xb, ct, tg)
+    an = torch.from_numpy(np.stack([np.arange(0, nn, 3), np.arange(0, nn, 3)], 1)).cuda()
+    o1 = torch.empty(len(an), dtype=torch.float64, device="cuda")
+    t = timed(lambda: s1.from_primitives(ha, hb, an, 10.0, out=o1), reps=50, warm=5)
+    res[f"single_structure_pair_{nn}_atoms"] = {"pairs": len(an), "ms_per_call": t}
+    s1.close()
+
 # ---- C2a clouds with other configurations (sweep phase per 10^6 pairs) ------------------------------------------------
 w = bench.make_workload("c2a", 0, 1_000_000)
 names = [f"c{i}" for i in range(w["C"])]
