@@ -230,7 +230,7 @@ static void launch_exclusive_scan(hipStream_t s, const uint32_t* in, uint32_t* o
 // entirely in LDS -- histogram with returned ranks, scan, scatter -- instead of the five global passes (two of them with one
 // global atomic per atom) of the generic path.  Structure k owns cells [k * cps, (k + 1) * cps) and records
 // [k * size, (k + 1) * size).
-constexpr int kStructCellsMax = 4096, kStructAtomsMax = 12288;
+constexpr int kStructCellsMax = 4096, kStructAtomsMax = 12000;  // 16 KB + 48 KB of dynamic LDS stay under the 64 KB launch limit
 __global__ __launch_bounds__(256) void k_cell_build_struct(CloudView c, GridView g, int cps, CellRec* __restrict__ rec,
                                                           uint32_t* __restrict__ pos_of, uint32_t* __restrict__ cell_start) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_cb[];  // hist[cps] u32 | cid[size] u16 | rank[size] u16

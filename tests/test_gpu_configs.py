@@ -332,3 +332,39 @@ def test_small_pair_kernel_with_a_minority_of_large_pairs(lh, oracle, monkeypatc
         plain, _ = run(lh)
         monkeypatch.delenv("LCHD_NO_DUO")
         assert np.max(np.abs(got - plain)) < 1e-13
+
+
+def test_regular_batch_of_large_structures_uses_the_per_structure_cell_build(lh, oracle):
+    """64 frames of an 11 000-atom structure: the one-workgroup-per-structure cell list at (almost) its LDS limit, against
+    the oracle on a sample of frames and against the generic cell-list path."""
+    import os
+
+    import torch
+    from loco_hd_amd.device import DeviceSession
+
+    rng = np.random.default_rng(31)
+    n, nf = 11_000, 64
+    side = (n / 0.05) ** (1 / 3)
+    base = rng.uniform(0, side, (n, 3))
+    cat = rng.integers(0, 6, n).astype(np.int32)
+    cats = [f"c{i}" for i in range(6)]
+    lchd = lh.LoCoHD(cats, lh.WeightFunction("hyper_exp", [1.0, 0.3]))
+    frames = base[None] + rng.normal(0, 0.3, (nf, n, 3))
+    la = np.arange(0, n, 37)
+    outs = {}
+    for mode in ("struct", "generic"):
+        if mode == "generic":
+            os.environ["LCHD_NO_STRUCT_CELLS"] = "1"
+        try:
+            sess = DeviceSession(lchd)
+            ref = sess.upload(base, cat)
+            outs[mode] = sess.score_trajectory(ref, frames, np.stack([la, la], 1), 7.0, chunk=nf)
+            sess.close()
+        finally:
+            os.environ.pop("LCHD_NO_STRUCT_CELLS", None)
+    assert np.array_equal(outs["struct"], outs["generic"])
+    lo = oracle.LoCoHD(cats, oracle.WeightFunction("hyper_exp", [1.0, 0.3]))
+    tag = np.zeros(n, dtype=np.int32)
+    for f in (0, 63):
+        want = np.asarray(lo.from_arrays(base, cat, tag, frames[f], cat, tag, np.stack([la, la], 1), 7.0))
+        assert np.max(np.abs(outs["struct"][f] - want)) < TIGHT
