@@ -22,6 +22,11 @@ import numpy as np
 
 from . import _native as N
 
+try:  # built by `make -C loco_hd_amd/csrc`; argument conversion only -- without it the same conversion runs as a Python loop
+    from . import _fastpack
+except ImportError:  # pragma: no cover
+    _fastpack = None
+
 WF_KINDS = {"hyper_exp": 0, "dagum": 1, "uniform": 2, "kumaraswamy": 3}
 SD_KINDS = {"Hellinger": 0, "Kolmogorov-Smirnov": 1, "Kullback-Leibler": 2, "Renyi": 3}
 
@@ -380,6 +385,10 @@ class LoCoHD:
     def pack(self, prims: Sequence[PrimitiveAtom], interner: Optional[Dict[str, int]] = None) -> _Packed:
         interner = {} if interner is None else interner
         n = len(prims)
+        if _fastpack is not None:  # native extraction (what PyO3 does for the reference), same results as the loop below
+            xyz, cat, tag = np.empty((n, 3), dtype=np.float64), np.empty(n, dtype=np.int32), np.empty(n, dtype=np.int32)
+            _fastpack.pack_into(prims, self._categories, interner, xyz, cat, tag)
+            return _Packed(xyz, cat, tag)
         xyz = np.array([p._coordinates if type(p) is PrimitiveAtom else p.coordinates for p in prims], dtype=np.float64).reshape(n, 3)
         cat = self._cats([p.primitive_type for p in prims])
         intern = interner.setdefault

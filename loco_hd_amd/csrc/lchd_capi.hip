@@ -171,6 +171,10 @@ struct lchd_ctx {
     unsigned long long* d_points = nullptr;
     double* d_tabs = nullptr;  // sqrt(k) | 1/sqrt(k), 65536 entries each
     uint32_t* d_partials = nullptr;  // scratch of k_pair_meta (kMetaPartials words)
+    // host-pointer calls: one grow-only device block + pinned staging block per context (no allocation in the steady state)
+    char *d_io = nullptr, *h_io = nullptr;
+    size_t io_cap = 0;
+    std::vector<char> cfg_blob_host;  // last configuration blob uploaded (identical configurations are not uploaded again)
     int cap_hint = 512;
     // timing
     bool timing = false;
@@ -252,6 +256,8 @@ extern "C" void lchd_ctx_destroy(lchd_ctx* c) {
     (void)hipFree(c->d_points);
     (void)hipFree(c->d_tabs);
     (void)hipFree(c->d_partials);
+    (void)hipFree(c->d_io);
+    if (c->h_io) (void)hipHostFree(c->h_io);
     (void)hipHostFree(c->h_status);
     for (auto& ev : c->ev) (void)hipEventDestroy(ev);
     delete c;
@@ -318,6 +324,13 @@ extern "C" int lchd_ctx_set_config(lchd_ctx* c, const lchd_config* cfg) {
     for (int64_t i = 0; i < cfg->n_tag_pairs; ++i)
         tp[i] = ((uint64_t)(uint32_t)cfg->tag_pairs[2 * i] << 32) | (uint32_t)cfg->tag_pairs[2 * i + 1];
     std::sort(tp, tp + cfg->n_tag_pairs);
+    // the words of DevConfig that are not in the blob, appended so that ONE comparison decides whether anything changed
+    const int32_t extra[10] = {C, cfg->n_weight_functions, cfg->sd_kind, cfg->sd_n_params, cfg->tag_mode, cfg->tag_accept_same,
+                               cfg->tag_accepted_pairs, cfg->tag_ordered, (int32_t)cfg->n_tag_pairs, 0};
+    std::vector<char> sig(blob.begin(), blob.begin() + total);
+    sig.insert(sig.end(), reinterpret_cast<const char*>(extra), reinterpret_cast<const char*>(extra) + sizeof extra);
+    sig.insert(sig.end(), reinterpret_cast<const char*>(cfg->sd_params), reinterpret_cast<const char*>(cfg->sd_params) + sizeof cfg->sd_params);
+    if (c->cfg_set && sig == c->cfg_blob_host) return LCHD_OK;  // same configuration as the last call: already on the device
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (total + 8 > c->blob_cap) {
         if (c->d_blob) HIP_TRY(hipFree(c->d_blob));
@@ -326,6 +339,8 @@ extern "C" int lchd_ctx_set_config(lchd_ctx* c, const lchd_config* cfg) {
         c->blob_cap = total + 4096;
     }
     HIP_TRY(hipMemcpy(c->d_blob, blob.data(), total, hipMemcpyHostToDevice));
+    c->cfg_set = false;
+    c->cfg_blob_host.swap(sig);
     DevConfig h{};
     h.n_categories = C;
     h.n_wf = cfg->n_weight_functions;
@@ -925,6 +940,36 @@ static int check_wf_index(const lchd_config* cfg, const int32_t* wf_index, int64
     return LCHD_OK;
 }
 
+// One structure of a host-pointer call inside the context's I/O block: SoA coordinates, tags, categories.  Fills the pinned
+// staging copy (AoS -> SoA, finiteness check, bounding box) and points a stack-allocated lchd_cloud at the device copy.
+static int stage_cloud(const double* xyz, const int32_t* cat, const int32_t* tag, int64_t n, char* h_base, char* d_base, size_t& off,
+                       lchd_cloud& cl) {
+    auto take = [&](size_t bytes) { off = (off + 255) & ~size_t(255); const size_t o = off; off += bytes; return o; };
+    const size_t m = (size_t)std::max<int64_t>(n, 1);
+    const size_t ox = take(8 * m), oy = take(8 * m), oz = take(8 * m), ot = take(4 * m), oc = take(m);
+    cl.x = reinterpret_cast<double*>(d_base + ox);
+    cl.y = reinterpret_cast<double*>(d_base + oy);
+    cl.z = reinterpret_cast<double*>(d_base + oz);
+    cl.tag = reinterpret_cast<int32_t*>(d_base + ot);
+    cl.cat = reinterpret_cast<uint8_t*>(d_base + oc);
+    cl.n = n;
+    if (!h_base) return LCHD_OK;  // sizing pass
+    double *hx = reinterpret_cast<double*>(h_base + ox), *hy = reinterpret_cast<double*>(h_base + oy), *hz = reinterpret_cast<double*>(h_base + oz);
+    int32_t* ht = reinterpret_cast<int32_t*>(h_base + ot);
+    uint8_t* hc = reinterpret_cast<uint8_t*>(h_base + oc);
+    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = 0; i < n; ++i) {
+        const double v[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+        if (!std::isfinite(v[0]) || !std::isfinite(v[1]) || !std::isfinite(v[2])) return fail(LCHD_EVALUE, "non-finite coordinate at atom %lld", (long long)i);
+        hx[i] = v[0]; hy[i] = v[1]; hz[i] = v[2];
+        for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], v[k]); mx[k] = std::max(mx[k], v[k]); }
+        ht[i] = tag ? tag[i] : 0;
+        hc[i] = (cat[i] >= 0 && cat[i] < 255) ? (uint8_t)cat[i] : (uint8_t)255;  // 255 = not in the map
+    }
+    for (int k = 0; k < 3; ++k) { cl.bbmin[k] = n ? mn[k] : 0.0; cl.bbmax[k] = n ? mx[k] : 0.0; }
+    return LCHD_OK;
+}
+
 extern "C" int lchd_from_primitives(lchd_ctx* c, const lchd_config* cfg, const double* xyz_a, const int32_t* cat_a,
                                     const int32_t* tag_a, int64_t n_a, const double* xyz_b, const int32_t* cat_b,
                                     const int32_t* tag_b, int64_t n_b, const int64_t* anchors, const int32_t* wf_index,
@@ -933,28 +978,49 @@ extern "C" int lchd_from_primitives(lchd_ctx* c, const lchd_config* cfg, const d
     if (int rc = lchd_ctx_set_config(c, cfg)) return rc;
     if (int rc = check_wf_index(cfg, wf_index, n_pairs)) return rc;
     if (n_pairs == 0) return LCHD_OK;
-    lchd_cloud *a = nullptr, *b = nullptr;
-    int64_t* d_anchors = nullptr;
-    int32_t* d_wf = nullptr;
-    double* d_out = nullptr;
-    int rc = lchd_cloud_create(c, xyz_a, cat_a, tag_a, n_a, &a);
-    if (!rc) rc = lchd_cloud_create(c, xyz_b, cat_b, tag_b, n_b, &b);
-    auto hip_rc = [&](hipError_t e, const char* what) {
-        if (e != hipSuccess && !rc) rc = fail(LCHD_EDEVICE, "HIP error %d in %s", (int)e, what);
-    };
-    if (!rc) hip_rc(hipMalloc(&d_anchors, sizeof(int64_t) * 2 * n_pairs), "hipMalloc(anchors)");
-    if (!rc) hip_rc(hipMalloc(&d_out, sizeof(double) * n_pairs), "hipMalloc(out)");
-    if (!rc && wf_index) hip_rc(hipMalloc(&d_wf, sizeof(int32_t) * n_pairs), "hipMalloc(wf_index)");
-    if (!rc) hip_rc(hipMemcpy(d_anchors, anchors, sizeof(int64_t) * 2 * n_pairs, hipMemcpyHostToDevice), "H2D anchors");
-    if (!rc && wf_index) hip_rc(hipMemcpy(d_wf, wf_index, sizeof(int32_t) * n_pairs, hipMemcpyHostToDevice), "H2D wf_index");
-    if (!rc) rc = lchd_from_primitives_dev(c, a, b, d_anchors, d_wf, n_pairs, thr, d_out);
-    if (!rc) hip_rc(hipMemcpy(out, d_out, sizeof(double) * n_pairs, hipMemcpyDeviceToHost), "D2H scores");
-    (void)hipFree(d_anchors);
-    (void)hipFree(d_wf);
-    (void)hipFree(d_out);
-    c->last_valid = false;  // the per-call anchor buffer is gone: lchd_ctx_last_env_points must not touch it
-    lchd_cloud_destroy(c, a);
-    lchd_cloud_destroy(c, b);
+    if (n_a < 0 || n_b < 0 || n_a > ((int64_t)1 << 30) || n_b > ((int64_t)1 << 30)) return fail(LCHD_EUNSUPPORTED, "structure size out of range");
+    // Everything a call sends to the device travels as ONE block through pinned staging and ONE asynchronous copy, the scores
+    // come back with one copy; the block and its staging twin belong to the context and only ever grow (the reference clones
+    // its arguments per call as well, primitive_atom.rs:5, but a device allocation costs far more than a Vec).
+    lchd_cloud a, b;
+    size_t o_anchors = 0, o_wf = 0, o_out = 0, in_bytes = 0, total = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        size_t off = 0;
+        char* hb = pass ? c->h_io : nullptr;
+        if (int rc = stage_cloud(xyz_a, cat_a, tag_a, n_a, hb, c->d_io, off, a)) return rc;
+        if (int rc = stage_cloud(xyz_b, cat_b, tag_b, n_b, hb, c->d_io, off, b)) return rc;
+        auto take = [&](size_t bytes) { off = (off + 255) & ~size_t(255); const size_t o = off; off += bytes; return o; };
+        o_anchors = take(sizeof(int64_t) * 2 * (size_t)n_pairs);
+        o_wf = take(wf_index ? sizeof(int32_t) * (size_t)n_pairs : 0);
+        in_bytes = off;
+        o_out = take(sizeof(double) * (size_t)n_pairs);
+        total = off;
+        if (pass == 0 && total > c->io_cap) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            (void)hipFree(c->d_io); c->d_io = nullptr;
+            if (c->h_io) { (void)hipHostFree(c->h_io); c->h_io = nullptr; }
+            c->io_cap = 0;
+            const size_t want = total + total / 4 + (1 << 16);
+            HIP_TRY(hipMalloc(&c->d_io, want));
+            HIP_TRY(hipHostMalloc(&c->h_io, want));
+            c->io_cap = want;
+        }
+    }
+    memcpy(c->h_io + o_anchors, anchors, sizeof(int64_t) * 2 * (size_t)n_pairs);
+    if (wf_index) memcpy(c->h_io + o_wf, wf_index, sizeof(int32_t) * (size_t)n_pairs);
+    HIP_TRY(hipMemcpyAsync(c->d_io, c->h_io, in_bytes, hipMemcpyHostToDevice, c->stream));
+    const int64_t* d_anchors = reinterpret_cast<const int64_t*>(c->d_io + o_anchors);
+    const int32_t* d_wf = wf_index ? reinterpret_cast<const int32_t*>(c->d_io + o_wf) : nullptr;
+    double* d_out = reinterpret_cast<double*>(c->d_io + o_out);
+    int rc = lchd_from_primitives_dev(c, &a, &b, d_anchors, d_wf, n_pairs, thr, d_out);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(c->h_io + o_out, d_out, sizeof(double) * (size_t)n_pairs, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(LCHD_EDEVICE, "HIP error %d in D2H scores", (int)e);
+        else memcpy(out, c->h_io + o_out, sizeof(double) * (size_t)n_pairs);
+    }
+    c->last_valid = false;  // the anchors of this call live in the I/O block, which the next call overwrites
+    c->pend.a = c->pend.b = nullptr;  // the stack clouds are gone
     return rc;
 }
 

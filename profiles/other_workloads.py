@@ -65,6 +65,19 @@ for nn in (1000, 3000):
     res[f"single_structure_pair_{nn}_atoms"] = {"pairs": len(an), "ms_per_call": t}
     s1.close()
 
+# ---- the reference's own call: LoCoHD.from_primitives(list[PrimitiveAtom], list[PrimitiveAtom], anchors, threshold) --------
+nn = 3000
+rs = np.random.default_rng(0)
+sd = (nn / 0.023) ** (1 / 3)
+pa = [lh.PrimitiveAtom(types[i % 8], f"A/{i // 3}-RES", rs.uniform(0, sd, 3)) for i in range(nn)]
+pb = [lh.PrimitiveAtom(types[i % 8], f"A/{i // 3}-RES", rs.uniform(0, sd, 3)) for i in range(nn)]
+anc = [(i, i) for i in range(0, nn, 3)]
+t = timed(lambda: lchd.from_primitives(pa, pb, anc, 10.0), reps=20, warm=3)
+it = {}
+ka, kb = lchd.pack(pa, it), lchd.pack(pb, it)
+t2 = timed(lambda: lchd.from_packed(ka, kb, np.asarray(anc, dtype=np.int64), 10.0, interner=it), reps=50, warm=3)
+res["reference_style_call_3000_atoms_1000_pairs"] = {"from_primitives_lists_ms": t, "c_abi_host_pointer_call_ms": t2}
+
 # ---- C2a clouds with other configurations (sweep phase per 10^6 pairs) ------------------------------------------------
 w = bench.make_workload("c2a", 0, 1_000_000)
 names = [f"c{i}" for i in range(w["C"])]

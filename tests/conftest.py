@@ -17,8 +17,11 @@ def pytest_sessionstart(session):
     import subprocess
 
     lib = ROOT / "loco_hd_amd" / "libloco_hd_hip.so"
-    srcs = list((ROOT / "loco_hd_amd" / "csrc").glob("*.hip")) + list((ROOT / "loco_hd_amd" / "csrc").glob("*.h")) + [ROOT / "include" / "loco_hd_hip.h"]
-    if not lib.exists() or lib.stat().st_mtime < max(p.stat().st_mtime for p in srcs):
+    csrc = ROOT / "loco_hd_amd" / "csrc"
+    srcs = list(csrc.glob("*.hip")) + list(csrc.glob("*.h")) + list(csrc.glob("*.c")) + [ROOT / "include" / "loco_hd_hip.h"]
+    ext = list((ROOT / "loco_hd_amd").glob("_fastpack*.so"))
+    newest = max(p.stat().st_mtime for p in srcs)
+    if not lib.exists() or not ext or min(lib.stat().st_mtime, ext[0].stat().st_mtime) < newest:
         subprocess.check_call(["make", "-C", str(ROOT / "loco_hd_amd" / "csrc"), "-j4"], stdout=subprocess.DEVNULL)
 
 

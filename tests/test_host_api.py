@@ -125,3 +125,42 @@ def test_scoring_fails_loudly_without_gpu():
         lchd.from_anchors(["A"], ["A"], [0.0], [0.0])
     with pytest.raises(lh.DeviceError):
         lchd.from_coords(["A"], ["A"], [[0.0, 0.0, 0.0]], [[0.0, 0.0, 0.0]])
+
+
+def test_native_pack_equals_python_pack():
+    """loco_hd_amd/_fastpack (CPython helper, the counterpart of the reference's PyO3 argument extraction) fills the same
+    arrays and interns the same tags as the pure-Python conversion loop."""
+    import numpy as np
+
+    import loco_hd_amd as lh
+    from loco_hd_amd import api
+
+    assert api._fastpack is not None, "the _fastpack extension was not built (make -C loco_hd_amd/csrc)"
+    rng = np.random.default_rng(3)
+    cats = ["a", "b", "c"]
+    prims = [lh.PrimitiveAtom(cats[i % 3] if i % 7 else "zz", f"T{i // 4}", rng.uniform(-5, 5, 3)) for i in range(200)]
+    prims[3].primitive_type = np.str_("b")
+    prims[4].coordinates = np.asarray([1, 2, 3], dtype=np.float32)
+
+    class Duck:  # any object with the three attributes is accepted, like in the Python loop
+        def __init__(self, t, g, c):
+            self.primitive_type, self.tag, self.coordinates = t, g, c
+
+    prims.append(Duck("c", "T0", (7, 8, 9)))
+    lchd = lh.LoCoHD(cats)
+    i_native, i_python = {"seed": 0}, {"seed": 0}
+    native = lchd.pack(prims, i_native)
+    saved, api._fastpack = api._fastpack, None
+    try:
+        python = lchd.pack(prims, i_python)
+    finally:
+        api._fastpack = saved
+    assert np.array_equal(native.xyz, python.xyz) and np.array_equal(native.cat, python.cat) and np.array_equal(native.tag, python.tag)
+    assert i_native == i_python and native.cat.dtype == np.int32 and native.xyz.shape == (201, 3)
+    assert (native.cat == -1).sum() == sum(1 for i in range(200) if i % 7 == 0)
+    import pytest
+
+    with pytest.raises(ValueError):
+        lchd.pack([Duck("a", "t", (1, 2))], {})
+    with pytest.raises(AttributeError):
+        lchd.pack([object()], {})
