@@ -131,7 +131,7 @@ for nn in (10_000, 20_000):
     xa, xb = rng.uniform(0, 58.5, (nn, 3)), rng.uniform(0, 58.5, (nn, 3))
     sa, sb = [names[i] for i in rng.integers(0, 10, nn)], [names[i] for i in rng.integers(0, 10, nn)]
     l3 = lh.LoCoHD(names, lh.WeightFunction(*w["wf"]))
-    l3.from_coords(sa[:64], sb[:64], xa[:64], xb[:64])
+    l3.from_coords(sa, sb, xa, xb)  # first call at this size: grows the context's workspace (a multi-GB hipMalloc)
     t0 = time.perf_counter()
     l3.from_coords(sa, sb, xa, xb)
     t = (time.perf_counter() - t0) * 1e3
