@@ -2,27 +2,34 @@
 //
 // Pipeline for one from_primitives call (reference: /root/reference/src/locohd.rs:479-567):
 //
-//   K0  cell list           k_cell_count / k_exclusive_scan (or the 3-phase multi-block scan) / k_cell_scatter
-//                           (replaces KdTree::build_by_ordered_float, :504-510); batches of structures carry the
-//                           structure id as the slowest grid dimension
-//   K0' anchor de-dup       k_mark_anchors / scan / k_compact_anchors
-//                           (an anchor that occurs in many pairs gets its environment built once)
-//   K1  environment build   k_env_cells<NT>: radius search over 32-byte cell records + tag filter + distances, then an O(n) bucket sort
-//                           (d^3 buckets, LDS histogram + scan + scatter + per-lane insertion sort) for environments
-//                           of <= 512 points, LDS bitonic network otherwise; optional CDF keying
-//                           (replaces env_from_idx :514-542, utils::sort_together utils.rs:25-39)
+//   K0  cell list           regular batches / small structures: k_cell_build_struct (one workgroup per structure, histogram +
+//                           scan + scatter in LDS); otherwise k_cell_count / k_exclusive_scan (or the 3-phase multi-block
+//                           scan) / k_cell_scatter.  Atoms are permuted into cell order as 32-byte records {x, y, z, tag, cat}
+//                           (replaces KdTree::build_by_ordered_float, :504-510); batches of structures carry the structure id
+//                           as the slowest grid dimension
+//   K0' anchor de-dup       k_anchor_dedupe_small (both sides in one launch, flags in LDS) or k_mark_anchors / scan /
+//                           k_compact_anchors: an anchor that occurs in many pairs gets its environment built once; every
+//                           unique anchor gets a 40-byte record (coordinates, tag, position in cell order, structure)
+//   K1  environment build   k_env_cells<NT,TAGLIST>, both structures in one launch: radius search over the concatenated
+//                           neighbour-cell runs (full wavefronts of candidates, two 16-byte loads per candidate, no dependent
+//                           loads) + tag filter + distances, then an O(n) bucket sort (d^3 buckets, LDS histogram + scan +
+//                           scatter + per-lane insertion sort) for environments of <= 512 points, LDS bitonic network
+//                           otherwise; optional CDF keying (replaces env_from_idx :514-542, utils::sort_together utils.rs:25-39)
 //       dense variant       k_env_rows<NT,GLOBALKV>: whole cloud / given distance-matrix row (from_coords, from_dmxs),
 //                           bucket sort on the row's empirical distance CDF
-//   K2  sweep               k_sweep<CMAX,MODE,FMODE,LDSTAB>: merge-path partition of the two sorted environments,
+//   K2' pair records        k_pair_meta (+ k_pair_meta_sum): one 16-byte record per pair {slot A, slot B, n_A | cat, n_B | cat}
+//                           and the number of pairs small enough for k_sweep_duo
+//   K2  sweep               k_sweep<CMAX,MODE,FMODE,LDSTAB,INDIRECT>: merge-path partition of the two sorted environments,
 //                           per-lane sequential sweep with a wavefront DPP prefix scan of packed category counts,
-//                           statistical distance per breakpoint, CDF differences, wave64 shuffle reduce
+//                           statistical distance per breakpoint, CDF differences, DPP reduction
 //                           (replaces stat_dist_integral :61-226, pmf.rs, statistical_distances.rs, cdfs.rs);
-//                           k_sweep_wide for 33..255 categories
+//                           k_sweep_duo<CMAX>: two pairs per wavefront for small environments (the device decides which of the
+//                           two sweeps the small pairs); k_sweep_wide for 33..255 categories
 //       trajectory frames   k_frames_labels / k_frames_unpack: SoA unpack + bounding box of a block of frames;
-//                           k_frames_centroids: primitive atoms of every frame from its float32 source atoms
+//                           k_frames_centroids (+ k_bbox_finish): primitive atoms of every frame from its float32 source atoms
 //
 // One wavefront owns one environment (K1: a 64-thread workgroup) or one anchor pair (K2: four pairs per
-// 256-thread workgroup); a launch has thousands of independent wavefronts, so all 256 CUs / 8 XCDs are
+// 256-thread workgroup; k_sweep_duo: eight); a launch has thousands of independent wavefronts, so all 256 CUs / 8 XCDs are
 // filled without any inter-workgroup communication.  All arithmetic is f64 like the reference; no MFMA
 // (there is no contraction in this path).
 #include <cstdlib>
