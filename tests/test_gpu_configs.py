@@ -368,3 +368,24 @@ def test_regular_batch_of_large_structures_uses_the_per_structure_cell_build(lh,
     for f in (0, 63):
         want = np.asarray(lo.from_arrays(base, cat, tag, frames[f], cat, tag, np.stack([la, la], 1), 7.0))
         assert np.max(np.abs(outs["struct"][f] - want)) < TIGHT
+
+
+@pytest.mark.parametrize("density", [0.022, 0.027, 0.032, 0.037, 0.045])
+def test_pair_sizes_around_the_small_pair_threshold(lh, oracle, density):
+    """Environment sizes spread around the 224-event tile of k_sweep_duo, so that the small pairs are sometimes the majority
+    and sometimes not: whichever kernels the device picks, every score equals the oracle's."""
+    rng = np.random.default_rng(int(density * 1e4))
+    n = 2500
+    side = (n / density) ** (1 / 3)
+    xa, xb = rng.uniform(0, side, (n, 3)), rng.uniform(0, side, (n, 3))
+    ca, cb = rng.integers(0, 9, n).astype(np.int32), rng.integers(0, 9, n).astype(np.int32)
+    cats = [f"c{i}" for i in range(9)]
+    pairs = np.stack([rng.integers(0, n, 20_000), rng.integers(0, n, 20_000)], 1).astype(np.int64)
+    tag = np.zeros(n, dtype=np.int32)
+    lo = oracle.LoCoHD(cats, oracle.WeightFunction("hyper_exp", [1.0, 0.15]))
+    want, sizes = lo.from_arrays(xa, ca, tag, xb, cb, tag, pairs, 10.0, return_env_sizes=True)
+    lchd = lh.LoCoHD(cats, lh.WeightFunction("hyper_exp", [1.0, 0.15]))
+    got = lchd.from_packed(lh.api._Packed(xa, ca, tag), lh.api._Packed(xb, cb, tag), pairs, 10.0)
+    assert np.max(np.abs(got - np.asarray(want))) < TIGHT
+    small = np.mean(np.asarray(sizes).sum(axis=1) - 2 <= 224)
+    assert 0.0 < small < 1.0 or density > 0.04  # the sweep really had both kinds of pairs to deal with

@@ -3,10 +3,13 @@
 Every case draws: cloud sizes and density, category count, category weights, weight function family and parameters
 (ranges of /root/reference/tests/generate_locohd_testcases.py:19-67), statistical distance (:70-103), tag rule,
 threshold, single vs. dictionary weight functions and the driver (from_primitives / from_coords / from_dmxs)."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+N_SEEDS = int(os.environ.get("LCHD_FUZZ_SEEDS", "40"))  # a one-off campaign: LCHD_FUZZ_SEEDS=3000 python -m pytest tests/test_gpu_fuzz.py
 
 
 def draw_wf(rng):
@@ -36,7 +39,7 @@ def draw_sd(rng):
     return ("Renyi", [rng.uniform(0.001, 5.0), rng.uniform(0.001, 5.0)])
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(N_SEEDS))
 def test_random_configuration(oracle, seed):
     import loco_hd_amd as lh
 
