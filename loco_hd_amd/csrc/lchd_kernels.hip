@@ -1140,7 +1140,7 @@ __device__ __forceinline__ double sqrt_unit(double x) {
     h = fma(h, r, h);
     const double d = fma(-g, g, x);
     g = fma(d, h, g);
-    return x > 0.0 ? g : 0.0;
+    return fmax(g, 0.0);  // x == 0: rsq gives inf, the chain NaN, and fmax returns its non-NaN operand: sqrt(0) = 0 in one instruction
 }
 
 // StatisticalDistance::run for the non-default distances; out of line so that the sweep kernel stays small.
