@@ -12,7 +12,8 @@ pair k = (k mod N, perm_r(k mod N)) with r = k div N and perm_r a seeded permuta
 every one of the 10^4 atoms of each cloud is an anchor ~100 times.  Coordinates, categories and anchor pairs
 are resident in HBM before the timed region; ONE STEP = one full pass of the hot path over that batch:
 cell lists for both clouds, anchor de-duplication, environment build (radius search + f64 distances + sort),
-merge sweep (Hellinger + CDF + reduction), status read-back.  Nothing is cached across steps.
+merge sweep (Hellinger + CDF + reduction), status read-back.  Nothing is cached across steps.  Two sessions take the steps
+in turn so that step k+1 is already enqueued while step k runs (the GPU does not idle during the host's status read-back).
 
 Multi-GPU (weak scaling): every rank holds both clouds and its own 10^6 pairs (different permutation
 rounds); the per-rank score vectors are gathered to rank 0 over RCCL inside the timed step.
@@ -311,47 +312,65 @@ def main():
 
     w = make_workload(args.workload, rank, args.pairs)
     lchd = lh.LoCoHD([f"c{i}" for i in range(w["C"])], lh.WeightFunction(*w["wf"]))
-    sess = DeviceSession(lchd, device=local_rank)
-    cloud_a = sess.upload(w["xyz_a"], w["cat_a"])
-    cloud_b = sess.upload(w["xyz_b"], w["cat_b"])
+    # Two sessions (contexts with their own workspace) take the steps in turn: step k+1 is enqueued while step k still runs, so
+    # the GPU does not idle during the status read-back and the host's launch work of a step (a step is still one complete
+    # pass; both sessions enqueue on the same stream, so the passes themselves run one after the other).
+    sessions = [DeviceSession(lchd, device=local_rank) for _ in range(2)]
+    sess = sessions[0]
+    clouds = [(s_.upload(w["xyz_a"], w["cat_a"]), s_.upload(w["xyz_b"], w["cat_b"])) for s_ in sessions]
+    cloud_a, cloud_b = clouds[0]
     anchors = torch.from_numpy(w["pairs"]).to(dev)
     p = anchors.shape[0]
     # Two score buffers: the RCCL gather of step k (asynchronous, on RCCL's stream) overlaps the scoring of step k+1.
     outs = [torch.empty(p, dtype=torch.float64, device=dev) for _ in range(2)]
     gathered = [torch.empty(p * world, dtype=torch.float64, device=dev) if (use_dist and rank == 0) else None for _ in range(2)]
     pending = [None, None]
-    sess.enable_timing(True)
+    in_flight = [False, False]
+    for s_ in sessions:
+        s_.enable_timing(True)
     counter = [0]
+    phase_ms = {"cells": 0.0, "anchors": 0.0, "env": 0.0, "sweep": 0.0}
+    collect = [False]
+
+    def finish(k):  # wait for the pass enqueued on session k (raises on a device-side error), book its kernel times
+        if in_flight[k]:
+            sessions[k].finish()
+            in_flight[k] = False
+            if collect[0]:
+                for name, v in sessions[k].last_ms().items():
+                    phase_ms[name] += v
 
     def step():
         k = counter[0] % 2
         counter[0] += 1
+        finish(k)  # the session's previous pass (two steps ago) and its score buffer
         if pending[k] is not None:  # the gather that last read this buffer must be done before it is overwritten
             pending[k].wait()
             pending[k] = None
-        sess.from_primitives(cloud_a, cloud_b, anchors, w["thr"], out=outs[k])
+        sessions[k].from_primitives_async(clouds[k][0], clouds[k][1], anchors, w["thr"], outs[k])
+        in_flight[k] = True
         if use_dist:
             pending[k] = gather_scores(outs[k], gathered[k], world, rank, force_collective=True, async_op=True)
 
     def drain():
         for k in range(2):
+            finish(k)
             if pending[k] is not None:
                 pending[k].wait()
                 pending[k] = None
 
-    phase_ms = {"cells": 0.0, "anchors": 0.0, "env": 0.0, "sweep": 0.0}
     for _ in range(args.warmup):
         step()
     drain()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    collect[0] = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        for k, v in sess.last_ms().items():
-            phase_ms[k] += v
-    drain()  # every gather of the timed steps has completed inside the timed region
+    drain()  # every pass and every gather of the timed steps has completed inside the timed region
+    collect[0] = False
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -424,7 +443,8 @@ def main():
             assert torch.equal(gathered[(counter[0] - 1) % 2][:p], out), "gathered scores differ from the local ones"
         dist.barrier()
         dist.destroy_process_group()
-    sess.close()
+    for s_ in sessions:
+        s_.close()
     if rank == 0:
         # RCCL prints a version banner through C stdio; flush it first so that the JSON line is the LAST line of stdout
         import ctypes
