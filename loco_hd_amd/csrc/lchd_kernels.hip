@@ -1016,17 +1016,17 @@ bool launch_env_rows(hipStream_t s, int cap, const DevConfig* cfg, const CloudVi
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2: the sweep.  One wavefront per anchor pair, eight pairs per 512-thread workgroup.
+// K2: the sweep.  One wavefront per anchor pair, four pairs per 256-thread workgroup.
 //
 // S = sum_k [F(t_{k+1}) - F(t_k)] * H(state after k events), t_0 = 0, t_{M+1} = inf, where the events are
 // the merged non-anchor points of both environments (the reference's two-pointer
 // loop src/locohd.rs:97-223 evaluates exactly this sum; cross-list ties collapse because a zero-width
 // interval contributes exactly 0).
 //
-// Events are processed in tiles of 512: lane l owns merged events [8l, 8l+8) of the tile, found with a
+// Events are processed in tiles of 384: lane l owns ceil(T/64) <= 6 consecutive merged events of the tile, found with a
 // merge-path binary search in LDS.  A packed (16-bit fields) wavefront prefix scan of the per-lane
 // category histograms gives every lane the exact integer category counts at its first event; it then
-// walks its 8 events sequentially with the per-category state in registers.
+// walks its events sequentially with the per-category state in registers.
 //
 // MODE_H2U / MODE_H2W: Hellinger distance with exponent 2 (the default, src/locohd.rs:365-370), unit /
 //   arbitrary category weights.  The per-lane state is just the packed integer category counts plus the
