@@ -1056,6 +1056,12 @@ enum { F_KEY = 0, F_FAST = 1, F_ANY = 2 };
 #define LCHD_SWEEP_MINW 2
 #endif
 constexpr int kDuoTileFwd = 224;  // = kDuoTile (k_sweep_duo, below)
+// H^2 = 1 - D / sqrt(N_a N_b) carries an absolute rounding error of a few 1e-16 (D is rebuilt from the exact integer counts at
+// every lane chunk, so nothing drifts); sqrt() turns that into an error of ~3e-16 / (2 sqrt(H^2)) in H.  Below this bound the
+// literal difference-of-roots form is evaluated instead (exactly 0 for identical environments); at the bound the cancellation
+// form is still good to ~2e-13.  (It used to be 1e-3: large random clouds -- dense from_coords rows -- sit at H^2 ~ 1e-4 and
+// paid the O(C) literal form with 2C square roots on nearly every event.)
+constexpr double kExactH2Below = 1e-6;
 constexpr int kSqrtTab = 512;  // LDSTAB kernels: environments of at most 512 points, sqrt tables entirely in LDS
 constexpr int kSweepWaves = LCHD_SWEEP_WAVES;  // anchor pairs (wavefronts) per workgroup
 
@@ -1392,7 +1398,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
                 // absolute) only matters when H^2 itself is tiny, so small values are recomputed in the exact form
                 // (which also returns exactly 0 for identical environments).
                 double h2 = 1.0 - (ra * rb) * D;
-                if (h2 < 1e-3) h2 = exact_h2();
+                if (h2 < kExactH2Below) h2 = exact_h2();
                 return sqrt_unit(h2);
             } else {
                 double pn[CMAX], qn[CMAX];
@@ -1829,7 +1835,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs arg
                 ra = takeA ? r : ra;
                 rb = takeA ? rb : r;
                 double h2 = 1.0 - (ra * rb) * D;
-                if (h2 < 1e-3) {  // literal difference-of-roots form where the cancellation form loses accuracy (k_sweep::exact_h2)
+                if (h2 < kExactH2Below) {  // literal difference-of-roots form where the cancellation form loses accuracy (k_sweep::exact_h2)
                     double acc2 = 0.0;
 #pragma unroll
                     for (int k = 0; k < NW; ++k) {
@@ -1993,7 +1999,7 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
                 // absolute) only matters when H^2 itself is tiny, so small values are recomputed in the exact form
                 // (which also returns exactly 0 for identical environments).
                 double h2 = 1.0 - (ra * rb) * D;
-                if (h2 < 1e-3) h2 = exact_h2();
+                if (h2 < kExactH2Below) h2 = exact_h2();
                 return sqrt_unit(h2);
             } else {
                 double pn[kWideMaxCat], qn[kWideMaxCat];
