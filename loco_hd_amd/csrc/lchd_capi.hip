@@ -1099,8 +1099,13 @@ static int dense_driver(lchd_ctx* c, const lchd_config* cfg, const int32_t* seq_
         }
         if (wf_index) HIP_TRY(hipMemcpyAsync(d_wf, wf_index, sizeof(int32_t) * rows, hipMemcpyHostToDevice, s));
         mark(c, 2);
-        if (!launch_env_rows(s, cap_a, c->d_cfg, a->view(), d_ma, cols_a, rows, cols_a, ea, c->d_status) ||
-            !launch_env_rows(s, cap_b, c->d_cfg, b->view(), d_mb, cols_b, rows, cols_b, eb, c->d_status))
+        auto diag2 = [](const lchd_cloud* cl) {  // squared diagonal of the bounding box, with a little headroom
+            double s2 = 0.0;
+            for (int k = 0; k < 3; ++k) { const double e = cl->bbmax[k] - cl->bbmin[k]; s2 += e * e; }
+            return s2 * (1.0 + 1e-9) + 1e-300;
+        };
+        if (!launch_env_rows(s, cap_a, c->d_cfg, a->view(), d_ma, cols_a, rows, cols_a, diag2(a), ea, c->d_status) ||
+            !launch_env_rows(s, cap_b, c->d_cfg, b->view(), d_mb, cols_b, rows, cols_b, diag2(b), eb, c->d_status))
             return fail(LCHD_EUNSUPPORTED, "no dense environment kernel for this row length");
         mark(c, 3);
         if (int rc2 = sweep_rows(c, ea, eb, wf_index ? d_wf : nullptr, rows, d_out, d_meta, DRV_DMXS)) return rc2;

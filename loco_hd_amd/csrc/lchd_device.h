@@ -129,7 +129,8 @@ bool launch_env_cells(hipStream_t s, int cap, const DevConfig* cfg, bool tag_lis
 
 // dense rows: either distances from coordinates (dmx == nullptr) or given rows (dmx != nullptr, leading dim ld)
 bool launch_env_rows(hipStream_t s, int cap, const DevConfig* cfg, const CloudView& c, const double* dmx, int64_t ld,
-                     int64_t n_rows, int64_t row_len, EnvStore env, DeviceStatus* st);
+                     int64_t n_rows, int64_t row_len, double image_bound /* coords: >= largest squared distance, or 0 */, EnvStore env,
+                     DeviceStatus* st);
 
 struct SweepArgs {
     const DevConfig* cfg;

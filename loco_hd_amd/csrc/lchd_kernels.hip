@@ -834,9 +834,10 @@ constexpr int kRowBucketLimit = 64;   // a fuller bucket sends the row to the bi
 
 template <int NT, bool GLOBALKV>
 __global__ __launch_bounds__(NT) void k_env_rows(const DevConfig* __restrict__ cfgp, CloudView c, const double* __restrict__ dmx,
-                                                 int64_t ld, int64_t row_len, int n2, int n_buckets, EnvStore env, DeviceStatus* st) {
+                                                 int64_t ld, int64_t row_len, int n2, int n_buckets, double image_bound, EnvStore env,
+                                                 DeviceStatus* st) {
     // Sorting one row of n <= 16384 distances in O(n): an empirical CDF of the row on kRowCoarse uniform bins of
-    // [0, d_max] gives every point an interpolated rank; rank * kRowBuckets / n is its bucket, so buckets hold
+    // [0, max] of a monotone image of the distance (d^2 for coordinates) gives every point an interpolated rank; rank * kRowBuckets / n is its bucket, so buckets hold
     // ~n / kRowBuckets points whatever the shape of the cloud.  One LDS histogram + scan + scatter puts the points
     // into bucket order, then one thread finishes each bucket with an insertion sort on the exact f64 keys.  The map
     // distance -> bucket is monotone, which is all correctness needs; a pathological row (a bucket with more than
@@ -861,7 +862,10 @@ __global__ __launch_bounds__(NT) void k_env_rows(const DevConfig* __restrict__ c
     const double* __restrict__ row = dmx ? dmx + r * ld : nullptr;
     double ax = 0.0, ay = 0.0, az = 0.0;
     if (!dmx) { ax = c.x[r]; ay = c.y[r]; az = c.z[r]; }
-    auto dist_of = [&](int i, bool& bad) -> double {
+    // The bucketing phases work on a MONOTONE image of the distance -- the squared distance for coordinates (no square root
+    // until the key is written), the distance itself for a given row -- and only the scatter takes the root of the survivors'
+    // d^2; `dist_of` of the same image is what the reference computes (utils.rs:1-8).
+    auto image_of = [&](int i, bool& bad) -> double {
         if (dmx) {
             double v = row[i];
             if (!(v >= 0.0)) { bad = true; v = 0.0; }  // negative or NaN
@@ -871,16 +875,20 @@ __global__ __launch_bounds__(NT) void k_env_rows(const DevConfig* __restrict__ c
         double d2 = dx * dx;  // utils.rs:1-8 order, uncontracted
         d2 = d2 + dy * dy;
         d2 = d2 + dz * dz;
-        return sqrt(d2);
+        return d2;
     };
+    auto dist_from_image = [&](double m) -> double { return dmx ? m : sqrt(m); };
+    auto dist_of = [&](int i, bool& bad) -> double { return dist_from_image(image_of(i, bad)); };
 
-    // 1. largest finite distance
+    // 1. largest finite distance image -- or, for coordinates, the caller's bound (squared diagonal of the bounding box): any
+    //    upper bound will do, the empirical CDF below adapts the buckets to wherever the points really are
     bool bad = false;
-    double dmax = 0.0;
-    for (int i = tid; i < n; i += NT) {
-        const double v = dist_of(i, bad);
-        if (v < 1.0e300 && v > dmax) dmax = v;
-    }
+    double dmax = image_bound > 0.0 ? image_bound : 0.0;
+    if (!(image_bound > 0.0))
+        for (int i = tid; i < n; i += NT) {
+            const double v = image_of(i, bad);
+            if (v < 1.0e300 && v > dmax) dmax = v;
+        }
     if (bad) atomicOr(&st->flags, ST_BAD_DISTANCE);
     for (int m = 32; m > 0; m >>= 1) dmax = fmax(dmax, shfl_xor_f64(dmax, m));
     if (lane == 0) red_max[wave] = dmax;
@@ -892,7 +900,7 @@ __global__ __launch_bounds__(NT) void k_env_rows(const DevConfig* __restrict__ c
     // 2. empirical CDF on the coarse bins
     const double inv_w = dmax > 0.0 ? (double)kRowCoarse / dmax : 0.0;
     for (int i = tid; i < n; i += NT) {
-        const double v = dist_of(i, bad);
+        const double v = image_of(i, bad);
         if (v <= dmax) atomicAdd(&coarse[min((int)(v * inv_w), kRowCoarse - 1)], 1u);
     }
     __syncthreads();
@@ -918,7 +926,7 @@ __global__ __launch_bounds__(NT) void k_env_rows(const DevConfig* __restrict__ c
     };
     // 3. bucket histogram
     uint32_t biggest = 0;
-    for (int i = tid; i < n; i += NT) biggest = max(biggest, atomicAdd(&hist[bucket_of(dist_of(i, bad))], 1u) + 1u);
+    for (int i = tid; i < n; i += NT) biggest = max(biggest, atomicAdd(&hist[bucket_of(image_of(i, bad))], 1u) + 1u);
     for (int m = 32; m > 0; m >>= 1) biggest = max(biggest, (uint32_t)__shfl_xor((int)biggest, m));
     if (lane == 0) red_cnt[wave] = biggest;
     __syncthreads();
@@ -949,9 +957,9 @@ __global__ __launch_bounds__(NT) void k_env_rows(const DevConfig* __restrict__ c
         }
         // 5. scatter; the bucket cursor advances in place, so afterwards hist[b] = END of bucket b
         for (int i = tid; i < n; i += NT) {
-            const double v = dist_of(i, bad);
-            const uint32_t pos = atomicAdd(&hist[bucket_of(v)], 1u);
-            key[pos] = d2u(v);
+            const double m = image_of(i, bad);
+            const uint32_t pos = atomicAdd(&hist[bucket_of(m)], 1u);
+            key[pos] = d2u(dist_from_image(m));
             val[pos] = c.cat[i];
         }
         __syncthreads();
@@ -983,7 +991,8 @@ __global__ __launch_bounds__(NT) void k_env_rows(const DevConfig* __restrict__ c
 }
 
 bool launch_env_rows(hipStream_t s, int cap, const DevConfig* cfg, const CloudView& c, const double* dmx, int64_t ld,
-                     int64_t n_rows, int64_t row_len, EnvStore env, DeviceStatus* st) {
+                     int64_t n_rows, int64_t row_len, double image_bound, EnvStore env, DeviceStatus* st) {
+    if (dmx) image_bound = 0.0;  // given rows: the kernel finds the largest finite entry itself
     if (n_rows <= 0) return true;
     if (cap > 65536 || row_len > cap || row_len > 65535) return false;
     const dim3 grid((unsigned)n_rows);
@@ -995,14 +1004,14 @@ bool launch_env_rows(hipStream_t s, int cap, const DevConfig* cfg, const CloudVi
                                       (int)((kRowBucketsBig + 1) * sizeof(uint32_t) + 16));
             attr_big = true;
         }
-        k_env_rows<1024, true><<<grid, 1024, lds, s>>>(cfg, c, dmx, ld, row_len, cap, kRowBucketsBig, env, st);
+        k_env_rows<1024, true><<<grid, 1024, lds, s>>>(cfg, c, dmx, ld, row_len, cap, kRowBucketsBig, image_bound, env, st);
         return true;
     }
     const size_t lds = (size_t)cap * 9 + 16 + (size_t)(kRowBucketsSmall + 1) * sizeof(uint32_t);
     if (cap <= 1024) {
-        k_env_rows<64, false><<<grid, 64, lds, s>>>(cfg, c, dmx, ld, row_len, cap, kRowBucketsSmall, env, st);
+        k_env_rows<64, false><<<grid, 64, lds, s>>>(cfg, c, dmx, ld, row_len, cap, kRowBucketsSmall, image_bound, env, st);
     } else if (cap <= 4096) {
-        k_env_rows<256, false><<<grid, 256, lds, s>>>(cfg, c, dmx, ld, row_len, cap, kRowBucketsSmall, env, st);
+        k_env_rows<256, false><<<grid, 256, lds, s>>>(cfg, c, dmx, ld, row_len, cap, kRowBucketsSmall, image_bound, env, st);
     } else {
         static bool attr_set = false;
         if (!attr_set) {
@@ -1010,7 +1019,7 @@ bool launch_env_rows(hipStream_t s, int cap, const DevConfig* cfg, const CloudVi
                                       16384 * 9 + 16 + (kRowBucketsSmall + 1) * 4);
             attr_set = true;
         }
-        k_env_rows<1024, false><<<grid, 1024, lds, s>>>(cfg, c, dmx, ld, row_len, cap, kRowBucketsSmall, env, st);
+        k_env_rows<1024, false><<<grid, 1024, lds, s>>>(cfg, c, dmx, ld, row_len, cap, kRowBucketsSmall, image_bound, env, st);
     }
     return true;
 }
