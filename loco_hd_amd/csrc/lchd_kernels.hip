@@ -1372,7 +1372,10 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
                             D += sqrt_cnt(ca) * sqrt_cnt(cb);
                         }
                     }
-                    __builtin_amdgcn_sched_barrier(0);  // keep only one word's table look-ups in flight (register pressure)
+                    // <= 16 slots run at 3-4 waves/SIMD on a tight register budget: one word's table look-ups in flight at a time;
+                    // the larger variants (2 waves/SIMD, 256 registers) profit from every second word's being in flight together
+                    if constexpr (CMAX <= 16) __builtin_amdgcn_sched_barrier(0);
+                    else if ((k & 1) == 1) __builtin_amdgcn_sched_barrier(0);
                 }
                 if constexpr (MODE == MODE_H2W) { ra = 1.0 / sqrt(na); rb = 1.0 / sqrt(nb); }
                 else { ra = rsqrt_cnt(totA); rb = rsqrt_cnt(totB); }
