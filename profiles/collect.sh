@@ -14,6 +14,11 @@ cp "$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)" "$OUT/rocprofv3_ke
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $BENCH --steps 2 --warmup 1 > "$OUT/pmc_fetch.log" 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc_write" -- $BENCH --steps 2 --warmup 1 > "$OUT/pmc_write.log" 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d "$OUT/pmc_sq" -- $BENCH --steps 2 --warmup 1 > "$OUT/pmc_sq.log" 2>&1 || exit 1
+for W in c4 c5; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$W" -- $BENCH --workload $W --steps 3 --warmup 1 > "$OUT/stats_$W.log" 2>&1 || exit 1
+  cp "$(find "$OUT/stats_$W" -name '*kernel_stats.csv' | head -1)" "$OUT/rocprofv3_kernel_stats_bench_$W.csv"
+  rm -rf "$OUT/stats_$W"
+done
 cd "$REPO"
 python3 profiles/summarize_pmc.py "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_sq" > "$OUT/pmc_summary_bench_c2a.txt" 2>&1
 python3 bench.py > "$OUT/bench_c2a.log" 2>&1; tail -1 "$OUT/bench_c2a.log" > "$OUT/bench_c2a.json"
