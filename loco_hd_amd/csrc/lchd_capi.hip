@@ -176,6 +176,7 @@ struct lchd_ctx {
     size_t io_cap = 0;
     std::vector<char> cfg_blob_host;  // last configuration blob uploaded (identical configurations are not uploaded again)
     int cap_hint = 512;
+    bool cap_env_done = false;
     // timing
     bool timing = false;
     hipEvent_t ev[PH_N + 1] = {};
@@ -701,6 +702,7 @@ extern "C" int lchd_from_primitives_dev_async(lchd_ctx* c, lchd_cloud* a, lchd_c
     auto& P = c->pend;
     P.a = a; P.b = b; P.anchors = d_anchors; P.wf = d_wf_index; P.n_pairs = n_pairs; P.thr = thr; P.out = d_out;
     P.cap = c->cap_hint;
+    if (const char* e_ = getenv("LCHD_CAP_HINT")) { if (!c->cap_env_done) { c->cap_env_done = true; P.cap = c->cap_hint = atoi(e_); } }
     if (int rc = prims_enqueue(c)) return rc;
     P.active = true;
     return LCHD_OK;

@@ -38,7 +38,9 @@
 #include "lchd_math.h"
 
 #ifndef LCHD_ENV_FLAT
+#ifndef LCHD_ENV_FLAT
 #define LCHD_ENV_FLAT 4   // steps of 64 candidates whose record loads are issued together in the radius search
+#endif
 #endif
 
 namespace lchd {
@@ -541,7 +543,12 @@ __device__ unsigned long long g_env_stamps[8];
 #define ESTAMP(i) do { } while (0)
 #endif
 template <int NT, bool TAGLIST>  // TAGLIST: the tag rule is a pair list (binary searches); otherwise one comparison, no branch
-__global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ cfgp, EnvSides sides, double thr, int cap, DeviceStatus* st) {
+#ifdef ENV_W8
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 64 ? 8 : 1, NT == 64 ? 8 : 8))) void k_env_cells(
+#else
+__global__ __launch_bounds__(NT) void k_env_cells(
+#endif
+const DevConfig* __restrict__ cfgp, EnvSides sides, double thr, int cap, DeviceStatus* st) {
     // both structures in one launch: workgroups [0, sides.s[0].max_envs) build side A, the rest side B; the side's block of
     // kernel arguments is read with a wave-uniform index (scalar loads from the kernarg segment, no per-field selects)
     const int side = (int64_t)blockIdx.x >= sides.s[0].max_envs ? 1 : 0;
@@ -588,25 +595,29 @@ __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ 
         // bounds are fetched first (one dependent-load latency), then the runs are walked as ONE concatenated candidate list,
         // 64 candidates per step (every step is a full wavefront, however short the individual runs are); the record loads
         // of U steps are issued together.
-        int rb[9], roff[10];
-        roff[0] = 0;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const int zz = cz - 1 + k / 3, yy = cy - 1 + k % 3;
-            const bool in = zz >= 0 && zz < g.dim[2] && yy >= 0 && yy < g.dim[1];
-            const int row = in ? (int)((((int64_t)asid * g.dim[2] + zz) * g.dim[1] + yy) * g.dim[0]) : 0;
-            const int b_ = (int)g.cell_start[row + x0], e_ = (int)g.cell_start[row + x1 + 1];
-            rb[k] = b_;
-            roff[k + 1] = roff[k] + (in ? e_ - b_ : 0);
-        }
-        const int total = __builtin_amdgcn_readfirstlane(roff[9]);
+        // The row bounds are worked out by lanes 0..8 (one row each: vector address arithmetic and two vector loads), turned
+        // into offsets of the concatenated list by a wave scan and handed to every lane through v_readlane.  Done row by row
+        // in scalar code the same thing took ~300 scalar instructions per environment, and the scalar unit (one per CU,
+        // shared by all resident waves) was what bounded this kernel.
+        const int kk = lane < 9 ? lane : 8;
+        const int kz = (kk * 11) >> 5, ky = kk - 3 * kz;  // kk / 3, kk % 3 for kk < 9
+        const int zz = cz - 1 + kz, yy = cy - 1 + ky;
+        const bool in = lane < 9 && zz >= 0 && zz < g.dim[2] && yy >= 0 && yy < g.dim[1];
+        const int row = in ? (int)((((int64_t)asid * g.dim[2] + zz) * g.dim[1] + yy) * g.dim[0]) : 0;
+        const int b_ = (int)g.cell_start[row + x0], e_ = (int)g.cell_start[row + x1 + 1];
+        const uint32_t len = in ? (uint32_t)(e_ - b_) : 0u;
+        const uint32_t incl = wave_incl_scan_u32(len);
+        const int roff_v = (int)(incl - len), dl_v = b_ - roff_v;
+        // (each value passes through an empty asm: a select between two readlanes of one register is otherwise folded into
+        // ONE readlane with a per-lane lane index, which the backend can only implement through a table in scratch memory)
+#define LCHD_ROW(k)                                                                               \
+    int dl##k = __builtin_amdgcn_readlane(dl_v, k), ro##k = __builtin_amdgcn_readlane(roff_v, k); \
+    asm("" : "+s"(dl##k), "+s"(ro##k));
+        LCHD_ROW(0) LCHD_ROW(1) LCHD_ROW(2) LCHD_ROW(3) LCHD_ROW(4) LCHD_ROW(5) LCHD_ROW(6) LCHD_ROW(7) LCHD_ROW(8)
+#undef LCHD_ROW
+        (void)ro0;
+        const int total = __builtin_amdgcn_readlane((int)incl, 8);
         ESTAMP(0);
-        auto index_of = [&](int t) -> int {  // candidate t of the concatenated list -> record index
-            int d = rb[0];
-#pragma unroll
-            for (int k = 1; k < 9; ++k) d = (t >= roff[k]) ? rb[k] - roff[k] : d;
-            return t + d;
-        };
         const double2* __restrict__ rec2 = reinterpret_cast<const double2*>(g.rec);
         constexpr int U = LCHD_ENV_FLAT;
         for (int c0 = 0; c0 < total; c0 += 64 * U) {
@@ -614,12 +625,21 @@ __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ 
             double2 R0[U], R1[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int t = c0 + 64 * u + lane;
-                idx[u] = index_of(t);
-                const bool v = t < total;
-                R0[u] = v ? rec2[2 * (int64_t)idx[u]] : make_double2(0.0, 0.0);
-                R1[u] = v ? rec2[2 * (int64_t)idx[u] + 1] : make_double2(0.0, 0.0);
+                const int t = min(c0 + 64 * u + lane, total - 1);  // lanes past the end re-read the last candidate (masked below)
+                int d = dl0;  // candidate t of the concatenated list -> record index t + dl[row of t]
+                d = (t >= ro1) ? dl1 : d;
+                d = (t >= ro2) ? dl2 : d;
+                d = (t >= ro3) ? dl3 : d;
+                d = (t >= ro4) ? dl4 : d;
+                d = (t >= ro5) ? dl5 : d;
+                d = (t >= ro6) ? dl6 : d;
+                d = (t >= ro7) ? dl7 : d;
+                d = (t >= ro8) ? dl8 : d;
+                idx[u] = t + d;
+                R0[u] = rec2[2 * (int64_t)idx[u]];
+                R1[u] = rec2[2 * (int64_t)idx[u] + 1];
             }
+            __builtin_amdgcn_sched_barrier(0);  // all 2U loads are issued before the first distance is computed
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (c0 + 64 * u < total) {  // wave-uniform
@@ -633,7 +653,7 @@ __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ 
                     if (v && d2 < thr2) ok = ((uint32_t)idx[u] == apos) || tag_ok((int32_t)(uint32_t)tc);
                     const unsigned long long m = __ballot(ok);
                     if (ok) {
-                        const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
+                        const int pos = count + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                         if (pos < cap) {
                             key[pos] = d2u(d2);  // the square root is taken after compaction (a sixth of the candidates survive)
                             val[pos] = (uint8_t)(tc >> 32);
@@ -710,21 +730,18 @@ __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ 
             __syncthreads();
             const double qs = (double)B / (thr2 * thr);  // B / thr^3
             uint64_t rk[EPT];
-            uint8_t rv[EPT];
-            uint16_t rb[EPT], rs[EPT];
+            uint32_t rp[EPT];  // category | bucket << 8 | slot inside the bucket << 16 (one register per element)
 #pragma unroll
             for (int q = 0; q < EPT; ++q) {
                 const int i = lane + 64 * q;
-                rk[q] = 0; rv[q] = 0; rb[q] = 0; rs[q] = 0;
+                rk[q] = 0; rp[q] = 0;
                 if (i < count) {
                     const double d2 = u2d(key[i]);
                     const double d = sqrt(d2);  // utils.rs:1-8
                     rk[q] = d2u(d);
-                    rv[q] = val[i];
                     const double t = d2 * d * qs;
                     const int b = t < (double)B ? (int)t : B - 1;
-                    rb[q] = (uint16_t)b;
-                    rs[q] = (uint16_t)atomicAdd(&hist[b], 1u);
+                    rp[q] = (uint32_t)val[i] | ((uint32_t)b << 8) | (atomicAdd(&hist[b], 1u) << 16);
                 }
             }
             __syncthreads();
@@ -745,9 +762,9 @@ __global__ __launch_bounds__(NT) void k_env_cells(const DevConfig* __restrict__ 
                 for (int q = 0; q < EPT; ++q) {
                     const int i = lane + 64 * q;
                     if (i < count) {
-                        const uint32_t pos = hist[rb[q]] + rs[q];
+                        const uint32_t pos = hist[(rp[q] >> 8) & 0xFFu] + (rp[q] >> 16);
                         key[pos] = rk[q];
-                        val[pos] = rv[q];
+                        val[pos] = (uint8_t)rp[q];
                     }
                 }
                 __syncthreads();
