@@ -636,8 +636,8 @@ const DevConfig* __restrict__ cfgp, EnvSides sides, double thr, int cap, DeviceS
                 d = (t >= ro7) ? dl7 : d;
                 d = (t >= ro8) ? dl8 : d;
                 idx[u] = t + d;
-                R0[u] = rec2[2 * (int64_t)idx[u]];
-                R1[u] = rec2[2 * (int64_t)idx[u] + 1];
+                R0[u] = rec2[2 * (uint64_t)(uint32_t)idx[u]];  // (record indices are non-negative: zero extension is cheaper)
+                R1[u] = rec2[2 * (uint64_t)(uint32_t)idx[u] + 1];
             }
             __builtin_amdgcn_sched_barrier(0);  // all 2U loads are issued before the first distance is computed
 #pragma unroll
@@ -650,8 +650,12 @@ const DevConfig* __restrict__ cfgp, EnvSides sides, double thr, int cap, DeviceS
                     d2 = d2 + dz * dz;
                     const uint64_t tc = d2u(R1[u].y);  // tag | cat << 32
                     bool ok = false;
-                    if (v && d2 < thr2) ok = ((uint32_t)idx[u] == apos) || tag_ok((int32_t)(uint32_t)tc);
-                    const unsigned long long m = __ballot(ok);
+                    if constexpr (TAGLIST) {
+                        if (v && d2 < thr2) ok = ((uint32_t)idx[u] == apos) || tag_ok((int32_t)(uint32_t)tc);
+                    } else {  // four compares and scalar mask logic, no branch
+                        ok = (v & (d2 < thr2)) & (((uint32_t)idx[u] == apos) | tag_ok((int32_t)(uint32_t)tc));
+                    }
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
                     if (ok) {
                         const int pos = count + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                         if (pos < cap) {
@@ -721,8 +725,9 @@ const DevConfig* __restrict__ cfgp, EnvSides sides, double thr, int cap, DeviceS
         // Typical environments (<= 512 points) are sorted in O(n) by one wavefront: inside a sphere the number of points
         // grows like d^3, so bucket = floor(256 * (d / thr)^3) spreads them almost evenly over 256 buckets (any
         // monotone map is correct; it only has to be balanced to be fast).  LDS histogram with returned slots -> wave
-        // scan of the bucket sizes -> in-place scatter from registers -> each lane insertion-sorts the 4 consecutive
-        // buckets it owns on the exact f64 keys.  Clustered inputs (a lane with > 48 points) use the bitonic network.
+        // scan of the bucket sizes -> scatter from registers, grouped by bucket -> every element ranks itself among the
+        // members of its own bucket on the exact f64 key (lane-parallel, a few LDS reads each) -> final placement.
+        // Clustered inputs (a bucket with > 16 points) use the bitonic network.
         constexpr int B = 256, EPT = 8;
         if (count <= 64 * EPT) {
             uint32_t* hist = reinterpret_cast<uint32_t*>(smem + (size_t)cap * 9 + ((16 - (((size_t)cap * 9) & 15)) & 15));  // [B + 1]
@@ -750,32 +755,49 @@ const DevConfig* __restrict__ cfgp, EnvSides sides, double thr, int cap, DeviceS
             const uint32_t mine = h0 + h1 + h2 + h3;
             const uint32_t incl = wave_incl_scan_u32(mine);
             const uint32_t seg_lo = incl - mine;
-            const unsigned long long too_big = __ballot(mine > 48u);
+            const unsigned long long too_big = __ballot(max(max(h0, h1), max(h2, h3)) > 16u);
             __syncthreads();
             hist[4 * lane] = seg_lo;
             hist[4 * lane + 1] = seg_lo + h0;
             hist[4 * lane + 2] = seg_lo + h0 + h1;
             hist[4 * lane + 3] = seg_lo + h0 + h1 + h2;
+            if (lane == 63) hist[B] = incl;  // = count
             __syncthreads();
             if (!too_big) {
+                // group by bucket (arrival order inside a bucket) ...
 #pragma unroll
                 for (int q = 0; q < EPT; ++q) {
                     const int i = lane + 64 * q;
                     if (i < count) {
                         const uint32_t pos = hist[(rp[q] >> 8) & 0xFFu] + (rp[q] >> 16);
                         key[pos] = rk[q];
-                        val[pos] = (uint8_t)rp[q];
+                        rp[q] = (rp[q] & 0xFFFFu) | (pos << 16);
                     }
                 }
                 __syncthreads();
-                const int lo = (int)seg_lo, hi = (int)incl;
-                for (int i = lo + 1; i < hi; ++i) {
-                    const uint64_t k = key[i];
-                    const uint8_t v = val[i];
-                    int j = i - 1;
-                    while (j >= lo && key[j] > k) { key[j + 1] = key[j]; val[j + 1] = val[j]; --j; }
-                    key[j + 1] = k;
-                    val[j + 1] = v;
+                // ... then every element ranks itself among the (one to a few) members of its bucket on the exact f64 key
+#pragma unroll
+                for (int q = 0; q < EPT; ++q) {
+                    const int i = lane + 64 * q;
+                    if (i < count) {
+                        const uint32_t b = (rp[q] >> 8) & 0xFFu, pos = rp[q] >> 16;
+                        const uint32_t s0 = hist[b], s1 = hist[b + 1];
+                        uint32_t rank = s0;
+                        for (uint32_t j = s0; j < s1; ++j) {
+                            const uint64_t kj = key[j];
+                            rank += (kj < rk[q]) | ((kj == rk[q]) & (j < pos));
+                        }
+                        rp[q] = (rp[q] & 0xFFFFu) | (rank << 16);
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < EPT; ++q) {
+                    const int i = lane + 64 * q;
+                    if (i < count) {
+                        key[rp[q] >> 16] = rk[q];
+                        val[rp[q] >> 16] = (uint8_t)rp[q];
+                    }
                 }
                 __syncthreads();
                 sorted = true;
