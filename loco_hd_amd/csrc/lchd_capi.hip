@@ -631,7 +631,7 @@ static int prims_enqueue(lchd_ctx* c) {
 
     auto grid_view = [](const GridPlan& g, const SideBufs& s) {
         GridView v{};
-        for (int k = 0; k < 3; ++k) { v.min[k] = g.min[k]; v.inv[k] = g.inv[k]; v.dim[k] = g.dim[k]; }
+        for (int k = 0; k < 3; ++k) { v.min[k] = g.min[k]; v.inv[k] = g.inv[k]; v.cell[k] = 1.0 / g.inv[k]; v.dim[k] = g.dim[k]; }
         v.n_cells = g.n_cells;
         v.cell_start = s.cell_start;
         v.rec = s.rec;

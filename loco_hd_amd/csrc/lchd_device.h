@@ -81,6 +81,7 @@ struct __attribute__((aligned(8))) AnchorRec {
 // Uniform grid over one cloud (replaces KdTree::build_by_ordered_float, src/locohd.rs:504-510).
 struct GridView {
     double min[3], inv[3];   // cell index = clamp(floor((p - min) * inv), 0, dim-1)
+    double cell[3];          // 1 / inv: the cell edge (only used to skip neighbour cells that lie wholly outside the radius)
     int32_t dim[3];          // per structure; cell = ((sid * dim[2] + cz) * dim[1] + cy) * dim[0] + cx
     int32_t n_cells;         // n_struct * dim[0] * dim[1] * dim[2]
     const uint32_t* cell_start;  // [n_cells + 1]

@@ -602,9 +602,20 @@ const DevConfig* __restrict__ cfgp, EnvSides sides, double thr, int cap, DeviceS
         const int kk = lane < 9 ? lane : 8;
         const int kz = (kk * 11) >> 5, ky = kk - 3 * kz;  // kk / 3, kk % 3 for kk < 9
         const int zz = cz - 1 + kz, yy = cy - 1 + ky;
-        const bool in = lane < 9 && zz >= 0 && zz < g.dim[2] && yy >= 0 && yy < g.dim[1];
+        // Neighbour cells that lie wholly outside the radius are skipped: with the anchor at fractional position f in its
+        // cell, a neighbour row / cell is at least (f or 1 - f) * edge away along every axis in which it differs.  A sphere
+        // of radius thr meets on average 17 of the 27 cells (edge = 1.1 thr), so a third of the candidates never get loaded.
+        // The test carries a relative margin of 1e-6 on thr^2 (rounding of the cell assignment is ~1e-16).
+        const double fx = (ax - g.min[0]) * g.inv[0] - (double)cx, fy = (ay - g.min[1]) * g.inv[1] - (double)cy,
+                     fz = (az - g.min[2]) * g.inv[2] - (double)cz;
+        const double gy = fmax((ky == 0 ? fy : (ky == 2 ? 1.0 - fy : 0.0)) * g.cell[1], 0.0);
+        const double gz = fmax((kz == 0 ? fz : (kz == 2 ? 1.0 - fz : 0.0)) * g.cell[2], 0.0);
+        const double gxl = fmax(fx * g.cell[0], 0.0), gxh = fmax((1.0 - fx) * g.cell[0], 0.0);
+        const double r2 = gy * gy + gz * gz, thr2m = thr2 * (1.0 + 1e-6);
+        const int xl = (r2 + gxl * gxl < thr2m) ? x0 : cx, xh = (r2 + gxh * gxh < thr2m) ? x1 : cx;  // this row's x range
+        const bool in = lane < 9 && zz >= 0 && zz < g.dim[2] && yy >= 0 && yy < g.dim[1] && r2 < thr2m;
         const int row = in ? (int)((((int64_t)asid * g.dim[2] + zz) * g.dim[1] + yy) * g.dim[0]) : 0;
-        const int b_ = (int)g.cell_start[row + x0], e_ = (int)g.cell_start[row + x1 + 1];
+        const int b_ = (int)g.cell_start[row + xl], e_ = (int)g.cell_start[row + xh + 1];
         const uint32_t len = in ? (uint32_t)(e_ - b_) : 0u;
         const uint32_t incl = wave_incl_scan_u32(len);
         const int roff_v = (int)(incl - len), dl_v = b_ - roff_v;
