@@ -96,8 +96,10 @@ __device__ __forceinline__ uint64_t wave_incl_scan_fields(uint64_t x) {
 // f64 across lanes without the LDS crossbar: DPP moves of the two halves (gfx9 DPP has whole-wave shifts)
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_mov_f64_or_zero(double v) {  // lanes without a source (or masked rows) read +0.0
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    // all rows enabled: bound_ctrl supplies the zero itself (no v_mov of the old value); masked rows need the explicit 0
+    constexpr bool BC = (ROW_MASK == 0xf);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, BC);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, BC);
     return __hiloint2double(hi, lo);
 }
 // value of lane - 1 (lane 0 keeps its own value): wave_shr:1
@@ -1099,6 +1101,9 @@ bool launch_env_rows(hipStream_t s, int cap, const DevConfig* cfg, const CloudVi
 enum { MODE_H2U = 0, MODE_H2W = 1, MODE_GEN = 2 };
 // where F(t) comes from: the environment keys already are F values / inline CDFs only / any CDF
 enum { F_KEY = 0, F_FAST = 1, F_ANY = 2 };
+#ifndef LCHD_PASS1_FUSED
+#define LCHD_PASS1_FUSED 1  // k_sweep: the chunk histogram is one fixed-trip loop over the lane's points
+#endif
 #ifndef LCHD_LDS_COUNTS
 #define LCHD_LDS_COUNTS 1   // k_sweep (Hellinger-2, LDS tables, > 12 category slots): per-lane category counts live in LDS during the event loop
 #endif
@@ -1576,6 +1581,29 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
             uint64_t hA[NH], hB[NH];
 #pragma unroll
             for (int k = 0; k < NH; ++k) hA[k] = hB[k] = 0;
+#if LCHD_PASS1_FUSED
+            if constexpr (NH == 1) {
+                // one fixed-trip loop over the chunk's (at most EPL) points, A's run first, then B's: the two data-dependent
+                // loops it replaces each ran for the longest run of any lane.  hT counts every point, hA only A's.
+                const int nAl = i1 - i0, nl = d1 - d0;
+                const uint8_t* pa_ = cA + i0;
+                const uint8_t* pb_ = cB + (j0 - nAl);
+                uint64_t hT = 0;
+#pragma unroll
+                for (int m = 0; m < EPL; ++m) {
+                    if (m < epl) {  // wave-uniform
+                        const bool isA = m < nAl;
+                        const int ct = (isA ? pa_ : pb_)[m < nl ? m : 0];
+                        const uint64_t inc = (m < nl) ? (1ull << ((ct & 15) * 4)) : 0ull;
+                        if (m < nl && ct >= C) bad_cat = true;
+                        hT += inc;
+                        hA[0] += isA ? inc : 0ull;
+                    }
+                }
+                hB[0] = hT - hA[0];
+            } else
+#endif
+            {
             for (int i = i0; i < i1; ++i) {
                 const int ct = cA[i];
                 if (ct >= C) bad_cat = true;
@@ -1587,6 +1615,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
                 if (ct >= C) bad_cat = true;
 #pragma unroll
                 for (int k = 0; k < NH; ++k) hB[k] += ((ct >> 4) == k) ? (1ull << ((ct & 15) * 4)) : 0ull;
+            }
             }
             STAMP(3);
             // widen to 16-bit fields and exclusive-scan across the wavefront
