@@ -1886,6 +1886,26 @@ __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs arg
 
         // pass 1: 4-bit-per-category histogram of the lane's chunk
         uint64_t hA = 0, hB = 0;
+#if LCHD_PASS1_FUSED
+        {   // one fixed-trip loop over the chunk's points, A's run first (see k_sweep)
+            const int nAl = i1 - i0, nl = d1 - d0;
+            const uint8_t* pa_ = cA + i0;
+            const uint8_t* pb_ = cB + (j0 - nAl);
+            uint64_t hT = 0;
+#pragma unroll
+            for (int m = 0; m < EPL; ++m) {
+                if (m < epl) {  // wave-uniform? no: epl differs between the two teams -- the test is per lane, the reads stay in range
+                    const bool isA = m < nAl;
+                    const int ct = (isA ? pa_ : pb_)[m < nl ? m : 0];
+                    const uint64_t inc = (m < nl) ? (1ull << ((ct & 15) * 4)) : 0ull;
+                    if (m < nl && ct >= C) bad_cat = true;
+                    hT += inc;
+                    hA += isA ? inc : 0ull;
+                }
+            }
+            hB = hT - hA;
+        }
+#else
         for (int i = i0; i < i1; ++i) {
             const int ct = cA[i];
             if (ct >= C) bad_cat = true;
@@ -1896,6 +1916,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs arg
             if (ct >= C) bad_cat = true;
             hB += 1ull << ((ct & 15) * 4);
         }
+#endif
         // packed counts at the start of the chunk: the anchors + an exclusive scan over the team's lanes
         uint64_t exA[NW], exB[NW];
 #pragma unroll
