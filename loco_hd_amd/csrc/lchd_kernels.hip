@@ -1540,19 +1540,25 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
             wave_sync_lds();  // previous tile fully consumed
             // stage the tile: the global loads of BOTH lists are issued before the first LDS write (one memory latency per tile)
             {
+                // (wave-uniform base + 32-bit lane offset + immediate: one address register pair serves all loads of a list)
                 uint64_t rkA[EPL], rkB[EPL];
                 uint8_t rcA[EPL], rcB[EPL];
+                const char* pkA = reinterpret_cast<const char*>(kA + (1 + ia));
+                const char* pkB = reinterpret_cast<const char*>(kB + (1 + ib));
+                const uint8_t* pcA = tA + (1 + ia);
+                const uint8_t* pcB = tB + (1 + ib);
+                const uint32_t lane8 = (uint32_t)lane * 8u, lane1 = (uint32_t)lane;
 #pragma unroll
                 for (int u = 0; u < EPL; ++u) {
-                    const int t = lane + 64 * u;
-                    rkA[u] = t < nAt ? kA[1 + ia + t] : 0ull;
-                    rcA[u] = t < nAt ? tA[1 + ia + t] : (uint8_t)0;
+                    const bool in = lane + 64 * u < nAt;
+                    rkA[u] = in ? *reinterpret_cast<const uint64_t*>(pkA + lane8 + 512u * u) : 0ull;
+                    rcA[u] = in ? pcA[lane1 + 64u * u] : (uint8_t)0;
                 }
 #pragma unroll
                 for (int u = 0; u < EPL; ++u) {
-                    const int t = lane + 64 * u;
-                    rkB[u] = t < nBt ? kB[1 + ib + t] : 0ull;
-                    rcB[u] = t < nBt ? tB[1 + ib + t] : (uint8_t)0;
+                    const bool in = lane + 64 * u < nBt;
+                    rkB[u] = in ? *reinterpret_cast<const uint64_t*>(pkB + lane8 + 512u * u) : 0ull;
+                    rcB[u] = in ? pcB[lane1 + 64u * u] : (uint8_t)0;
                 }
 #pragma unroll
                 for (int u = 0; u < EPL; ++u) {
