@@ -1457,6 +1457,11 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
             double acc2 = 0.0;
 #pragma unroll
             for (int k = 0; k < NW; ++k) {
+                // the chunk-start words go through an empty volatile asm: they do not change during the event loop, and the
+                // optimiser otherwise hoists all 2 * CMAX table addresses of this rarely taken path out of the loop, where
+                // they occupy registers the common path has to spill for
+                uint64_t ea = exA[k], eb = exB[k];
+                if constexpr (!LDSCNT) asm volatile("" : "+v"(ea), "+v"(eb));
 #pragma unroll
                 for (int f = 0; f < 4; ++f) {
                     const int c = 4 * k + f;
@@ -1465,8 +1470,8 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
                         ca = *reinterpret_cast<const uint16_t*>(lcl + (c >> 2) * 512 + (c & 3) * 2);
                         cb = *reinterpret_cast<const uint16_t*>(lcl + kLcSide + (c >> 2) * 512 + (c & 3) * 2);
                     } else {
-                        ca = field(exA, c) + (int)((dA[c >> 4] >> ((c & 15) * 4)) & 15ull);
-                        cb = field(exB, c) + (int)((dB[c >> 4] >> ((c & 15) * 4)) & 15ull);
+                        ca = (int)((ea >> (f * 16)) & 0xFFFFull) + (int)((dA[c >> 4] >> ((c & 15) * 4)) & 15ull);
+                        cb = (int)((eb >> (f * 16)) & 0xFFFFull) + (int)((dB[c >> 4] >> ((c & 15) * 4)) & 15ull);
                     }
                     const double d = root_of(c, ca) * ra - root_of(c, cb) * rb;  // equal inputs cancel exactly
                     acc2 = fma(d, d, acc2);
