@@ -1107,6 +1107,9 @@ enum { F_KEY = 0, F_FAST = 1, F_ANY = 2 };
 #ifndef LCHD_LDS_COUNTS
 #define LCHD_LDS_COUNTS 1   // k_sweep (Hellinger-2, LDS tables, > 12 category slots): per-lane category counts live in LDS during the event loop
 #endif
+#ifndef LCHD_HEADS_REREAD
+#define LCHD_HEADS_REREAD 1   // k_sweep: both list heads are re-read from LDS after every event
+#endif
 #ifndef LCHD_BRANCHFREE_HEADS
 #define LCHD_BRANCHFREE_HEADS 1
 #endif
@@ -1657,12 +1660,27 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
             // that was consumed is refilled with a single (address-selected) LDS read.  The packed counts exA/exB stay
             // fixed at their chunk-start values; what the chunk itself adds (<= 6 per category) is kept in 4-bit fields.
             int i = i0, j = j0;
+#if LCHD_HEADS_REREAD
+            uint64_t ka = sA[i], kb = sB[j];  // both heads are re-read after every event; run ends are tested on the indices
+#else
             uint64_t ka = (i < i1) ? sA[i] : kPadKey, kb = (j < j1) ? sB[j] : kPadKey;
+#endif
 #pragma unroll
             for (int k = 0; k < NH; ++k) dA[k] = dB[k] = 0;
             double Fp = 0.0, Hp = 0.0, firstF = 0.0, local = 0.0;
             for (int e = 0; e < epl; ++e) {
                 if (d0 + e < d1) {
+#if LCHD_HEADS_REREAD
+                    // A-first on ties; an exhausted run cannot be taken.  Two LDS reads per event instead of one, but none of
+                    // the selects that steer a single refill into the right head register (the kernel is VALU-issue bound).
+                    const bool takeA = (i < i1) & ((j >= j1) | (ka <= kb));
+                    const uint64_t key = takeA ? ka : kb;
+                    const int ct = (takeA ? cA : cB)[takeA ? i : j];
+                    i += takeA ? 1 : 0;
+                    j += takeA ? 0 : 1;
+                    ka = sA[i];  // (one past the run's end at most: inside the tile buffers, never used)
+                    kb = sB[j];
+#else
                     const bool takeA = (ka <= kb);  // an exhausted list shows the pad key (> every real key)
                     const uint64_t key = takeA ? ka : kb;
 #if LCHD_BRANCHFREE_HEADS
@@ -1679,6 +1697,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
 #else
                     const int ct = takeA ? cA[i] : cB[j];
                     if (takeA) { ++i; ka = (i < i1) ? sA[i] : kPadKey; } else { ++j; kb = (j < j1) ? sB[j] : kPadKey; }
+#endif
 #endif
                     const double F = cdf_of_key(key);
                     if (e == 0) firstF = F; else local += (F - Fp) * Hp;
