@@ -1161,6 +1161,14 @@ extern "C" int lchd_from_anchors(lchd_ctx* c, const lchd_config* cfg, const int3
                                                "unsorted input is unspecified)");
         }
     }
+    // pmf.rs:38-42: every point of both lists enters a PMF.  (The environment kernels make this check for the other entry
+    // points; here the lists go to the sweep kernel as they are, and that kernel does not test categories.)
+    for (int side = 0; side < 2; ++side) {
+        const int32_t* q = side ? seq_b : seq_a;
+        const int64_t n = side ? len_seq_b : len_seq_a;
+        for (int64_t i = 0; i < n; ++i)
+            if (q[i] < 0 || q[i] >= cfg->n_categories) return fail(LCHD_EVALUE, "Category not found!");
+    }
     EnvStore ea{}, eb{};
     double* d_out = nullptr;
     int4* d_meta = nullptr;

@@ -555,7 +555,6 @@ const DevConfig* __restrict__ cfgp, EnvSides sides, double thr, int cap, DeviceS
     // kernel arguments is read with a wave-uniform index (scalar loads from the kernarg segment, no per-field selects)
     const int side = (int64_t)blockIdx.x >= sides.s[0].max_envs ? 1 : 0;
     const EnvSide& S = sides.s[side];
-    const CloudView c = S.c;
     const GridView g = S.g;
     const AnchorRec* __restrict__ uniq = S.uniq;
     const EnvStore env = S.env;
@@ -835,7 +834,16 @@ const DevConfig* __restrict__ cfgp, EnvSides sides, double thr, int cap, DeviceS
     ESTAMP(3);
     uint64_t* ok_ = env.key + e * env.stride;
     uint8_t* oc_ = env.cat + e * env.stride;
-    for (int i = tid; i < count; i += NT) { ok_[i] = key[i]; oc_[i] = val[i]; }
+    // categories outside the map are reported HERE (pmf.rs:38-42 raises for a point of a used environment, which is exactly
+    // what gets written below) and stored as 0: the sweep kernels do not test categories again
+    bool bad = false;
+    for (int i = tid; i < count; i += NT) {
+        const uint8_t v = val[i];
+        bad |= (int)v >= cfg.n_categories;
+        ok_[i] = key[i];
+        oc_[i] = (int)v < cfg.n_categories ? v : (uint8_t)0;
+    }
+    if (__ballot(bad) && (tid & 63) == 0) atomicOr(&st->flags, ST_BAD_CATEGORY);
     if (tid == 0) env.len[e] = count;
     ESTAMP(4);
 }
@@ -1035,10 +1043,25 @@ __global__ __launch_bounds__(NT) void k_env_rows(const DevConfig* __restrict__ c
     }
     __syncthreads();
     if (env.cdf_keys) keys_to_cdf_lds<NT>(key, n, tid, cfgp);
-    if constexpr (!GLOBALKV) {
-        uint64_t* ok_ = env.key + r * env.stride;
-        uint8_t* oc_ = env.cat + r * env.stride;
-        for (int i = tid; i < n; i += NT) { ok_[i] = key[i]; oc_[i] = val[i]; }
+    {   // categories outside the map: reported here, stored as 0 (see k_env_cells)
+        const int C = cfgp->n_categories;
+        bool bad_c = false;
+        if constexpr (!GLOBALKV) {
+            uint64_t* ok_ = env.key + r * env.stride;
+            uint8_t* oc_ = env.cat + r * env.stride;
+            for (int i = tid; i < n; i += NT) {
+                const uint8_t v = val[i];
+                bad_c |= (int)v >= C;
+                ok_[i] = key[i];
+                oc_[i] = (int)v < C ? v : (uint8_t)0;
+            }
+        } else {
+            for (int i = tid; i < n; i += NT) {
+                const uint8_t v = val[i];
+                if ((int)v >= C) { bad_c = true; val[i] = 0; }
+            }
+        }
+        if (__ballot(bad_c) && (tid & 63) == 0) atomicOr(&st->flags, ST_BAD_CATEGORY);
     }
 }
 
@@ -1396,11 +1419,10 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
             else return cdf_dev<WFANY>(wf, u2d(k));
         };
 
-        bool bad_cat = false, zero_norm = false;
+        bool zero_norm = false;
         // wave-uniform packed integer category counts (16-bit fields), seeded with the two anchors (:82-84)
         uint64_t cntA[NW], cntB[NW];
         {
-            if (c0a >= C || c0b >= C) bad_cat = true;
 #pragma unroll
             for (int k = 0; k < NW; ++k) {
                 cntA[k] = ((c0a >> 2) == k) ? (1ull << ((c0a & 3) * 16)) : 0ull;
@@ -1535,7 +1557,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
             H_carry = (c0a == c0b) ? 0.0 : 1.0;
         } else {
             load_state();
-            H_carry = bad_cat ? 0.0 : distance();
+            H_carry = distance();
         }
         double acc = 0.0;
 
@@ -1609,7 +1631,6 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
                         const bool isA = m < nAl;
                         const int ct = (isA ? pa_ : pb_)[m < nl ? m : 0];
                         const uint64_t inc = (m < nl) ? (1ull << ((ct & 15) * 4)) : 0ull;
-                        if (m < nl && ct >= C) bad_cat = true;
                         hT += inc;
                         hA[0] += isA ? inc : 0ull;
                     }
@@ -1620,13 +1641,11 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
             {
             for (int i = i0; i < i1; ++i) {
                 const int ct = cA[i];
-                if (ct >= C) bad_cat = true;
 #pragma unroll
                 for (int k = 0; k < NH; ++k) hA[k] += ((ct >> 4) == k) ? (1ull << ((ct & 15) * 4)) : 0ull;
             }
             for (int j = j0; j < j1; ++j) {
                 const int ct = cB[j];
-                if (ct >= C) bad_cat = true;
 #pragma unroll
                 for (int k = 0; k < NH; ++k) hB[k] += ((ct >> 4) == k) ? (1ull << ((ct & 15) * 4)) : 0ull;
             }
@@ -1710,8 +1729,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
                             // counts of category ct on both sides: two 16-bit LDS reads at one address (+ an immediate for side
                             // B); the side that took the event writes its count back incremented.  LDS serves a wave's requests
                             // in order, so the next event of this lane sees the update.
-                            const int ctc = min(ct, CMAX - 1);  // a category outside the map is flagged above; keep the address in range
-                            unsigned char* pf = lcl + ((ctc >> 2) << 9) + ((ctc & 3) << 1);
+                            unsigned char* pf = lcl + ((ct >> 2) << 9) + ((ct & 3) << 1);
                             cntA_ = *reinterpret_cast<const uint16_t*>(pf);
                             cntB_ = *reinterpret_cast<const uint16_t*>(pf + kLcSide);
                             *reinterpret_cast<uint16_t*>(pf + (takeA ? 0 : kLcSide)) = (uint16_t)((takeA ? cntA_ : cntB_) + 1);
@@ -1728,7 +1746,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
                         if constexpr (NH == 2) { qA = (ct & 16) ? dA[1] : qA; qB = (ct & 16) ? dB[1] : qB; }
                         cntA_ = (int)((wA >> sh) & 0xFFFFull) + (int)((qA >> sh4) & 15ull);  // before the update
                         cntB_ = (int)((wB >> sh) & 0xFFFFull) + (int)((qB >> sh4) & 15ull);
-                        const uint64_t inc4 = (ct < C) ? (1ull << sh4) : 0ull;
+                        const uint64_t inc4 = 1ull << sh4;
                         if constexpr (NH == 2) {
                             dA[0] += (takeA && !(ct & 16)) ? inc4 : 0ull;
                             dA[1] += (takeA && (ct & 16)) ? inc4 : 0ull;
@@ -1785,9 +1803,8 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
         acc = wave_sum_f64(acc);
         const double Finf = args.wf_index ? finf_tab[wfi] : Finf0;
         acc += (Finf - F_carry) * H_carry;
-        const unsigned long long anybad = __ballot(bad_cat), anyzero = __ballot(zero_norm);
+        const unsigned long long anyzero = __ballot(zero_norm);  // (categories were checked when the environments were built)
         if (lane == 0) {
-            if (anybad) { atomicOr(&args.st->flags, ST_BAD_CATEGORY); acc = nan(""); }
             if (anyzero) atomicOr(&args.st->flags, ST_ZERO_NORM);
             args.out[p] = acc;
         }
@@ -1846,7 +1863,6 @@ __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs arg
     const int tid = threadIdx.x, lane = tid & 63, tl = lane & 31, team = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const DevConfig* __restrict__ cfgp = args.cfg;
-    const int C = cfgp->n_categories;
     const double Finf0 = cfgp->wf_finf[0];
     for (int k = tid; k < NT; k += 64 * WPB) {
         t_sqrt[k] = args.sqrt_tab[k];
@@ -1873,7 +1889,6 @@ __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs arg
         const uint64_t* __restrict__ kB = args.env_b.key + (int64_t)m.y * args.env_b.stride;
         const uint8_t* __restrict__ tA = args.env_a.cat + (int64_t)m.x * args.env_a.stride;
         const uint8_t* __restrict__ tB = args.env_b.cat + (int64_t)m.y * args.env_b.stride;
-        bool bad_cat = valid && (c0a >= C || c0b >= C);
         const double F0 = valid ? u2d(kA[0]) : 0.0;            // F(0): both anchors sit at distance 0
         const double H0 = (c0a == c0b) ? 0.0 : 1.0;            // two point masses
 
@@ -1928,7 +1943,6 @@ __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs arg
                     const bool isA = m < nAl;
                     const int ct = (isA ? pa_ : pb_)[m < nl ? m : 0];
                     const uint64_t inc = (m < nl) ? (1ull << ((ct & 15) * 4)) : 0ull;
-                    if (m < nl && ct >= C) bad_cat = true;
                     hT += inc;
                     hA += isA ? inc : 0ull;
                 }
@@ -1938,12 +1952,10 @@ __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs arg
 #else
         for (int i = i0; i < i1; ++i) {
             const int ct = cA[i];
-            if (ct >= C) bad_cat = true;
             hA += 1ull << ((ct & 15) * 4);
         }
         for (int j = j0; j < j1; ++j) {
             const int ct = cB[j];
-            if (ct >= C) bad_cat = true;
             hB += 1ull << ((ct & 15) * 4);
         }
 #endif
@@ -2003,7 +2015,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs arg
                 }
                 const int cntA_ = (int)((wA >> sh) & 0xFFFFull) + (int)((dA >> sh4) & 15ull);  // before the update
                 const int cntB_ = (int)((wB >> sh) & 0xFFFFull) + (int)((dB >> sh4) & 15ull);
-                const uint64_t inc4 = (ct < C) ? (1ull << sh4) : 0ull;
+                const uint64_t inc4 = 1ull << sh4;
                 dA += takeA ? inc4 : 0ull;
                 dB += takeA ? 0ull : inc4;
                 const int mine = takeA ? cntA_ : cntB_, other = takeA ? cntB_ : cntA_;
@@ -2039,12 +2051,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs arg
         const int last = T > 0 ? (T - 1) / epl : 0;  // the team lane that holds the last event (lane 0 if there is none)
         if (tl == last) local += (T > 0) ? (Finf0 - Fp) * Hp : (Finf0 - F0) * H0;
         const double acc = half_sum_f64(local);
-        const unsigned long long anybad = __ballot(bad_cat);
-        const bool team_bad = ((team ? (anybad >> 32) : anybad) & 0xFFFFFFFFull) != 0;
-        if (tl == 31 && live && mine) {
-            if (team_bad) atomicOr(&args.st->flags, ST_BAD_CATEGORY);
-            args.out[p] = (valid && !team_bad) ? acc : nan("");
-        }
+        if (tl == 31 && live && mine) args.out[p] = valid ? acc : nan("");  // (categories were checked when the environments were built)
     }
 }
 
