@@ -1735,9 +1735,9 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
                             *reinterpret_cast<uint16_t*>(pf + (takeA ? 0 : kLcSide)) = (uint16_t)((takeA ? cntA_ : cntB_) + 1);
                         } else {
                         const int sh = (ct & 3) * 16, sh4 = (ct & 15) * 4;
-                        uint64_t wA = 0, wB = 0;
+                        uint64_t wA = exA[0], wB = exB[0];  // (every category is inside the map: checked at the environment build)
 #pragma unroll
-                        for (int k = 0; k < NW; ++k) {
+                        for (int k = 1; k < NW; ++k) {
                             const bool hit = ((ct >> 2) == k);
                             wA = hit ? exA[k] : wA;
                             wB = hit ? exB[k] : wB;
@@ -1767,6 +1767,9 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
                             const double r = 1.0 / sqrt(takeA ? na : nb);
                             ra = takeA ? r : ra;
                             rb = takeA ? rb : r;
+                        } else if constexpr (LDSTAB) {
+                            ra = rsqrt_cnt(totA);  // two table reads instead of one read and five selects
+                            rb = rsqrt_cnt(totB);
                         } else {
                             const double r = rsqrt_cnt(takeA ? totA : totB);
                             ra = takeA ? r : ra;
