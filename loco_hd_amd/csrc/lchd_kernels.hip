@@ -2009,9 +2009,9 @@ __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs arg
                 totA += takeA ? 1 : 0;
                 totB += takeA ? 0 : 1;
                 const int sh = (ct & 3) * 16, sh4 = (ct & 15) * 4;
-                uint64_t wA = 0, wB = 0;
+                uint64_t wA = exA[0], wB = exB[0];
 #pragma unroll
-                for (int k = 0; k < NW; ++k) {
+                for (int k = 1; k < NW; ++k) {
                     const bool hit = ((ct >> 2) == k);
                     wA = hit ? exA[k] : wA;
                     wB = hit ? exB[k] : wB;
@@ -2023,9 +2023,8 @@ __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs arg
                 dB += takeA ? 0ull : inc4;
                 const int mine = takeA ? cntA_ : cntB_, other = takeA ? cntB_ : cntA_;
                 D += (t_sqrt[mine + 1] - t_sqrt[mine]) * t_sqrt[other];
-                const double r = t_rsqrt[takeA ? totA : totB];
-                ra = takeA ? r : ra;
-                rb = takeA ? rb : r;
+                ra = t_rsqrt[totA];
+                rb = t_rsqrt[totB];
                 double h2 = 1.0 - (ra * rb) * D;
                 if (h2 < kExactH2Below) {  // literal difference-of-roots form where the cancellation form loses accuracy (k_sweep::exact_h2)
                     double acc2 = 0.0;
