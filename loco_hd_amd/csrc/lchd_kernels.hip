@@ -1767,8 +1767,9 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
                             const double r = 1.0 / sqrt(takeA ? na : nb);
                             ra = takeA ? r : ra;
                             rb = takeA ? rb : r;
-                        } else if constexpr (LDSTAB) {
-                            ra = rsqrt_cnt(totA);  // two table reads instead of one read and five selects
+                        } else if constexpr (LDSTAB && !LDSCNT) {
+                            ra = rsqrt_cnt(totA);  // two table reads instead of one read and five selects (the LDS-count variants already
+                                                   // queue five LDS operations per event: there the select form is the faster one)
                             rb = rsqrt_cnt(totB);
                         } else {
                             const double r = rsqrt_cnt(takeA ? totA : totB);
