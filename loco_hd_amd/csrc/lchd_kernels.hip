@@ -1178,10 +1178,12 @@ __device__ __forceinline__ int merge_path(const uint64_t* A, int nA, const uint6
 
 // spread the four 4-bit fields of the low 16 bits of x into four 16-bit fields
 __device__ __forceinline__ uint64_t spread4(uint64_t x) {
-    x &= 0xFFFFull;
-    x = (x | (x << 24)) & 0x000000FF000000FFull;
-    x = (x | (x << 12)) & 0x000F000F000F000Full;
-    return x;
+    // two 32-bit halves, three operations each (and, and / bfe, shift-or); the 64-bit shift-or-mask form is compiled to
+    // quarter-rate 32x32 multiplies
+    const uint32_t v = (uint32_t)x;
+    const uint32_t lo = (v & 0xFu) | ((v & 0xF0u) << 12);
+    const uint32_t hi = ((v >> 8) & 0xFu) | ((v & 0xF000u) << 4);
+    return ((uint64_t)hi << 32) | lo;
 }
 
 // One pair's weight function.  hyper_exp with <= 4 terms and uniform keep their parameters in (scalar)
