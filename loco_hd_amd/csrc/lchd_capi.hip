@@ -156,6 +156,7 @@ enum { PH_CELLS = 0, PH_ANCHORS = 1, PH_ENV = 2, PH_SWEEP = 3, PH_N = 4 };
 struct lchd_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    Tuning tune{};  // LCHD_* test / tuning hooks, read once in lchd_ctx_create
     // configuration
     bool cfg_set = false;
     bool hellinger2 = false, unit_weights = false, wf_pow = false;  // which sweep kernel variant applies
@@ -166,8 +167,11 @@ struct lchd_ctx {
     // workspace arena
     char* ws = nullptr;
     size_t ws_cap = 0;
-    DeviceStatus* d_status = nullptr;
-    DeviceStatus* h_status = nullptr;  // pinned
+    DeviceStatus* d_status = nullptr;  // clean (all zero) between passes: k_pair_meta's last workgroup resets it
+    HostStatus* h_status = nullptr;    // pinned, device-visible: the kernels publish into it with plain stores (no D2H copy)
+    bool status_dirty = false;         // a pass was abandoned half-way: memset d_status before the next one
+    uint32_t seq = 0;                  // pass counter (HostStatus::snapshot_seq)
+    int sweep_hint = 0;                // 0 unknown, 1 small pairs were the majority in the last pass, 2 they were not (launch_sweep)
     unsigned long long* d_points = nullptr;
     double* d_tabs = nullptr;  // sqrt(k) | 1/sqrt(k), 65536 entries each
     uint32_t* d_partials = nullptr;  // scratch of k_pair_meta (kMetaPartials words)
@@ -176,7 +180,7 @@ struct lchd_ctx {
     size_t io_cap = 0;
     std::vector<char> cfg_blob_host;  // last configuration blob uploaded (identical configurations are not uploaded again)
     int cap_hint = 512;
-    bool cap_env_done = false;
+    int shrink_votes = 0;  // consecutive passes whose largest environment would fit half of cap_hint
     // timing
     bool timing = false;
     hipEvent_t ev[PH_N + 1] = {};
@@ -212,6 +216,45 @@ struct Arena {
     }
 };
 
+// HIP's current device is per-thread state that torch, another context or another library may change between two calls:
+// every entry point that takes a context makes the context's device current for its duration and restores the caller's.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int device) {  // device < 0: nothing to do
+        if (device < 0) return;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) switched = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched && prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define CTX_GUARD(c) DeviceGuard device_guard_((c)->device)
+
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+static Tuning tuning_from_env() {  // the ONLY place that reads LCHD_* hooks (tests and tuning runs; unset in production)
+    Tuning t;
+    t.no_struct_cells = getenv("LCHD_NO_STRUCT_CELLS") != nullptr;
+    t.no_small_dedupe = getenv("LCHD_NO_SMALL_DEDUPE") != nullptr;
+    t.no_cdf_keys = getenv("LCHD_NO_CDF_KEYS") != nullptr;
+    t.no_duo = getenv("LCHD_NO_DUO") != nullptr;
+    t.force_wide = env_int("LCHD_FORCE_WIDE", 0) != 0;
+    t.force_generic = env_int("LCHD_FORCE_GENERIC", 0) != 0;
+    t.force_bigenv = env_int("LCHD_FORCE_BIGENV", 0) != 0;
+    t.no_sweep_hint = getenv("LCHD_NO_SWEEP_HINT") != nullptr;
+    t.no_count8 = getenv("LCHD_NO_COUNT8") != nullptr;
+    t.no_tables = getenv("LCHD_NO_SD_TABLES") != nullptr;
+    t.force_cmax = env_int("LCHD_FORCE_CMAX", 0);
+    t.cap_hint = env_int("LCHD_CAP_HINT", 0);
+    return t;
+}
+
 static int ensure_ws(lchd_ctx* ctx, size_t need) {
     if (need <= ctx->ws_cap) return LCHD_OK;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -219,36 +262,65 @@ static int ensure_ws(lchd_ctx* ctx, size_t need) {
     ctx->ws = nullptr;
     ctx->ws_cap = 0;
     ctx->last_valid = false;
-    const size_t want = need + need / 8 + (1 << 20);
-    HIP_TRY(hipMalloc(&ctx->ws, want));
-    ctx->ws_cap = want;
+    size_t got = need + need / 8 + (1 << 20);
+    hipError_t e = hipMalloc(&ctx->ws, got);
+    if (e != hipSuccess) {  // without the growth margin
+        (void)hipGetLastError();
+        got = need;
+        e = hipMalloc(&ctx->ws, got);
+    }
+    if (e != hipSuccess) {
+        ctx->ws = nullptr;
+        (void)hipGetLastError();
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        return fail(LCHD_EUNSUPPORTED, "this call needs a device workspace of %zu bytes (environment store included) but only %zu of %zu "
+                                       "bytes are free on the device", need, free_b, total_b);
+    }
+    ctx->ws_cap = got;
     return LCHD_OK;
 }
 
 extern "C" int lchd_ctx_create(int32_t device, lchd_ctx** out) {
+    if (!out) return fail(LCHD_EVALUE, "null output pointer");
+    *out = nullptr;
     int n_dev = 0;
     hipError_t e = hipGetDeviceCount(&n_dev);
     if (e != hipSuccess || n_dev <= 0)
         return fail(LCHD_EDEVICE, "no usable HIP device (hipGetDeviceCount -> %d, %d devices): the LoCoHD scoring path has no "
                                   "CPU fallback", (int)e, n_dev);
-    if (device >= 0) HIP_TRY(hipSetDevice(device));
+    if (device >= n_dev) return fail(LCHD_EDEVICE, "device %d requested, %d HIP devices visible", device, n_dev);
+    int cur = 0;
+    HIP_TRY(hipGetDevice(&cur));
     lchd_ctx* c = new lchd_ctx();
-    HIP_TRY(hipGetDevice(&c->device));
-    HIP_TRY(hipMalloc(&c->d_cfg, sizeof(DevConfig)));
-    HIP_TRY(hipMalloc(&c->d_status, sizeof(DeviceStatus)));
-    HIP_TRY(hipMalloc(&c->d_points, sizeof(unsigned long long)));
-    HIP_TRY(hipHostMalloc(&c->h_status, sizeof(DeviceStatus)));
-    HIP_TRY(hipMalloc(&c->d_tabs, sizeof(double) * 2 * 65536));
-    HIP_TRY(hipMalloc(&c->d_partials, sizeof(uint32_t) * kMetaPartials));
+    c->device = device >= 0 ? device : cur;
+    c->tune = tuning_from_env();
+    if (c->tune.cap_hint > 0) c->cap_hint = c->tune.cap_hint;
+    CTX_GUARD(c);  // the caller's current device is restored on every path out of here
+    auto bail = [&](hipError_t err, const char* what) {
+        lchd_ctx_destroy(c);
+        return fail(LCHD_EDEVICE, "HIP error %d (%s) in lchd_ctx_create: %s", (int)err, hipGetErrorName(err), what);
+    };
+    if ((e = hipMalloc(&c->d_cfg, sizeof(DevConfig))) != hipSuccess) return bail(e, "hipMalloc(config)");
+    if ((e = hipMalloc(&c->d_status, sizeof(DeviceStatus))) != hipSuccess) return bail(e, "hipMalloc(status)");
+    if ((e = hipMemset(c->d_status, 0, sizeof(DeviceStatus))) != hipSuccess) return bail(e, "hipMemset(status)");
+    if ((e = hipMalloc(&c->d_points, sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(points)");
+    if ((e = hipHostMalloc(&c->h_status, sizeof(HostStatus))) != hipSuccess) return bail(e, "hipHostMalloc(status)");
+    memset(c->h_status, 0, sizeof(HostStatus));
+    if ((e = hipMalloc(&c->d_tabs, sizeof(double) * 2 * 65536)) != hipSuccess) return bail(e, "hipMalloc(tables)");
+    if ((e = hipMalloc(&c->d_partials, sizeof(uint32_t) * kMetaPartials)) != hipSuccess) return bail(e, "hipMalloc(partials)");
+    init_device_kernels();  // per device, not per process
     launch_fill_sqrt_tables(c->stream, c->d_tabs, c->d_tabs + 65536);
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    for (auto& ev : c->ev) HIP_TRY(hipEventCreate(&ev));
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(e, "table fill");
+    for (auto& ev : c->ev)
+        if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
     *out = c;
     return LCHD_OK;
 }
 
 extern "C" void lchd_ctx_destroy(lchd_ctx* c) {
     if (!c) return;
+    CTX_GUARD(c);
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->ws);
     (void)hipFree(c->d_blob);
@@ -259,30 +331,36 @@ extern "C" void lchd_ctx_destroy(lchd_ctx* c) {
     (void)hipFree(c->d_partials);
     (void)hipFree(c->d_io);
     if (c->h_io) (void)hipHostFree(c->h_io);
-    (void)hipHostFree(c->h_status);
-    for (auto& ev : c->ev) (void)hipEventDestroy(ev);
+    if (c->h_status) (void)hipHostFree(c->h_status);
+    for (auto& ev : c->ev)
+        if (ev) (void)hipEventDestroy(ev);
     delete c;
 }
 
 extern "C" int lchd_ctx_set_stream(lchd_ctx* c, void* s) {
     if (!c) return fail(LCHD_EVALUE, "null context");
+    if (c->pend.active) return fail(LCHD_EVALUE, "an asynchronous call has not been finished (lchd_ctx_finish)");
+    CTX_GUARD(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->stream = reinterpret_cast<hipStream_t>(s);
     return LCHD_OK;
 }
 
 extern "C" int lchd_ctx_enable_timing(lchd_ctx* c, int32_t on) {
+    if (!c) return fail(LCHD_EVALUE, "null context");
     c->timing = on != 0;
     return LCHD_OK;
 }
 extern "C" double lchd_ctx_last_ms(lchd_ctx* c, const char* phase) {
     static const char* names[PH_N] = {"cells", "anchors", "env", "sweep"};
+    if (!c || !phase) return -1.0;
     for (int i = 0; i < PH_N; ++i)
         if (!strcmp(phase, names[i])) return c->ms[i];
     return -1.0;
 }
 extern "C" int64_t lchd_ctx_last_env_points(lchd_ctx* c) {
-    if (!c->last_valid) return -1;
+    if (!c || !c->last_valid || c->pend.active) return -1;
+    CTX_GUARD(c);
     launch_env_points(c->stream, c->last, c->d_points);
     unsigned long long v = 0;
     if (hipMemcpyAsync(&v, c->d_points, sizeof v, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
@@ -292,6 +370,8 @@ extern "C" int64_t lchd_ctx_last_env_points(lchd_ctx* c) {
 
 extern "C" int lchd_ctx_set_config(lchd_ctx* c, const lchd_config* cfg) {
     if (!c || !cfg) return fail(LCHD_EVALUE, "null context/config");
+    if (c->pend.active) return fail(LCHD_EVALUE, "an asynchronous call has not been finished (lchd_ctx_finish)");
+    CTX_GUARD(c);
     const int C = cfg->n_categories;
     if (C <= 0) return fail(LCHD_EVALUE, "The number of possible categories (primitive types) cannot be zero!");
     if (C > 255) return fail(LCHD_EUNSUPPORTED, "at most 255 categories are supported (categories travel as u8; got %d)", C);
@@ -341,6 +421,7 @@ extern "C" int lchd_ctx_set_config(lchd_ctx* c, const lchd_config* cfg) {
     }
     HIP_TRY(hipMemcpy(c->d_blob, blob.data(), total, hipMemcpyHostToDevice));
     c->cfg_set = false;
+    c->sweep_hint = 0;  // another configuration: what the last pass looked like says nothing about the next
     c->cfg_blob_host.swap(sig);
     DevConfig h{};
     h.n_categories = C;
@@ -402,28 +483,37 @@ static std::vector<uint8_t> cats_to_u8(const int32_t* cat, int64_t n) {
 }
 
 extern "C" int lchd_cloud_create(lchd_ctx* c, const double* xyz, const int32_t* cat, const int32_t* tag, int64_t n, lchd_cloud** out) {
-    if (!c) return fail(LCHD_EVALUE, "null context");
+    if (!c || !out) return fail(LCHD_EVALUE, "null context");
+    *out = nullptr;
     if (n < 0 || n > (int64_t)1 << 30) return fail(LCHD_EUNSUPPORTED, "cloud size %lld out of range", (long long)n);
+    if (n > 0 && !cat) return fail(LCHD_EVALUE, "null category array");
+    CTX_GUARD(c);
     lchd_cloud* cl = new lchd_cloud();
     cl->n = n;
     const size_t m = (size_t)std::max<int64_t>(n, 1);
-    HIP_TRY(hipMalloc(&cl->x, sizeof(double) * m));
-    HIP_TRY(hipMalloc(&cl->y, sizeof(double) * m));
-    HIP_TRY(hipMalloc(&cl->z, sizeof(double) * m));
-    HIP_TRY(hipMalloc(&cl->cat, m));
-    HIP_TRY(hipMalloc(&cl->tag, sizeof(int32_t) * m));
+    auto bail = [&](hipError_t e, const char* what) {  // nothing allocated so far outlives a failed call
+        lchd_cloud_destroy(c, cl);
+        return fail(LCHD_EDEVICE, "HIP error %d (%s) in lchd_cloud_create: %s", (int)e, hipGetErrorName(e), what);
+    };
+    hipError_t e;
+    if ((e = hipMalloc(&cl->x, sizeof(double) * m)) != hipSuccess) return bail(e, "hipMalloc(x)");
+    if ((e = hipMalloc(&cl->y, sizeof(double) * m)) != hipSuccess) return bail(e, "hipMalloc(y)");
+    if ((e = hipMalloc(&cl->z, sizeof(double) * m)) != hipSuccess) return bail(e, "hipMalloc(z)");
+    if ((e = hipMalloc(&cl->cat, m)) != hipSuccess) return bail(e, "hipMalloc(cat)");
+    if ((e = hipMalloc(&cl->tag, sizeof(int32_t) * m)) != hipSuccess) return bail(e, "hipMalloc(tag)");
     if (xyz) {
         if (int rc = upload_coords(c, cl, xyz)) { lchd_cloud_destroy(c, cl); return rc; }
     } else {
-        HIP_TRY(hipMemsetAsync(cl->x, 0, sizeof(double) * m, c->stream));
-        HIP_TRY(hipMemsetAsync(cl->y, 0, sizeof(double) * m, c->stream));
-        HIP_TRY(hipMemsetAsync(cl->z, 0, sizeof(double) * m, c->stream));
+        if ((e = hipMemsetAsync(cl->x, 0, sizeof(double) * m, c->stream)) != hipSuccess) return bail(e, "hipMemset(x)");
+        if ((e = hipMemsetAsync(cl->y, 0, sizeof(double) * m, c->stream)) != hipSuccess) return bail(e, "hipMemset(y)");
+        if ((e = hipMemsetAsync(cl->z, 0, sizeof(double) * m, c->stream)) != hipSuccess) return bail(e, "hipMemset(z)");
     }
     if (n) {
         std::vector<uint8_t> c8 = cats_to_u8(cat, n);
-        HIP_TRY(hipMemcpy(cl->cat, c8.data(), (size_t)n, hipMemcpyHostToDevice));
-        if (tag) HIP_TRY(hipMemcpy(cl->tag, tag, sizeof(int32_t) * n, hipMemcpyHostToDevice));
-        else HIP_TRY(hipMemset(cl->tag, 0, sizeof(int32_t) * n));
+        if ((e = hipMemcpy(cl->cat, c8.data(), (size_t)n, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(cat)");
+        if (tag) e = hipMemcpy(cl->tag, tag, sizeof(int32_t) * n, hipMemcpyHostToDevice);
+        else e = hipMemset(cl->tag, 0, sizeof(int32_t) * n);
+        if (e != hipSuccess) return bail(e, "tags");
     }
     *out = cl;
     return LCHD_OK;
@@ -431,9 +521,11 @@ extern "C" int lchd_cloud_create(lchd_ctx* c, const double* xyz, const int32_t* 
 
 extern "C" int lchd_cloud_create_batch(lchd_ctx* c, const double* xyz, const int32_t* cat, const int32_t* tag, const int32_t* sid,
                                        int64_t n, int32_t n_struct, lchd_cloud** out) {
+    if (!c || !out) return fail(LCHD_EVALUE, "null context");
     if (n_struct < 1 || !sid) return fail(LCHD_EVALUE, "a batch needs n_struct >= 1 and a structure id per atom");
     for (int64_t i = 0; i < n; ++i)
         if (sid[i] < 0 || sid[i] >= n_struct) return fail(LCHD_EVALUE, "structure id %d of atom %lld is outside [0, %d)", sid[i], (long long)i, n_struct);
+    CTX_GUARD(c);
     lchd_cloud* cl = nullptr;
     if (int rc = lchd_cloud_create(c, xyz, cat, tag, n, &cl)) return rc;
     cl->n_struct = n_struct;
@@ -454,11 +546,15 @@ extern "C" int lchd_cloud_create_batch(lchd_ctx* c, const double* xyz, const int
 
 extern "C" int lchd_cloud_set_coords(lchd_ctx* c, lchd_cloud* cl, const double* xyz) {
     if (!c || !cl || !xyz) return fail(LCHD_EVALUE, "null argument");
+    if (c->pend.active && (c->pend.a == cl || c->pend.b == cl))
+        return fail(LCHD_EVALUE, "this structure is in use by an unfinished asynchronous call");
+    CTX_GUARD(c);
     return upload_coords(c, cl, xyz);
 }
 
 extern "C" void lchd_cloud_destroy(lchd_ctx* c, lchd_cloud* cl) {
     if (!cl) return;
+    DeviceGuard device_guard_(c ? c->device : -1);
     if (c) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(cl->x);
     (void)hipFree(cl->y);
@@ -503,10 +599,41 @@ static int status_to_rc(uint32_t f, Driver drv) {
     return fail(LCHD_EDEVICE, "unexpected device status 0x%x", f);
 }
 
-static int read_status(lchd_ctx* c) {
-    HIP_TRY(hipMemcpyAsync(c->h_status, c->d_status, sizeof(DeviceStatus), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+// Status protocol of a pass.  begin_pass: the device status is clean unless a pass was abandoned half-way; the host-mapped
+// mirror's error words and sequence number are reset by the CPU (no pass is in flight).  After the stream has been waited
+// for, pass_flags() = what the kernels up to the record pass reported (snapshot by k_pair_meta) | what the sweeps reported.
+static int begin_pass(lchd_ctx* c) {
+    if (c->status_dirty) {
+        HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(DeviceStatus), c->stream));
+        c->status_dirty = false;
+    }
+    HostStatus* h = c->h_status;
+    for (uint32_t& w : h->sweep_flags) w = 0u;
+    h->flags = 0u;
+    h->max_env = 0u;
+    h->snapshot_seq = 0u;
+    c->seq = c->seq == 0xFFFFFFFFu ? 1u : c->seq + 1u;
     return LCHD_OK;
+}
+static int pass_flags(lchd_ctx* c, uint32_t* flags) {
+    const HostStatus* h = c->h_status;
+    if (h->snapshot_seq != c->seq) {  // the record pass never ran to its end
+        c->status_dirty = true;
+        return fail(LCHD_EDEVICE, "the device did not complete the pass (status snapshot %u, expected %u)", h->snapshot_seq, c->seq);
+    }
+    uint32_t f = h->flags;
+    for (int k = 0; k < 8; ++k)
+        if (h->sweep_flags[k]) f |= 1u << k;
+    *flags = f;
+    return LCHD_OK;
+}
+static int wait_pass(lchd_ctx* c, uint32_t* flags) {
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        c->status_dirty = true;
+        return fail(LCHD_EDEVICE, "HIP error %d (%s) while waiting for the pass", (int)e, hipGetErrorName(e));
+    }
+    return pass_flags(c, flags);
 }
 
 static void mark(lchd_ctx* c, int i) {
@@ -568,23 +695,46 @@ struct SideBufs {
     EnvStore env;
 };
 
-static void carve_side(Arena& a, int64_t n, int n_cells, int64_t max_envs, int cap, SideBufs& b) {
-    const size_t m = (size_t)std::max<int64_t>(n, 1);
-    b.cell_of = a.take<uint32_t>(m);
-    b.cell_count = a.take<uint32_t>((size_t)n_cells + 1);
-    b.cursor = a.take<uint32_t>((size_t)n_cells + 1);
-    b.cell_start = a.take<uint32_t>((size_t)n_cells + 1);
-    b.rec = a.take<CellRec>(m);
-    b.pos_of = a.take<uint32_t>(m);
-    b.slot = a.take<uint32_t>(m + 1);
-    b.uniq = a.take<AnchorRec>((size_t)std::max<int64_t>(max_envs, 1));
-    b.scan_tmp = a.take<uint32_t>(std::max<size_t>(m, (size_t)n_cells) / 4096 + 4);
-    const size_t ne = (size_t)std::max<int64_t>(max_envs, 1);
-    b.env.key = a.take<uint64_t>(ne * (size_t)cap);
-    b.env.cat = a.take<uint8_t>(ne * (size_t)cap);
-    b.env.len = a.take<int32_t>(ne);
-    b.env.stride = cap;
-    b.env.cdf_keys = 0;
+// Workspace layout of one pass.  Everything that must be zero when the prologue starts -- the generic cell list's counters
+// and the anchor flags of both sides -- is carved as ONE contiguous region (slot_a, slot_b last), so at most one memset
+// (or none: the fused / per-structure prologue launches zero what they need themselves) precedes the kernels.
+struct PassBufs {
+    SideBufs a, b;
+    int4* pair_meta;
+    char* zero_base;
+    size_t zero_bytes;
+};
+static void carve_pass(Arena& ar, int64_t n_a, int cells_a, int64_t envs_a, int64_t n_b, int cells_b, int64_t envs_b, int cap, int64_t n_pairs,
+                       PassBufs& pb) {
+    const size_t ma = (size_t)std::max<int64_t>(n_a, 1), mb = (size_t)std::max<int64_t>(n_b, 1);
+    ar.off = (ar.off + 255) & ~size_t(255);
+    const size_t z0 = ar.off;
+    pb.a.cell_count = ar.take<uint32_t>((size_t)cells_a + 1);
+    pb.a.cursor = ar.take<uint32_t>((size_t)cells_a + 1);
+    pb.b.cell_count = ar.take<uint32_t>((size_t)cells_b + 1);
+    pb.b.cursor = ar.take<uint32_t>((size_t)cells_b + 1);
+    pb.a.slot = ar.take<uint32_t>(ma + 1);
+    pb.b.slot = ar.take<uint32_t>(mb + 1);
+    pb.zero_base = ar.dry ? nullptr : ar.base + z0;
+    pb.zero_bytes = ar.off - z0;
+    for (int side = 0; side < 2; ++side) {
+        SideBufs& b = side ? pb.b : pb.a;
+        const size_t m = side ? mb : ma;
+        const int n_cells = side ? cells_b : cells_a;
+        const size_t ne = (size_t)std::max<int64_t>(side ? envs_b : envs_a, 1);
+        b.cell_of = ar.take<uint32_t>(m);
+        b.cell_start = ar.take<uint32_t>((size_t)n_cells + 1);
+        b.rec = ar.take<CellRec>(m);
+        b.pos_of = ar.take<uint32_t>(m);
+        b.uniq = ar.take<AnchorRec>(ne);
+        b.scan_tmp = ar.take<uint32_t>(std::max<size_t>(m, (size_t)n_cells) / 4096 + 4);
+        b.env.key = ar.take<uint64_t>(ne * (size_t)cap);
+        b.env.cat = ar.take<uint8_t>(ne * (size_t)cap);
+        b.env.len = ar.take<int32_t>(ne);
+        b.env.stride = cap;
+        b.env.cdf_keys = 0;
+    }
+    pb.pair_meta = ar.take<int4>((size_t)n_pairs);
 }
 
 static int next_pow2_host(int64_t n) {
@@ -606,7 +756,17 @@ static int resolve_bbox(lchd_ctx* c, lchd_cloud* cl) {
     return LCHD_OK;
 }
 
-// Everything of one from_primitives pass up to (and including) the asynchronous status read-back; no host sync.
+static void fill_sweep_args(lchd_ctx* c, SweepArgs& sw) {
+    sw.cfg = c->d_cfg;
+    sw.st = c->d_status;
+    sw.hst = c->h_status;
+    sw.seq = c->seq;
+    sw.sqrt_tab = c->d_tabs;
+    sw.rsqrt_tab = c->d_tabs + 65536;
+    sw.partials = c->d_partials;
+}
+
+// Everything of one from_primitives pass; no host synchronisation (the workspace only grows between passes).
 static int prims_enqueue(lchd_ctx* c) {
     auto& P = c->pend;
     lchd_cloud *a = P.a, *b = P.b;
@@ -615,19 +775,16 @@ static int prims_enqueue(lchd_ctx* c) {
     const int cap = P.cap;
     const GridPlan ga = plan_grid(a, thr), gb = plan_grid(b, thr);
     const int64_t max_env_a = std::min<int64_t>(a->n, n_pairs), max_env_b = std::min<int64_t>(b->n, n_pairs);
-    SideBufs sa{}, sb{};
+    PassBufs pb{};
     {
         Arena dry(nullptr, 0, true);
-        carve_side(dry, a->n, ga.n_cells, max_env_a, cap, sa);
-        carve_side(dry, b->n, gb.n_cells, max_env_b, cap, sb);
-        (void)dry.take<int4>((size_t)n_pairs);
+        carve_pass(dry, a->n, ga.n_cells, max_env_a, b->n, gb.n_cells, max_env_b, cap, n_pairs, pb);
         if (int rc = ensure_ws(c, dry.off + 4096)) return rc;
     }
     Arena ar(c->ws, c->ws_cap, false);
-    carve_side(ar, a->n, ga.n_cells, max_env_a, cap, sa);
-    carve_side(ar, b->n, gb.n_cells, max_env_b, cap, sb);
-    int4* pair_meta = ar.take<int4>((size_t)n_pairs);
-    sa.env.cdf_keys = sb.env.cdf_keys = (c->h_cfg.n_wf == 1 && !getenv("LCHD_NO_CDF_KEYS")) ? 1 : 0;
+    carve_pass(ar, a->n, ga.n_cells, max_env_a, b->n, gb.n_cells, max_env_b, cap, n_pairs, pb);
+    SideBufs &sa = pb.a, &sb = pb.b;
+    sa.env.cdf_keys = sb.env.cdf_keys = (c->h_cfg.n_wf == 1 && !c->tune.no_cdf_keys) ? 1 : 0;
 
     auto grid_view = [](const GridPlan& g, const SideBufs& s) {
         GridView v{};
@@ -644,23 +801,28 @@ static int prims_enqueue(lchd_ctx* c) {
     // frames buffers are filled on another stream: order this pass behind their upload
     if (a->ev_ready && a->cap_frames) HIP_TRY(hipStreamWaitEvent(s, a->ev_ready, 0));
     if (b->ev_ready && b->cap_frames) HIP_TRY(hipStreamWaitEvent(s, b->ev_ready, 0));
-    HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(DeviceStatus), s));
+    if (int rc = begin_pass(c)) return rc;
+    c->status_dirty = true;  // until the whole pass has been enqueued
     mark(c, 0);
-    launch_cell_build(s, cva, gva, sa.cell_of, sa.cell_count, sa.cursor, sa.rec, sa.pos_of, sa.cell_start, sa.scan_tmp);
-    launch_cell_build(s, cvb, gvb, sb.cell_of, sb.cell_count, sb.cursor, sb.rec, sb.pos_of, sb.cell_start, sb.scan_tmp);
+    auto prep_side = [](const CloudView& cv, const GridView& gv, const SideBufs& sbuf) {
+        PrepSide ps{};
+        ps.c = cv; ps.g = gv;
+        ps.cell_start = sbuf.cell_start; ps.rec = sbuf.rec; ps.pos_of = sbuf.pos_of;
+        ps.cell_of = sbuf.cell_of; ps.cell_count = sbuf.cell_count; ps.cursor = sbuf.cursor; ps.scan_tmp = sbuf.scan_tmp;
+        ps.slot = sbuf.slot; ps.uniq = sbuf.uniq;
+        return ps;
+    };
+    (void)launch_prologue(s, c->tune, P.anchors, n_pairs, prep_side(cva, gva, sa), prep_side(cvb, gvb, sb), pb.zero_base, pb.zero_bytes,
+                          c->d_status);
     mark(c, 1);
-    if (!launch_anchor_dedupe_small(s, P.anchors, n_pairs, cva, cvb, sa.pos_of, sb.pos_of, sa.slot, sb.slot, sa.uniq, sb.uniq, c->d_status)) {
-        launch_anchor_dedupe(s, P.anchors, n_pairs, 0, (int32_t)a->n, sa.slot, sa.uniq, cva, sa.pos_of, c->d_status, sa.scan_tmp);
-        launch_anchor_dedupe(s, P.anchors, n_pairs, 1, (int32_t)b->n, sb.slot, sb.uniq, cvb, sb.pos_of, c->d_status, sb.scan_tmp);
-    }
-    mark(c, 2);
+    mark(c, 2);  // (cell lists and anchor de-duplication are one phase now; "anchors" reads 0)
     const bool tag_list = c->h_cfg.tag_mode != 0;
     const EnvSide esa{cva, gva, sa.uniq, sa.env, max_env_a}, esb{cvb, gvb, sb.uniq, sb.env, max_env_b};
     if (!launch_env_cells(s, cap, c->d_cfg, tag_list, esa, esb, thr, c->d_status))
         return fail(LCHD_EUNSUPPORTED, "no environment kernel variant with capacity %d", cap);
     mark(c, 3);
     SweepArgs sw{};
-    sw.cfg = c->d_cfg;
+    fill_sweep_args(c, sw);
     sw.env_a = sa.env;
     sw.env_b = sb.env;
     sw.anchors = P.anchors;
@@ -671,17 +833,13 @@ static int prims_enqueue(lchd_ctx* c) {
     sw.wf_index = P.wf;
     sw.n_pairs = n_pairs;
     sw.out = P.out;
-    sw.st = c->d_status;
-    sw.sqrt_tab = c->d_tabs;
-    sw.rsqrt_tab = c->d_tabs + 65536;
-    sw.meta = pair_meta;
-    sw.partials = c->d_partials;
-    launch_sweep(s, c->h_cfg.n_categories, c->hellinger2, c->unit_weights, c->wf_pow, sw);
+    sw.meta = pb.pair_meta;
+    launch_sweep(s, c->tune, c->h_cfg.n_categories, c->hellinger2, c->unit_weights, c->wf_pow, c->sweep_hint, sw);
     mark(c, 4);
     if (a->ev_used) { HIP_TRY(hipEventRecord(a->ev_used, s)); a->used_valid = true; }
     if (b->ev_used) { HIP_TRY(hipEventRecord(b->ev_used, s)); b->used_valid = true; }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(c->h_status, c->d_status, sizeof(DeviceStatus), hipMemcpyDeviceToHost, s));
+    c->status_dirty = false;  // the record pass of this sequence leaves the device status clean
     P.sw = sw;
     return LCHD_OK;
 }
@@ -693,16 +851,17 @@ extern "C" int lchd_from_primitives_dev_async(lchd_ctx* c, lchd_cloud* a, lchd_c
     if (c->pend.active) return fail(LCHD_EVALUE, "a previous asynchronous call has not been finished (lchd_ctx_finish)");
     c->last_valid = false;
     if (n_pairs <= 0) return LCHD_OK;
+    if (!d_anchors || !d_out) return fail(LCHD_EVALUE, "null anchor / score pointer");
     if (!(thr > 0.0))  // within_radius returns nothing => dists[0] panics (src/locohd.rs:74)
         return fail(LCHD_EPANIC, "index out of bounds: threshold_distance = %g leaves every environment empty", thr);
     if (a->n == 0 || b->n == 0) return fail(LCHD_EPANIC, "index out of bounds: anchor pairs given for an empty structure");
     if (!std::isfinite(thr)) thr = 1.7e308;
+    CTX_GUARD(c);
     if (int rc = resolve_bbox(c, a)) return rc;
     if (int rc = resolve_bbox(c, b)) return rc;
     auto& P = c->pend;
     P.a = a; P.b = b; P.anchors = d_anchors; P.wf = d_wf_index; P.n_pairs = n_pairs; P.thr = thr; P.out = d_out;
     P.cap = c->cap_hint;
-    if (const char* e_ = getenv("LCHD_CAP_HINT")) { if (!c->cap_env_done) { c->cap_env_done = true; P.cap = c->cap_hint = atoi(e_); } }
     if (int rc = prims_enqueue(c)) return rc;
     P.active = true;
     return LCHD_OK;
@@ -713,21 +872,32 @@ extern "C" int lchd_ctx_finish(lchd_ctx* c) {
     auto& P = c->pend;
     if (!P.active) return LCHD_OK;
     P.active = false;
+    CTX_GUARD(c);
     for (int attempt = 0; attempt < 6; ++attempt) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        uint32_t f = 0;
+        if (int rc = wait_pass(c, &f)) return rc;
         collect_times(c, 0, 4);
-        const uint32_t f = c->h_status->flags;
         if (f & ST_BAD_ANCHOR) return status_to_rc(f, DRV_PRIMS);
+        const int64_t biggest = c->h_status->max_env;  // largest environment of the pass (k_pair_meta), or what overflowed
         if (f & ST_ENV_OVERFLOW) {  // an environment did not fit the kernel variant's LDS capacity: run the pass again, larger
-            const int64_t need = c->h_status->max_env;
-            if (need > 16384)
+            if (biggest > 16384)
                 return fail(LCHD_EUNSUPPORTED, "an environment holds %lld points; this build sorts at most 16384 per environment",
-                            (long long)need);
-            P.cap = next_pow2_host(need);
+                            (long long)biggest);
+            P.cap = next_pow2_host(biggest);
             c->cap_hint = P.cap;
+            c->shrink_votes = 0;
             if (int rc = prims_enqueue(c)) return rc;
             continue;
         }
+        // The capacity hint decays: a single dense environment should not make every later call of this context pay for
+        // its slot size (slots are fixed-stride).  Eight passes in a row that would have fitted half the capacity halve it.
+        if (c->cap_hint > 512 && !c->tune.cap_hint && biggest > 0 && 2 * next_pow2_host(biggest) <= c->cap_hint) {
+            if (++c->shrink_votes >= 8) { c->cap_hint = std::max(512, c->cap_hint / 2); c->shrink_votes = 0; }
+        } else {
+            c->shrink_votes = 0;
+        }
+        if (c->h_cfg.n_categories <= 16)  // who swept the pairs this time is the hint for the next pass of this configuration
+            c->sweep_hint = (2 * c->h_status->n_small >= (unsigned long long)P.n_pairs) ? 1 : 2;
         c->last = P.sw;
         c->last_valid = true;
         return status_to_rc(f, DRV_PRIMS);
@@ -745,7 +915,8 @@ extern "C" int lchd_from_primitives_dev(lchd_ctx* c, lchd_cloud* a, lchd_cloud* 
 // trajectory frames: a batch cloud whose structures are frames of one template structure
 // ------------------------------------------------------------------------------------------------
 extern "C" int lchd_frames_create(lchd_ctx* c, const lchd_cloud* tmpl, int32_t capacity_frames, lchd_cloud** out) {
-    if (!c || !tmpl || capacity_frames < 1) return fail(LCHD_EVALUE, "bad argument");
+    if (!c || !tmpl || !out || capacity_frames < 1) return fail(LCHD_EVALUE, "bad argument");
+    CTX_GUARD(c);
     if (tmpl->sid) return fail(LCHD_EVALUE, "the template of a frames buffer must be a single structure");
     const int64_t nt = tmpl->n, total = nt * capacity_frames;
     if (nt < 1 || total > ((int64_t)1 << 30)) return fail(LCHD_EUNSUPPORTED, "frames buffer of %lld atoms is out of range", (long long)total);
@@ -782,6 +953,7 @@ extern "C" int lchd_frames_load(lchd_ctx* c, lchd_cloud* fr, const double* xyz, 
     if (n_frames < 1 || n_frames > fr->cap_frames) return fail(LCHD_EVALUE, "%d frames do not fit a buffer of %d", n_frames, fr->cap_frames);
     if (c->pend.active && (c->pend.a == fr || c->pend.b == fr))
         return fail(LCHD_EVALUE, "this frames buffer is in use by an unfinished asynchronous call");
+    CTX_GUARD(c);
     hipStream_t s = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->stream;
     const int64_t total = fr->n_tmpl * n_frames;
     // the pinned staging block is free again once the previous upload from it has completed
@@ -803,6 +975,7 @@ extern "C" int lchd_frames_set_sources(lchd_ctx* c, lchd_cloud* fr, const int32_
     if (!c || !fr || !fr->cap_frames || !src_start || !src_idx) return fail(LCHD_EVALUE, "not a frames buffer / null map");
     if (c->pend.active && (c->pend.a == fr || c->pend.b == fr))
         return fail(LCHD_EVALUE, "this frames buffer is in use by an unfinished asynchronous call");
+    CTX_GUARD(c);
     const int64_t np = fr->n_tmpl;
     if (n_src_atoms < 1 || n_src_atoms * (int64_t)fr->cap_frames > ((int64_t)1 << 31))
         return fail(LCHD_EUNSUPPORTED, "%lld source atoms x %d frames is out of range", (long long)n_src_atoms, fr->cap_frames);
@@ -851,15 +1024,25 @@ extern "C" int lchd_frames_set_sources(lchd_ctx* c, lchd_cloud* fr, const int32_
     if (fr->h_pinned32) { (void)hipHostFree(fr->h_pinned32); fr->h_pinned32 = nullptr; }
     fr->n_src = 0;
     const size_t raw_elems = (size_t)3 * (size_t)n_src_atoms * (size_t)fr->cap_frames;
-    HIP_TRY(hipMalloc(&fr->d_src_start, sizeof(int32_t) * (size_t)(np + 1)));
-    HIP_TRY(hipMalloc(&fr->d_src_idx, sizeof(int32_t) * (size_t)nnz));
-    HIP_TRY(hipMalloc(&fr->d_raw32, sizeof(float) * raw_elems));
-    HIP_TRY(hipHostMalloc(&fr->h_pinned32, sizeof(float) * raw_elems));
-    HIP_TRY(hipMemcpy(fr->d_src_start, src_start, sizeof(int32_t) * (size_t)(np + 1), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(fr->d_src_idx, src_idx, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
-    if (!fr->d_bbox_part) HIP_TRY(hipMalloc(&fr->d_bbox_part, sizeof(unsigned long long) * 7 * (size_t)bbox_parts_capacity()));
-    HIP_TRY(hipMalloc(&fr->d_tiles, sizeof(int32_t) * tiles.size()));
-    HIP_TRY(hipMemcpy(fr->d_tiles, tiles.data(), sizeof(int32_t) * tiles.size(), hipMemcpyHostToDevice));
+    {   // all or nothing: a failure leaves the buffer without sources (n_src == 0) and without half-made allocations
+        hipError_t e = hipMalloc(&fr->d_src_start, sizeof(int32_t) * (size_t)(np + 1));
+        if (e == hipSuccess) e = hipMalloc(&fr->d_src_idx, sizeof(int32_t) * (size_t)nnz);
+        if (e == hipSuccess) e = hipMalloc(&fr->d_raw32, sizeof(float) * raw_elems);
+        if (e == hipSuccess) e = hipHostMalloc(&fr->h_pinned32, sizeof(float) * raw_elems);
+        if (e == hipSuccess) e = hipMemcpy(fr->d_src_start, src_start, sizeof(int32_t) * (size_t)(np + 1), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(fr->d_src_idx, src_idx, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice);
+        if (e == hipSuccess && !fr->d_bbox_part) e = hipMalloc(&fr->d_bbox_part, sizeof(unsigned long long) * 7 * (size_t)bbox_parts_capacity());
+        if (e == hipSuccess) e = hipMalloc(&fr->d_tiles, sizeof(int32_t) * tiles.size());
+        if (e == hipSuccess) e = hipMemcpy(fr->d_tiles, tiles.data(), sizeof(int32_t) * tiles.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(fr->d_src_start); fr->d_src_start = nullptr;
+            (void)hipFree(fr->d_src_idx); fr->d_src_idx = nullptr;
+            (void)hipFree(fr->d_tiles); fr->d_tiles = nullptr;
+            (void)hipFree(fr->d_raw32); fr->d_raw32 = nullptr;
+            if (fr->h_pinned32) { (void)hipHostFree(fr->h_pinned32); fr->h_pinned32 = nullptr; }
+            return fail(LCHD_EDEVICE, "HIP error %d (%s) in lchd_frames_set_sources", (int)e, hipGetErrorName(e));
+        }
+    }
     fr->n_tiles = (int32_t)(tiles.size() / 4);
     fr->n_src = n_src_atoms;
     return LCHD_OK;
@@ -872,6 +1055,7 @@ static int frames_load_atoms(lchd_ctx* c, lchd_cloud* fr, const float* atom_xyz,
     if (n_frames < 1 || n_frames > fr->cap_frames) return fail(LCHD_EVALUE, "%d frames do not fit a buffer of %d", n_frames, fr->cap_frames);
     if (c->pend.active && (c->pend.a == fr || c->pend.b == fr))
         return fail(LCHD_EVALUE, "this frames buffer is in use by an unfinished asynchronous call");
+    CTX_GUARD(c);
     hipStream_t s = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->stream;
     const size_t elems = (size_t)3 * (size_t)fr->n_src * (size_t)n_frames;
     const float* d_src = atom_xyz;
@@ -908,6 +1092,7 @@ extern "C" int lchd_frames_load_atoms_dev(lchd_ctx* c, lchd_cloud* fr, const flo
 }
 extern "C" double lchd_frames_last_convert_ms(lchd_ctx* c, lchd_cloud* fr) {
     if (!c || !fr || !fr->t_valid) return -1.0;
+    CTX_GUARD(c);
     float t = -1.f;
     if (hipEventSynchronize(fr->ev_t1) != hipSuccess || hipEventElapsedTime(&t, fr->ev_t0, fr->ev_t1) != hipSuccess) return -1.0;
     return t;
@@ -918,6 +1103,7 @@ extern "C" double lchd_frames_last_convert_ms(lchd_ctx* c, lchd_cloud* fr) {
 extern "C" int lchd_cloud_get_coords(lchd_ctx* c, lchd_cloud* cl, double* xyz_out, int64_t n) {
     if (!c || !cl || !xyz_out) return fail(LCHD_EVALUE, "null argument");
     if (n != cl->n) return fail(LCHD_EVALUE, "the cloud holds %lld atoms, not %lld", (long long)cl->n, (long long)n);
+    CTX_GUARD(c);
     if (cl->ev_ready && cl->bbox_pending) HIP_TRY(hipEventSynchronize(cl->ev_ready));
     HIP_TRY(hipStreamSynchronize(c->stream));
     std::vector<double> soa((size_t)3 * (size_t)n);
@@ -972,18 +1158,41 @@ static int stage_cloud(const double* xyz, const int32_t* cat, const int32_t* tag
     return LCHD_OK;
 }
 
+// Scores of a host-pointer call with at most this many pairs are stored by the sweep kernels straight into the pinned,
+// device-visible staging block (8 bytes per pair over the host link): no device-to-host copy operation behind the pass.
+constexpr int64_t kDirectOutPairs = 1 << 16;
+
+static int grow_io(lchd_ctx* c, size_t total) {
+    if (total <= c->io_cap) return LCHD_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->d_io); c->d_io = nullptr;
+    if (c->h_io) { (void)hipHostFree(c->h_io); c->h_io = nullptr; }
+    c->io_cap = 0;
+    const size_t want = total + total / 4 + (1 << 16);
+    HIP_TRY(hipMalloc(&c->d_io, want));
+    hipError_t e = hipHostMalloc(&c->h_io, want);
+    if (e != hipSuccess) {
+        (void)hipFree(c->d_io); c->d_io = nullptr; c->h_io = nullptr;
+        return fail(LCHD_EDEVICE, "HIP error %d (%s) in hipHostMalloc of the staging block", (int)e, hipGetErrorName(e));
+    }
+    c->io_cap = want;
+    return LCHD_OK;
+}
+
 extern "C" int lchd_from_primitives(lchd_ctx* c, const lchd_config* cfg, const double* xyz_a, const int32_t* cat_a,
                                     const int32_t* tag_a, int64_t n_a, const double* xyz_b, const int32_t* cat_b,
                                     const int32_t* tag_b, int64_t n_b, const int64_t* anchors, const int32_t* wf_index,
                                     int64_t n_pairs, double thr, double* out) {
     if (!c) return fail(LCHD_EVALUE, "null context");
+    if (c->pend.active) return fail(LCHD_EVALUE, "an asynchronous call has not been finished (lchd_ctx_finish)");
+    CTX_GUARD(c);
     if (int rc = lchd_ctx_set_config(c, cfg)) return rc;
     if (int rc = check_wf_index(cfg, wf_index, n_pairs)) return rc;
     if (n_pairs == 0) return LCHD_OK;
     if (n_a < 0 || n_b < 0 || n_a > ((int64_t)1 << 30) || n_b > ((int64_t)1 << 30)) return fail(LCHD_EUNSUPPORTED, "structure size out of range");
-    // Everything a call sends to the device travels as ONE block through pinned staging and ONE asynchronous copy, the scores
-    // come back with one copy; the block and its staging twin belong to the context and only ever grow (the reference clones
-    // its arguments per call as well, primitive_atom.rs:5, but a device allocation costs far more than a Vec).
+    // Everything a call sends to the device travels as ONE block through pinned staging and ONE asynchronous copy; the block
+    // and its staging twin belong to the context and only ever grow (the reference clones its arguments per call as well,
+    // primitive_atom.rs:5, but a device allocation costs far more than a Vec).
     lchd_cloud a, b;
     size_t o_anchors = 0, o_wf = 0, o_out = 0, in_bytes = 0, total = 0;
     for (int pass = 0; pass < 2; ++pass) {
@@ -997,30 +1206,23 @@ extern "C" int lchd_from_primitives(lchd_ctx* c, const lchd_config* cfg, const d
         in_bytes = off;
         o_out = take(sizeof(double) * (size_t)n_pairs);
         total = off;
-        if (pass == 0 && total > c->io_cap) {
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            (void)hipFree(c->d_io); c->d_io = nullptr;
-            if (c->h_io) { (void)hipHostFree(c->h_io); c->h_io = nullptr; }
-            c->io_cap = 0;
-            const size_t want = total + total / 4 + (1 << 16);
-            HIP_TRY(hipMalloc(&c->d_io, want));
-            HIP_TRY(hipHostMalloc(&c->h_io, want));
-            c->io_cap = want;
-        }
+        if (pass == 0)
+            if (int rc = grow_io(c, total)) return rc;
     }
     memcpy(c->h_io + o_anchors, anchors, sizeof(int64_t) * 2 * (size_t)n_pairs);
     if (wf_index) memcpy(c->h_io + o_wf, wf_index, sizeof(int32_t) * (size_t)n_pairs);
     HIP_TRY(hipMemcpyAsync(c->d_io, c->h_io, in_bytes, hipMemcpyHostToDevice, c->stream));
     const int64_t* d_anchors = reinterpret_cast<const int64_t*>(c->d_io + o_anchors);
     const int32_t* d_wf = wf_index ? reinterpret_cast<const int32_t*>(c->d_io + o_wf) : nullptr;
-    double* d_out = reinterpret_cast<double*>(c->d_io + o_out);
+    const bool direct = n_pairs <= kDirectOutPairs;
+    double* d_out = reinterpret_cast<double*>((direct ? c->h_io : c->d_io) + o_out);
     int rc = lchd_from_primitives_dev(c, &a, &b, d_anchors, d_wf, n_pairs, thr, d_out);
-    if (!rc) {
+    if (!rc && !direct) {
         hipError_t e = hipMemcpyAsync(c->h_io + o_out, d_out, sizeof(double) * (size_t)n_pairs, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) rc = fail(LCHD_EDEVICE, "HIP error %d in D2H scores", (int)e);
-        else memcpy(out, c->h_io + o_out, sizeof(double) * (size_t)n_pairs);
     }
+    if (!rc) memcpy(out, c->h_io + o_out, sizeof(double) * (size_t)n_pairs);
     c->last_valid = false;  // the anchors of this call live in the I/O block, which the next call overwrites
     c->pend.a = c->pend.b = nullptr;  // the stack clouds are gone
     return rc;
@@ -1031,28 +1233,28 @@ extern "C" int lchd_from_primitives(lchd_ctx* c, const lchd_config* cfg, const d
 static int sweep_rows(lchd_ctx* c, const EnvStore& ea, const EnvStore& eb, const int32_t* d_wf, int64_t rows, double* d_out,
                       int4* d_meta, Driver drv) {
     SweepArgs sw{};
-    sw.cfg = c->d_cfg;
+    fill_sweep_args(c, sw);
     sw.env_a = ea;
     sw.env_b = eb;
     sw.wf_index = d_wf;
     sw.n_pairs = rows;
     sw.out = d_out;
-    sw.st = c->d_status;
-    sw.sqrt_tab = c->d_tabs;
-    sw.rsqrt_tab = c->d_tabs + 65536;
     sw.meta = d_meta;
-    sw.partials = c->d_partials;
-    launch_sweep(c->stream, c->h_cfg.n_categories, c->hellinger2, c->unit_weights, c->wf_pow, sw);
+    launch_sweep(c->stream, c->tune, c->h_cfg.n_categories, c->hellinger2, c->unit_weights, c->wf_pow, 0, sw);
     mark(c, 4);
     HIP_TRY(hipGetLastError());
-    if (int rc = read_status(c)) return rc;
+    c->status_dirty = false;  // the record pass of this sequence resets the device status
+    uint32_t f = 0;
+    if (int rc = wait_pass(c, &f)) return rc;
     collect_times(c, 2, 4);
-    return status_to_rc(c->h_status->flags, drv);
+    return status_to_rc(f, drv);
 }
 
 static int dense_driver(lchd_ctx* c, const lchd_config* cfg, const int32_t* seq_a, int64_t len_seq_a, const int32_t* seq_b,
                         int64_t len_seq_b, const double* xyz_a, const double* xyz_b, const double* dmx_a, const double* dmx_b,
                         int64_t rows, int64_t cols_a, int64_t cols_b, const int32_t* wf_index, double* out) {
+    if (c->pend.active) return fail(LCHD_EVALUE, "an asynchronous call has not been finished (lchd_ctx_finish)");
+    CTX_GUARD(c);
     if (int rc = lchd_ctx_set_config(c, cfg)) return rc;
     if (int rc = check_wf_index(cfg, wf_index, rows)) return rc;
     c->last_valid = false;
@@ -1083,7 +1285,7 @@ static int dense_driver(lchd_ctx* c, const lchd_config* cfg, const int32_t* seq_
             eb.cat = ar.take<uint8_t>((size_t)rows * cap_b);
             eb.len = ar.take<int32_t>((size_t)rows);
             eb.stride = cap_b;
-            ea.cdf_keys = eb.cdf_keys = (c->h_cfg.n_wf == 1 && !getenv("LCHD_NO_CDF_KEYS")) ? 1 : 0;
+            ea.cdf_keys = eb.cdf_keys = (c->h_cfg.n_wf == 1 && !c->tune.no_cdf_keys) ? 1 : 0;
             d_out = ar.take<double>((size_t)rows);
             d_wf = ar.take<int32_t>((size_t)rows);
             d_meta = ar.take<int4>((size_t)rows);
@@ -1094,7 +1296,8 @@ static int dense_driver(lchd_ctx* c, const lchd_config* cfg, const int32_t* seq_
             if (dry) if (int rc2 = ensure_ws(c, ar.off + 4096)) return rc2;
         }
         hipStream_t s = c->stream;
-        HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(DeviceStatus), s));
+        if (int rc2 = begin_pass(c)) return rc2;
+        c->status_dirty = true;  // until the record pass has been enqueued (sweep_rows)
         if (dmx_a) {
             HIP_TRY(hipMemcpyAsync(d_ma, dmx_a, sizeof(double) * rows * cols_a, hipMemcpyHostToDevice, s));
             HIP_TRY(hipMemcpyAsync(d_mb, dmx_b, sizeof(double) * rows * cols_b, hipMemcpyHostToDevice, s));
@@ -1142,6 +1345,8 @@ extern "C" int lchd_from_anchors(lchd_ctx* c, const lchd_config* cfg, const int3
                                  int64_t len_dists_a, const int32_t* seq_b, int64_t len_seq_b, const double* dists_b,
                                  int64_t len_dists_b, int32_t wf_index, double* out) {
     if (!c) return fail(LCHD_EVALUE, "null context");
+    if (c->pend.active) return fail(LCHD_EVALUE, "an asynchronous call has not been finished (lchd_ctx_finish)");
+    CTX_GUARD(c);
     if (int rc = lchd_ctx_set_config(c, cfg)) return rc;
     if (wf_index < 0 || wf_index >= cfg->n_weight_functions) return fail(LCHD_EVALUE, "weight-function index out of range");
     c->last_valid = false;
@@ -1169,51 +1374,45 @@ extern "C" int lchd_from_anchors(lchd_ctx* c, const lchd_config* cfg, const int3
         for (int64_t i = 0; i < n; ++i)
             if (q[i] < 0 || q[i] >= cfg->n_categories) return fail(LCHD_EVALUE, "Category not found!");
     }
-    EnvStore ea{}, eb{};
-    double* d_out = nullptr;
-    int4* d_meta = nullptr;
-    for (int dry = 1; dry >= 0; --dry) {
-        Arena ar(dry ? nullptr : c->ws, dry ? 0 : c->ws_cap, dry != 0);
-        ea.key = ar.take<uint64_t>((size_t)len_seq_a);
-        ea.cat = ar.take<uint8_t>((size_t)len_seq_a);
-        ea.len = ar.take<int32_t>(1);
-        ea.stride = len_seq_a;
-        eb.key = ar.take<uint64_t>((size_t)len_seq_b);
-        eb.cat = ar.take<uint8_t>((size_t)len_seq_b);
-        eb.len = ar.take<int32_t>(1);
-        eb.stride = len_seq_b;
-        d_out = ar.take<double>(1);
-        d_meta = ar.take<int4>(1);
-        if (dry) if (int rc = ensure_ws(c, ar.off + 4096)) return rc;
-    }
-    hipStream_t s = c->stream;
-    HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(DeviceStatus), s));
-    auto upload = [&](const EnvStore& e, const int32_t* seq, const double* d, int64_t n) -> int {
-        std::vector<uint64_t> k((size_t)n);
-        for (int64_t i = 0; i < n; ++i) { const double v = d[i] + 0.0; memcpy(&k[(size_t)i], &v, 8); }
-        std::vector<uint8_t> c8 = cats_to_u8(seq, n);
+    // The two lists, the weight-function index and the score travel through the context's pinned staging block: ONE
+    // asynchronous copy on the context's stream in (ordered with everything else on that stream), the score is stored by the
+    // sweep kernel straight into the pinned block.
+    const size_t na = (size_t)len_seq_a, nb = (size_t)len_seq_b;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { off = (off + 255) & ~size_t(255); const size_t o = off; off += bytes; return o; };
+    const size_t o_ka = take(8 * na), o_kb = take(8 * nb), o_ca = take(na), o_cb = take(nb), o_la = take(4), o_lb = take(4), o_wf = take(4);
+    const size_t in_bytes = off;
+    const size_t o_meta = take(sizeof(int4)), o_out = take(sizeof(double));
+    if (int rc = grow_io(c, off)) return rc;
+    auto stage = [&](size_t o_k, size_t o_c, size_t o_l, const int32_t* seq, const double* d, size_t n) {
+        uint64_t* k = reinterpret_cast<uint64_t*>(c->h_io + o_k);
+        uint8_t* c8 = reinterpret_cast<uint8_t*>(c->h_io + o_c);
+        for (size_t i = 0; i < n; ++i) {
+            const double v = d[i] + 0.0;  // -0.0 -> +0.0
+            memcpy(&k[i], &v, 8);
+            c8[i] = (uint8_t)seq[i];      // inside [0, n_categories): checked above
+        }
         const int32_t len = (int32_t)n;
-        HIP_TRY(hipMemcpy(e.key, k.data(), sizeof(uint64_t) * n, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(e.cat, c8.data(), (size_t)n, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(e.len, &len, sizeof len, hipMemcpyHostToDevice));
-        return LCHD_OK;
+        memcpy(c->h_io + o_l, &len, 4);
     };
-    if (int rc = upload(ea, seq_a, dists_a, len_seq_a)) return rc;
-    if (int rc = upload(eb, seq_b, dists_b, len_seq_b)) return rc;
-    int32_t* d_wf = nullptr;
-    // a single pair: its weight function index travels as a 1-element device array only when it is not 0
-    std::vector<int32_t> wfv(1, wf_index);
-    if (wf_index != 0) {
-        HIP_TRY(hipMalloc(&d_wf, sizeof(int32_t)));
-        HIP_TRY(hipMemcpy(d_wf, wfv.data(), sizeof(int32_t), hipMemcpyHostToDevice));
-    }
+    stage(o_ka, o_ca, o_la, seq_a, dists_a, na);
+    stage(o_kb, o_cb, o_lb, seq_b, dists_b, nb);
+    memcpy(c->h_io + o_wf, &wf_index, 4);
+    EnvStore ea{}, eb{};
+    ea.key = reinterpret_cast<uint64_t*>(c->d_io + o_ka); ea.cat = reinterpret_cast<uint8_t*>(c->d_io + o_ca);
+    ea.len = reinterpret_cast<int32_t*>(c->d_io + o_la); ea.stride = len_seq_a;
+    eb.key = reinterpret_cast<uint64_t*>(c->d_io + o_kb); eb.cat = reinterpret_cast<uint8_t*>(c->d_io + o_cb);
+    eb.len = reinterpret_cast<int32_t*>(c->d_io + o_lb); eb.stride = len_seq_b;
+    hipStream_t s = c->stream;
+    if (int rc = begin_pass(c)) return rc;
+    c->status_dirty = true;
+    HIP_TRY(hipMemcpyAsync(c->d_io, c->h_io, in_bytes, hipMemcpyHostToDevice, s));
     mark(c, 2);
     mark(c, 3);
-    int rc = sweep_rows(c, ea, eb, d_wf, 1, d_out, d_meta, DRV_ANCHORS);
-    if (!rc) {
-        hipError_t e = hipMemcpy(out, d_out, sizeof(double), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = fail(LCHD_EDEVICE, "HIP error %d in D2H score", (int)e);
-    }
-    (void)hipFree(d_wf);
+    double* h_out = reinterpret_cast<double*>(c->h_io + o_out);
+    // a single pair: its weight-function index travels as a 1-element device array only when it is not 0
+    int rc = sweep_rows(c, ea, eb, wf_index != 0 ? reinterpret_cast<const int32_t*>(c->d_io + o_wf) : nullptr, 1, h_out,
+                        reinterpret_cast<int4*>(c->d_io + o_meta), DRV_ANCHORS);
+    if (!rc) *out = *h_out;
     return rc;
 }

@@ -23,12 +23,44 @@ enum : uint32_t {
     ST_BAD_DISTANCE = 1u << 6,    // negative / NaN distance in a matrix row    (reference: ValueError / panic)
     ST_BAD_WF = 1u << 7,          // weight-function index outside the table
 };
+// Device-resident status of a pass.  Invariant between passes: flags == max_env == meta_done == 0 -- the last workgroup of
+// k_pair_meta copies the words the host needs into the host-mapped HostStatus and resets them, so a pass needs neither a
+// memset in front of it nor a device-to-host copy behind it.  n_unique / n_small are plain-stored by every pass.
 struct DeviceStatus {
     uint32_t flags;
     uint32_t max_env;        // largest environment seen (for the overflow retry)
     uint32_t n_unique[2];    // unique anchors per side
-    unsigned long long env_points;  // sum over pairs of n_A + n_B
+    uint32_t meta_done;      // workgroups of k_pair_meta that have finished (the last one folds the partial counts)
+    uint32_t pad;
     unsigned long long n_small;     // pairs with at most kDuoTile merged events (k_pair_meta): who sweeps them is decided on the device
+};
+// Host-mapped (pinned, device-visible) mirror: written with plain stores only -- the snapshot by one thread of k_pair_meta,
+// the error words by whichever sweep wavefront meets the (rare) condition; every writer of a word stores the same value.
+struct HostStatus {
+    uint32_t flags;          // DeviceStatus::flags at the end of the record pass (everything the kernels before the sweep reported)
+    uint32_t max_env;
+    uint32_t n_unique[2];
+    unsigned long long n_small;
+    uint32_t sweep_flags[8]; // word k != 0 <=> a sweep kernel reported status bit k (ST_* below)
+    uint32_t snapshot_seq;   // pass counter written with the snapshot (the host checks that the pass it waited for got this far)
+    uint32_t pad;
+};
+
+// Test / tuning hooks.  Read from the environment ONCE, when a context is created (lchd_ctx_create), and handed to the
+// launchers by value: nothing in the launch path calls getenv().
+struct Tuning {
+    bool no_struct_cells = false;   // LCHD_NO_STRUCT_CELLS: always the generic (multi-pass, global atomics) cell list
+    bool no_small_dedupe = false;   // LCHD_NO_SMALL_DEDUPE: never the fused one-workgroup-per-side prologue
+    bool no_cdf_keys = false;       // LCHD_NO_CDF_KEYS: environments keep distance keys even with a single weight function
+    bool no_duo = false;            // LCHD_NO_DUO: never two pairs per wavefront
+    bool force_wide = false;        // LCHD_FORCE_WIDE: k_sweep_wide for any category count
+    bool force_generic = false;     // LCHD_FORCE_GENERIC: MODE_GEN even for Hellinger-2
+    bool force_bigenv = false;      // LCHD_FORCE_BIGENV: the !LDSTAB sweep instantiations
+    bool no_sweep_hint = false;     // LCHD_NO_SWEEP_HINT: always launch all three sweep kernels and let the device decide
+    bool no_count8 = false;         // LCHD_NO_COUNT8: never the 8-bit-count sweep
+    bool no_tables = false;         // LCHD_NO_SD_TABLES: generic distances without the per-launch power / log tables
+    int force_cmax = 0;             // LCHD_FORCE_CMAX: at least this many category slots
+    int cap_hint = 0;               // LCHD_CAP_HINT: first environment capacity to try
 };
 
 struct WfEntry {
@@ -100,18 +132,26 @@ struct EnvStore {
     int32_t cdf_keys;  // 1: key = bits of F(distance) for the configuration's single weight function (sweep needs no CDF evaluation)
 };
 
-// `scan_tmp` holds (n / 4096 + 2) u32 of scratch for the multi-block scan
-void launch_cell_build(hipStream_t s, const CloudView& c, GridView g, uint32_t* cell_of, uint32_t* cell_count,
-                       uint32_t* cell_cursor, CellRec* rec, uint32_t* pos_of, uint32_t* cell_start, uint32_t* scan_tmp);
-
-void launch_anchor_dedupe(hipStream_t s, const int64_t* anchors, int64_t n_pairs, int side, int32_t n_points,
-                          uint32_t* flag_then_slot, AnchorRec* uniq, const CloudView& c, const uint32_t* pos_of, DeviceStatus* st,
-                          uint32_t* scan_tmp);
-
-// both sides in one launch when the inputs are small; returns false (nothing launched) otherwise
-bool launch_anchor_dedupe_small(hipStream_t s, const int64_t* anchors, int64_t n_pairs, const CloudView& ca, const CloudView& cb,
-                                const uint32_t* pos_a, const uint32_t* pos_b, uint32_t* slot_a, uint32_t* slot_b, AnchorRec* uniq_a,
-                                AnchorRec* uniq_b, DeviceStatus* st);
+// One structure (or batch of structures) of a from_primitives pass as the prologue sees it: the inputs, and the arrays the
+// prologue fills (cell list, anchor slots, anchor records).
+struct PrepSide {
+    CloudView c;
+    GridView g;              // geometry; g.cell_start / g.rec / g.pos_of alias the three output arrays below
+    uint32_t* cell_start;    // [n_cells + 1]
+    CellRec* rec;            // [n] atoms permuted into cell order
+    uint32_t* pos_of;        // [n] atom -> position in cell order
+    uint32_t *cell_of, *cell_count, *cursor;  // scratch of the generic cell-list build (cell_count, cursor inside the zero region)
+    uint32_t* scan_tmp;      // (n / 4096 + 4) u32 of scratch for the multi-block scan
+    uint32_t* slot;          // [n + 1] anchor flags (inside the zero region), then environment slots
+    AnchorRec* uniq;         // [max_envs]
+};
+// Cell lists of both sides + anchor de-duplication (see lchd_kernels.hip).  [zero_base, zero_base + zero_bytes) is the
+// contiguous region holding cell_count / cursor of both sides followed by slot_a, slot_b (in this order, slot_b last): the
+// prologue zeroes what its launch tier needs with at most one operation.  Returns the number of stream operations enqueued.
+int launch_prologue(hipStream_t s, const Tuning& t, const int64_t* anchors, int64_t n_pairs, const PrepSide& a, const PrepSide& b,
+                    void* zero_base, size_t zero_bytes, DeviceStatus* st);
+// Per-device function attributes (dynamic LDS above 64 KB): called by lchd_ctx_create with the context's device current.
+void init_device_kernels();
 
 // returns false if `cap` is not an available variant
 // one side of an environment-build launch (both structures are built by ONE launch: workgroups [0, a.max_envs) side A, the rest B)
@@ -148,9 +188,16 @@ struct SweepArgs {
     const double* rsqrt_tab;  // [65536] 1/sqrt(k)
     int4* meta;               // [P] workspace: per-pair records written by k_pair_meta, read by the sweep kernels
     uint32_t* partials;       // [kMetaPartials] context-owned scratch of k_pair_meta
+    HostStatus* hst;          // host-mapped mirror (snapshot by k_pair_meta, error words by the sweep kernels)
+    uint32_t seq;             // pass counter echoed into HostStatus::snapshot_seq
     int32_t duo_enabled;      // set by launch_sweep: k_sweep_duo was launched too and sweeps the small pairs when they are the majority
+    int32_t forced;           // set by launch_sweep: the host picked the sweep kernels (hint from the previous pass): no device-side decision
 };
-void launch_sweep(hipStream_t s, int n_categories, bool hellinger2, bool unit_weights, bool wf_pow, const SweepArgs& a);
+// sweep_hint: 0 = unknown (launch every candidate kernel, the device decides from the pair records), 1 = the previous pass of
+// this configuration had a majority of small pairs (k_sweep_duo + the indirect k_sweep), 2 = it had not (plain k_sweep only).
+// Any choice is correct for any input; the hint only avoids launching kernels that return at once.
+void launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinger2, bool unit_weights, bool wf_pow, int sweep_hint,
+                  const SweepArgs& a);
 // trajectory frames: replicate the template's labels / unpack [frames][atoms][3] into SoA + bounding box keys
 void launch_frames_labels(hipStream_t s, const uint8_t* tcat, const int32_t* ttag, int64_t n_tmpl, int32_t n_frames, uint8_t* cat,
                           int32_t* tag, int32_t* sid);

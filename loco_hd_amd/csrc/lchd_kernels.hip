@@ -7,8 +7,8 @@
 //                           scan) / k_cell_scatter.  Atoms are permuted into cell order as 32-byte records {x, y, z, tag, cat}
 //                           (replaces KdTree::build_by_ordered_float, :504-510); batches of structures carry the structure id
 //                           as the slowest grid dimension
-//   K0' anchor de-dup       k_anchor_dedupe_small (both sides in one launch, flags in LDS) or k_mark_anchors / scan /
-//                           k_compact_anchors: an anchor that occurs in many pairs gets its environment built once; every
+//   K0' anchor de-dup       fused into the cell-list launch for small inputs (k_prologue_fused), otherwise k_mark_anchors2 +
+//                           k_dedupe_finish_small or scan + k_compact_anchors: an anchor that occurs in many pairs gets its environment built once; every
 //                           unique anchor gets a 40-byte record (coordinates, tag, position in cell order, structure)
 //   K1  environment build   k_env_cells<NT,TAGLIST>, both structures in one launch: radius search over the concatenated
 //                           neighbour-cell runs (full wavefronts of candidates, two 16-byte loads per candidate, no dependent
@@ -17,7 +17,7 @@
 //                           otherwise; optional CDF keying (replaces env_from_idx :514-542, utils::sort_together utils.rs:25-39)
 //       dense variant       k_env_rows<NT,GLOBALKV>: whole cloud / given distance-matrix row (from_coords, from_dmxs),
 //                           bucket sort on the row's empirical distance CDF
-//   K2' pair records        k_pair_meta (+ k_pair_meta_sum): one 16-byte record per pair {slot A, slot B, n_A | cat, n_B | cat}
+//   K2' pair records        k_pair_meta: one 16-byte record per pair {slot A, slot B, n_A | cat, n_B | cat}
 //                           and the number of pairs small enough for k_sweep_duo
 //   K2  sweep               k_sweep<CMAX,MODE,FMODE,LDSTAB,INDIRECT>: merge-path partition of the two sorted environments,
 //                           per-lane sequential sweep with a wavefront DPP prefix scan of packed category counts,
@@ -32,15 +32,14 @@
 // 256-thread workgroup; k_sweep_duo: eight); a launch has thousands of independent wavefronts, so all 256 CUs / 8 XCDs are
 // filled without any inter-workgroup communication.  All arithmetic is f64 like the reference; no MFMA
 // (there is no contraction in this path).
+#include <algorithm>
 #include <cstdlib>
 
 #include "lchd_device.h"
 #include "lchd_math.h"
 
 #ifndef LCHD_ENV_FLAT
-#ifndef LCHD_ENV_FLAT
 #define LCHD_ENV_FLAT 4   // steps of 64 candidates whose record loads are issued together in the radius search
-#endif
 #endif
 
 namespace lchd {
@@ -237,24 +236,38 @@ static void launch_exclusive_scan(hipStream_t s, const uint32_t* in, uint32_t* o
     k_scan_apply<<<nb, 1024, 0, s>>>(in, out, n, tmp, nb, total_out);
 }
 
-// Batches of equal-sized structures (trajectory frames, regular batches): one workgroup builds the cell list of one structure
-// entirely in LDS -- histogram with returned ranks, scan, scatter -- instead of the five global passes (two of them with one
-// global atomic per atom) of the generic path.  Structure k owns cells [k * cps, (k + 1) * cps) and records
-// [k * size, (k + 1) * size).
+// ------------------------------------------------------------------------------------------------
+// Prologue of a from_primitives pass: cell lists of both structures + anchor de-duplication, in as few launches as the sizes
+// allow (a structure pair of a few thousand atoms spends more time between kernels than inside them):
+//   fused     both sides single structures of <= kStructAtomsMax atoms, <= kFusedPairsMax pairs: ONE launch, workgroup 0 =
+//             side A, workgroup 1 = side B: cell list in LDS (histogram with returned ranks, scan, scatter), anchor flags as
+//             an LDS bit set, scan, anchor records
+//   struct    equal-sized structures that fit LDS (trajectory frames, regular batches, one medium structure): one workgroup
+//             per structure, both sides in one launch, which also zeroes the anchor flags
+//   generic   k_cell_count / scan / k_cell_scatter with global atomics (the caller zeroes the counters with ONE memset)
+// followed, unless fused, by k_mark_anchors2 (both sides from one pass over the pair list) and either
+// k_dedupe_finish_small (both sides, one launch) or scan + k_compact_anchors per side.
+// ------------------------------------------------------------------------------------------------
 constexpr int kStructCellsMax = 4096, kStructAtomsMax = 12000;  // 16 KB + 48 KB of dynamic LDS stay under the 64 KB launch limit
-__global__ __launch_bounds__(256) void k_cell_build_struct(CloudView c, GridView g, int cps, CellRec* __restrict__ rec,
-                                                          uint32_t* __restrict__ pos_of, uint32_t* __restrict__ cell_start) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_cb[];  // hist[cps] u32 | cid[size] u16 | rank[size] u16
-    uint32_t* hist = reinterpret_cast<uint32_t*>(smem_cb);
-    uint16_t* cid = reinterpret_cast<uint16_t*>(smem_cb + (size_t)cps * 4);
-    uint16_t* rank_ = cid + c.struct_size;
-    __shared__ uint32_t wsum[4];
+constexpr int kFusedPairsMax = 1 << 16;                         // one workgroup per side reads the whole pair list
+constexpr int kBitWordsMax = (kStructAtomsMax + 31) / 32;       // anchor flags of one side as a bit set
+
+// One workgroup of NT threads builds the cell list of ONE structure of `size` atoms starting at atom `base`, entirely in
+// LDS -- histogram with returned ranks, scan, scatter -- instead of the five global passes (two of them with one global
+// atomic per atom) of the generic path.  The structure owns cells [cell_base, cell_base + cps) and records
+// [base, base + size).  smem: hist[cps] u32 | cid[size] u16 | rank[size] u16; on return hist[] holds the first slot of
+// every cell (relative to `base`) and cid / rank are intact, so position(atom a) = base + hist[cid[a]] + rank[a].
+template <int NT>
+__device__ __forceinline__ void cell_build_wg(const CloudView& c, const GridView& g, int cps, int64_t base, int size, int64_t cell_base,
+                                              bool write_end, CellRec* __restrict__ rec, uint32_t* __restrict__ pos_of,
+                                              uint32_t* __restrict__ cell_start, unsigned char* smem, uint32_t* wsum /* [NT / 64] */) {
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
+    uint16_t* cid = reinterpret_cast<uint16_t*>(smem + (size_t)cps * 4);
+    uint16_t* rank_ = cid + size;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int size = c.struct_size;
-    const int64_t base = (int64_t)blockIdx.x * size;
-    for (int k = tid; k < cps; k += 256) hist[k] = 0u;
+    for (int k = tid; k < cps; k += NT) hist[k] = 0u;
     __syncthreads();
-    for (int a = tid; a < size; a += 256) {
+    for (int a = tid; a < size; a += NT) {
         const int64_t i = base + a;
         const int cx = cell_coord(c.x[i], g.min[0], g.inv[0], g.dim[0]);
         const int cy = cell_coord(c.y[i], g.min[1], g.inv[1], g.dim[1]);
@@ -264,8 +277,8 @@ __global__ __launch_bounds__(256) void k_cell_build_struct(CloudView c, GridView
         rank_[a] = (uint16_t)atomicAdd(&hist[cell], 1u);
     }
     __syncthreads();
-    // exclusive scan of hist[0 .. cps): thread t owns the cps/256 consecutive entries [t * per, (t + 1) * per)
-    const int per = (cps + 255) / 256, lo = min(tid * per, cps), hi = min(lo + per, cps);
+    // exclusive scan of hist[0 .. cps): thread t owns the consecutive entries [t * per, (t + 1) * per)
+    const int per = (cps + NT - 1) / NT, lo = min(tid * per, cps), hi = min(lo + per, cps);
     uint32_t sum = 0;
     for (int k = lo; k < hi; ++k) sum += hist[k];
     const uint32_t incl = wave_incl_scan_u32(sum);
@@ -276,12 +289,12 @@ __global__ __launch_bounds__(256) void k_cell_build_struct(CloudView c, GridView
     for (int k = lo; k < hi; ++k) {
         const uint32_t h = hist[k];
         hist[k] = pre;
-        cell_start[(int64_t)blockIdx.x * cps + k] = (uint32_t)base + pre;
+        cell_start[cell_base + k] = (uint32_t)base + pre;
         pre += h;
     }
-    if (blockIdx.x == gridDim.x - 1 && tid == 255) cell_start[(int64_t)gridDim.x * cps] = (uint32_t)(base + size);
+    if (write_end && tid == NT - 1) cell_start[cell_base + cps] = (uint32_t)(base + size);
     __syncthreads();
-    for (int a = tid; a < size; a += 256) {
+    for (int a = tid; a < size; a += NT) {
         const int64_t i = base + a;
         const uint32_t pos = (uint32_t)base + hist[cid[a]] + rank_[a];
         CellRec r;
@@ -295,39 +308,96 @@ __global__ __launch_bounds__(256) void k_cell_build_struct(CloudView c, GridView
     }
 }
 
-void launch_cell_build(hipStream_t s, const CloudView& c, GridView g, uint32_t* cell_of, uint32_t* cell_count,
-                       uint32_t* cell_cursor, CellRec* rec, uint32_t* pos_of, uint32_t* cell_start, uint32_t* scan_tmp) {
-    const int cps = g.dim[0] * g.dim[1] * g.dim[2];
-    {   // one workgroup per structure: many structures of any (supported) size, or a few small ones -- a single structure of a
-        // few thousand atoms included, where one launch replaces two memsets and four to six small kernels
-        CloudView cs = c;
-        if (!c.sid) { cs.struct_size = c.n; cs.n_struct = 1; }
-        const bool fits = cs.struct_size > 0 && cs.struct_size <= kStructAtomsMax && cps <= kStructCellsMax &&
-                          (int64_t)cs.n_struct * cs.struct_size == c.n;
-        if (fits && (cs.n_struct >= 64 || cs.struct_size <= 4096) && !getenv("LCHD_NO_STRUCT_CELLS")) {
-            k_cell_build_struct<<<cs.n_struct, 256, (size_t)cps * 4 + (size_t)cs.struct_size * 4, s>>>(cs, g, cps, rec, pos_of, cell_start);
-            return;
+// Anchor flags of one side as an LDS bit set (bits[w] bit k <=> atom 32 w + k is an anchor) -> environment slots and anchor
+// records.  wpre [nw + 1] receives the exclusive prefix of the per-word counts.  `apos_of(i)` = position of atom i in cell
+// order.  Only the slots of anchors are written (nothing reads the others).  nw <= NT.
+template <int NT, class F>
+__device__ __forceinline__ void dedupe_finish_wg(const uint32_t* bits, uint32_t* wpre, int nw, const CloudView& c, uint32_t* __restrict__ slot,
+                                                 AnchorRec* __restrict__ uniq, uint32_t* n_unique_out, uint32_t* wsum /* [NT / 64] */, F apos_of) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t v = tid < nw ? (uint32_t)__popc(bits[tid]) : 0u;
+    const uint32_t incl = wave_incl_scan_u32(v);
+    __syncthreads();  // wsum may still be read by the caller's previous phase
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t pre = incl - v;
+    for (int w = 0; w < wave; ++w) pre += wsum[w];
+    if (tid < nw) wpre[tid] = pre;
+    if (tid == nw - 1) { wpre[nw] = pre + v; *n_unique_out = pre + v; slot[c.n] = pre + v; }
+    __syncthreads();
+    for (int i = tid; i < c.n; i += NT) {
+        const uint32_t w = bits[i >> 5];
+        if ((w >> (i & 31)) & 1u) {
+            const uint32_t sl = wpre[i >> 5] + (uint32_t)__popc(w & ((1u << (i & 31)) - 1u));
+            slot[i] = sl;
+            AnchorRec r;
+            r.x = c.x[i]; r.y = c.y[i]; r.z = c.z[i];
+            r.tag = (uint32_t)c.tag[i];
+            r.apos = apos_of(i);
+            r.sid = c.sid ? c.sid[i] : 0;
+            r.atom = (uint32_t)i;
+            uniq[sl] = r;
         }
     }
-    (void)hipMemsetAsync(cell_count, 0, sizeof(uint32_t) * (size_t)(g.n_cells + 1), s);
-    (void)hipMemsetAsync(cell_cursor, 0, sizeof(uint32_t) * (size_t)(g.n_cells + 1), s);
-    const int nb = (c.n + 255) / 256 > 4096 ? 4096 : (c.n + 255) / 256;
-    if (c.n > 0) k_cell_count<<<nb, 256, 0, s>>>(c, g, cell_of, cell_count);
-    launch_exclusive_scan(s, cell_count, cell_start, g.n_cells, nullptr, scan_tmp);
-    if (c.n > 0) k_cell_scatter<<<nb, 256, 0, s>>>(c, cell_of, cell_start, cell_cursor, rec, pos_of);
 }
 
-// ------------------------------------------------------------------------------------------------
-// K0': anchor de-duplication.  flag[i] = 1 if atom i is an anchor of some pair; exclusive scan turns the
-// flags into environment slots; uniq[slot] = the anchor's record (coordinates, tag, position in cell order, structure).
-// ------------------------------------------------------------------------------------------------
-__global__ void k_mark_anchors(const int64_t* anchors, int64_t n_pairs, int side, int32_t n_points, uint32_t* flag,
-                               DeviceStatus* st) {
-    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n_pairs; p += (int64_t)gridDim.x * blockDim.x) {
+// fused: see the section header.  Dynamic LDS: max over the sides of (cells * 4 + atoms * 4) bytes.
+__global__ __launch_bounds__(1024) void k_prologue_fused(const int64_t* __restrict__ anchors, int64_t n_pairs, PrepSide pa, PrepSide pb,
+                                                          DeviceStatus* st) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_pf[];
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t bits[kBitWordsMax + 1], wpre[kBitWordsMax + 2];
+    const int side = blockIdx.x, tid = threadIdx.x;
+    const PrepSide& P = side ? pb : pa;
+    const CloudView c = P.c;
+    const int n = c.n, cps = P.g.dim[0] * P.g.dim[1] * P.g.dim[2], nw = (n + 31) >> 5;
+    for (int w = tid; w <= kBitWordsMax; w += 1024) bits[w] = 0u;
+    cell_build_wg<1024>(c, P.g, cps, 0, n, 0, true, P.rec, P.pos_of, P.cell_start, smem_pf, wsum);  // (its barriers order the clear above)
+    bool bad = false;
+    for (int64_t p = tid; p < n_pairs; p += 1024) {
         const int64_t a = anchors[2 * p + side];
-        if (a < 0 || a >= n_points) atomicOr(&st->flags, ST_BAD_ANCHOR);
-        else flag[a] = 1u;
+        if (a < 0 || a >= n) bad = true;
+        else atomicOr(&bits[a >> 5], 1u << (a & 31));
     }
+    if (__ballot(bad) && (tid & 63) == 0) atomicOr(&st->flags, ST_BAD_ANCHOR);
+    __syncthreads();
+    const uint32_t* hist = reinterpret_cast<const uint32_t*>(smem_pf);
+    const uint16_t* cid = reinterpret_cast<const uint16_t*>(smem_pf + (size_t)cps * 4);
+    const uint16_t* rank_ = cid + n;
+    dedupe_finish_wg<1024>(bits, wpre, nw, c, P.slot, P.uniq, &st->n_unique[side], wsum,
+                           [&](int i) { return hist[cid[i]] + (uint32_t)rank_[i]; });
+}
+
+// struct: one workgroup per structure, both sides; workgroups past the structures zero `zero_words` u32 at zero_base
+// (the anchor flags of the de-duplication that follows).
+template <int NT>
+__global__ __launch_bounds__(NT) void k_cells_struct2(PrepSide pa, PrepSide pb, int nsa, int nsb, uint32_t* __restrict__ zero_base,
+                                                      int64_t zero_words) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_cb[];
+    __shared__ uint32_t wsum[NT / 64];
+    const int b = blockIdx.x;
+    if (b >= nsa + nsb) {
+        const int64_t nz = (int64_t)gridDim.x - nsa - nsb;
+        for (int64_t i = (int64_t)(b - nsa - nsb) * NT + threadIdx.x; i < zero_words; i += nz * NT) zero_base[i] = 0u;
+        return;
+    }
+    const int side = b >= nsa ? 1 : 0, k = side ? b - nsa : b;
+    const PrepSide& P = side ? pb : pa;
+    const int size = P.c.struct_size, cps = P.g.dim[0] * P.g.dim[1] * P.g.dim[2];
+    const int ns = side ? nsb : nsa;
+    cell_build_wg<NT>(P.c, P.g, cps, (int64_t)k * size, size, (int64_t)k * cps, k == ns - 1, P.rec, P.pos_of, P.cell_start, smem_cb, wsum);
+}
+
+// flag[a] = 1 for every anchor, both sides from one pass over the pair list (flags zeroed beforehand)
+__global__ void k_mark_anchors2(const int64_t* __restrict__ anchors, int64_t n_pairs, int32_t n_a, int32_t n_b, uint32_t* flag_a,
+                                uint32_t* flag_b, DeviceStatus* st) {
+    bool bad = false;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n_pairs; p += (int64_t)gridDim.x * blockDim.x) {
+        const longlong2 ab = reinterpret_cast<const longlong2*>(anchors)[p];
+        if (ab.x < 0 || ab.x >= n_a) bad = true; else flag_a[ab.x] = 1u;
+        if (ab.y < 0 || ab.y >= n_b) bad = true; else flag_b[ab.y] = 1u;
+    }
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(&st->flags, ST_BAD_ANCHOR);
 }
 __global__ void k_compact_anchors(const uint32_t* slot, int32_t n_points, AnchorRec* uniq, CloudView c, const uint32_t* pos_of) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_points; i += gridDim.x * blockDim.x)
@@ -341,81 +411,95 @@ __global__ void k_compact_anchors(const uint32_t* slot, int32_t n_points, Anchor
             uniq[slot[i]] = r;
         }
 }
-
-// Small inputs (both structures <= kDedupeSmallPoints atoms, <= kDedupeSmallPairs pairs): one launch does flags, scan and
-// compaction of BOTH sides -- workgroup 0 side A, workgroup 1 side B, the flags never leave LDS -- instead of four operations
-// per side.  For a 1 000-atom structure pair the eight small launches cost more than the environment build.
-constexpr int kDedupeSmallPoints = 8192, kDedupeSmallPairs = 1 << 16;
-__global__ __launch_bounds__(1024) void k_anchor_dedupe_small(const int64_t* __restrict__ anchors, int64_t n_pairs, CloudView ca, CloudView cb,
-                                                              const uint32_t* pos_a, const uint32_t* pos_b, uint32_t* slot_a, uint32_t* slot_b,
-                                                              AnchorRec* uniq_a, AnchorRec* uniq_b, DeviceStatus* st) {
-    __shared__ uint32_t flag[kDedupeSmallPoints];
+// both sides of <= kStructAtomsMax atoms: global flags -> LDS bit set -> slots + anchor records, one launch
+__global__ __launch_bounds__(1024) void k_dedupe_finish_small(PrepSide pa, PrepSide pb, DeviceStatus* st) {
     __shared__ uint32_t wsum[16];
-    const int side = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const CloudView c = side ? cb : ca;
-    const uint32_t* pos_of = side ? pos_b : pos_a;
-    uint32_t* slot = side ? slot_b : slot_a;
-    AnchorRec* uniq = side ? uniq_b : uniq_a;
-    const int n = c.n;
-    for (int i = tid; i < kDedupeSmallPoints; i += 1024) flag[i] = 0u;
-    __syncthreads();
-    for (int64_t p = tid; p < n_pairs; p += 1024) {
-        const int64_t a = anchors[2 * p + side];
-        if (a < 0 || a >= n) atomicOr(&st->flags, ST_BAD_ANCHOR);
-        else flag[a] = 1u;
+    __shared__ uint32_t bits[kBitWordsMax + 1], wpre[kBitWordsMax + 2];
+    const int side = blockIdx.x, tid = threadIdx.x;
+    const PrepSide& P = side ? pb : pa;
+    const int n = P.c.n, nw = (n + 31) >> 5;
+    const uint32_t* __restrict__ flag = P.slot;
+    for (int w = tid; w < nw; w += 1024) {
+        uint32_t m = 0;
+        for (int k = 0; k < 32; ++k) { const int i = 32 * w + k; m |= (i < n && flag[i]) ? (1u << k) : 0u; }
+        bits[w] = m;
     }
     __syncthreads();
-    // exclusive scan: thread t owns items [8t, 8t + 8)
-    uint32_t v[8], sum = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { v[k] = flag[8 * tid + k]; sum += v[k]; }
-    const uint32_t incl = wave_incl_scan_u32(sum);
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    uint32_t pre = incl - sum;
-    for (int w = 0; w < wave; ++w) pre += wsum[w];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int i = 8 * tid + k;
-        if (i < n) {
-            slot[i] = pre;
-            if (v[k]) {
-                AnchorRec r;
-                r.x = c.x[i]; r.y = c.y[i]; r.z = c.z[i];
-                r.tag = (uint32_t)c.tag[i];
-                r.apos = pos_of[i];
-                r.sid = c.sid ? c.sid[i] : 0;
-                r.atom = (uint32_t)i;
-                uniq[pre] = r;
-            }
-        }
-        pre += v[k];
-    }
-    if (tid == 1023) { slot[n] = pre; st->n_unique[side] = pre; }
-}
-bool launch_anchor_dedupe_small(hipStream_t s, const int64_t* anchors, int64_t n_pairs, const CloudView& ca, const CloudView& cb,
-                                const uint32_t* pos_a, const uint32_t* pos_b, uint32_t* slot_a, uint32_t* slot_b, AnchorRec* uniq_a,
-                                AnchorRec* uniq_b, DeviceStatus* st) {
-    if (ca.n > kDedupeSmallPoints || cb.n > kDedupeSmallPoints || n_pairs > kDedupeSmallPairs || n_pairs <= 0 || ca.n <= 0 || cb.n <= 0 ||
-        getenv("LCHD_NO_SMALL_DEDUPE"))
-        return false;
-    k_anchor_dedupe_small<<<2, 1024, 0, s>>>(anchors, n_pairs, ca, cb, pos_a, pos_b, slot_a, slot_b, uniq_a, uniq_b, st);
-    return true;
+    const uint32_t* __restrict__ pos_of = P.pos_of;
+    dedupe_finish_wg<1024>(bits, wpre, nw, P.c, P.slot, P.uniq, &st->n_unique[side], wsum, [&](int i) { return pos_of[i]; });
 }
 
-void launch_anchor_dedupe(hipStream_t s, const int64_t* anchors, int64_t n_pairs, int side, int32_t n_points,
-                          uint32_t* flag_then_slot, AnchorRec* uniq, const CloudView& c, const uint32_t* pos_of, DeviceStatus* st,
-                          uint32_t* scan_tmp) {
-    (void)hipMemsetAsync(flag_then_slot, 0, sizeof(uint32_t) * (size_t)(n_points + 1), s);
+static bool fits_struct_path(const PrepSide& P, const Tuning& t, CloudView& cs) {
+    cs = P.c;
+    if (!P.c.sid) { cs.struct_size = P.c.n; cs.n_struct = 1; }
+    const int cps = P.g.dim[0] * P.g.dim[1] * P.g.dim[2];
+    return !t.no_struct_cells && cs.struct_size > 0 && cs.struct_size <= kStructAtomsMax && cps <= kStructCellsMax &&
+           (int64_t)cs.n_struct * cs.struct_size == P.c.n;
+}
+static void launch_cells_generic(hipStream_t s, const PrepSide& P) {  // cell_count / cursor already zeroed
+    const CloudView& c = P.c;
+    const int nb = (c.n + 255) / 256 > 4096 ? 4096 : (c.n + 255) / 256;
+    if (c.n > 0) k_cell_count<<<nb, 256, 0, s>>>(c, P.g, P.cell_of, P.cell_count);
+    launch_exclusive_scan(s, P.cell_count, P.cell_start, P.g.n_cells, nullptr, P.scan_tmp);
+    if (c.n > 0) k_cell_scatter<<<nb, 256, 0, s>>>(c, P.cell_of, P.cell_start, P.cursor, P.rec, P.pos_of);
+}
+
+int launch_prologue(hipStream_t s, const Tuning& t, const int64_t* anchors, int64_t n_pairs, const PrepSide& a_in, const PrepSide& b_in,
+                    void* zero_base, size_t zero_bytes, DeviceStatus* st) {
+    PrepSide a = a_in, b = b_in;
+    CloudView csa, csb;
+    const bool fa = fits_struct_path(a, t, csa), fb = fits_struct_path(b, t, csb);
+    const int cps_a = a.g.dim[0] * a.g.dim[1] * a.g.dim[2], cps_b = b.g.dim[0] * b.g.dim[1] * b.g.dim[2];
+    int ops = 0;
+    if (fa && fb && csa.n_struct == 1 && csb.n_struct == 1 && n_pairs <= kFusedPairsMax && !t.no_small_dedupe && a.c.n > 0 && b.c.n > 0) {
+        const size_t lds = std::max((size_t)cps_a * 4 + (size_t)a.c.n * 4, (size_t)cps_b * 4 + (size_t)b.c.n * 4);
+        k_prologue_fused<<<2, 1024, lds, s>>>(anchors, n_pairs, a, b, st);
+        return 1;
+    }
+    // the anchor flags (and, for the generic cell list, its counters) must be zero: folded into the struct launch when both
+    // sides take it, otherwise ONE memset over the contiguous region the caller laid out
+    const bool fold_zero = fa && fb;
+    if (!fold_zero) { (void)hipMemsetAsync(zero_base, 0, zero_bytes, s); ++ops; }
+    if (fa || fb) {
+        PrepSide sa_ = a, sb_ = b;
+        sa_.c = csa; sb_.c = csb;
+        const int nsa = fa ? csa.n_struct : 0, nsb = fb ? csb.n_struct : 0;
+        const size_t lds = std::max(fa ? (size_t)cps_a * 4 + (size_t)csa.struct_size * 4 : 0, fb ? (size_t)cps_b * 4 + (size_t)csb.struct_size * 4 : 0);
+        // the flag arrays sit at the END of the zero region: [.. counters ..][slot_a][slot_b]
+        const int64_t flag_words = (int64_t)a.c.n + 1 + (int64_t)b.c.n + 1;
+        uint32_t* zb = fold_zero ? a.slot : nullptr;
+        const int64_t zw = fold_zero ? (int64_t)((reinterpret_cast<char*>(b.slot) + ((size_t)b.c.n + 1) * 4 - reinterpret_cast<char*>(a.slot)) / 4) : 0;
+        (void)flag_words;
+        if (nsa + nsb <= 16) {
+            const int nz = fold_zero ? (int)std::min<int64_t>(64, (zw + 4095) / 4096) : 0;
+            k_cells_struct2<1024><<<nsa + nsb + nz, 1024, lds, s>>>(sa_, sb_, nsa, nsb, zb, zw);
+        } else {
+            const int nz = fold_zero ? (int)std::min<int64_t>(1024, (zw + 1023) / 1024) : 0;
+            k_cells_struct2<256><<<nsa + nsb + nz, 256, lds, s>>>(sa_, sb_, nsa, nsb, zb, zw);
+        }
+        ++ops;
+    }
+    if (!fa) { launch_cells_generic(s, a); ops += 3; }
+    if (!fb) { launch_cells_generic(s, b); ops += 3; }
     if (n_pairs > 0) {
         const int64_t nbp = (n_pairs + 255) / 256;
-        k_mark_anchors<<<(int)(nbp > 4096 ? 4096 : nbp), 256, 0, s>>>(anchors, n_pairs, side, n_points, flag_then_slot, st);
+        k_mark_anchors2<<<(int)(nbp > 4096 ? 4096 : nbp), 256, 0, s>>>(anchors, n_pairs, a.c.n, b.c.n, a.slot, b.slot, st);
+        ++ops;
     }
-    launch_exclusive_scan(s, flag_then_slot, flag_then_slot, n_points, &st->n_unique[side], scan_tmp);
-    if (n_points > 0) {
-        const int nb = (n_points + 255) / 256;
-        k_compact_anchors<<<nb > 4096 ? 4096 : nb, 256, 0, s>>>(flag_then_slot, n_points, uniq, c, pos_of);
+    if (a.c.n <= kStructAtomsMax && b.c.n <= kStructAtomsMax && !t.no_small_dedupe && a.c.n > 0 && b.c.n > 0) {
+        k_dedupe_finish_small<<<2, 1024, 0, s>>>(a, b, st);
+        return ops + 1;
     }
+    for (int side = 0; side < 2; ++side) {
+        const PrepSide& P = side ? b : a;
+        launch_exclusive_scan(s, P.slot, P.slot, P.c.n, &st->n_unique[side], P.scan_tmp);
+        if (P.c.n > 0) {
+            const int nb = (P.c.n + 255) / 256;
+            k_compact_anchors<<<nb > 4096 ? 4096 : nb, 256, 0, s>>>(P.slot, P.c.n, P.uniq, P.c, P.pos_of);
+        }
+        ops += 2;
+    }
+    return ops;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -869,14 +953,6 @@ bool launch_env_cells(hipStream_t s, int cap, const DevConfig* cfg, bool tag_lis
     } else if (cap <= 4096) {
         launch_env_cells_nt<256>(s, grid, lds, tag_list, cfg, a, b, thr, cap, st);
     } else {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_cells<1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      16384 * 9);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_cells<1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      16384 * 9);
-            attr_set = true;
-        }
         launch_env_cells_nt<1024>(s, grid, lds, tag_list, cfg, a, b, thr, cap, st);
     }
     return true;
@@ -1073,12 +1149,6 @@ bool launch_env_rows(hipStream_t s, int cap, const DevConfig* cfg, const CloudVi
     const dim3 grid((unsigned)n_rows);
     if (cap > 16384) {  // keys in global memory, 64 KB histogram in LDS
         const size_t lds = (size_t)(kRowBucketsBig + 1) * sizeof(uint32_t) + 16;
-        static bool attr_big = false;
-        if (!attr_big) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_rows<1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)((kRowBucketsBig + 1) * sizeof(uint32_t) + 16));
-            attr_big = true;
-        }
         k_env_rows<1024, true><<<grid, 1024, lds, s>>>(cfg, c, dmx, ld, row_len, cap, kRowBucketsBig, image_bound, env, st);
         return true;
     }
@@ -1088,12 +1158,6 @@ bool launch_env_rows(hipStream_t s, int cap, const DevConfig* cfg, const CloudVi
     } else if (cap <= 4096) {
         k_env_rows<256, false><<<grid, 256, lds, s>>>(cfg, c, dmx, ld, row_len, cap, kRowBucketsSmall, image_bound, env, st);
     } else {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_env_rows<1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      16384 * 9 + 16 + (kRowBucketsSmall + 1) * 4);
-            attr_set = true;
-        }
         k_env_rows<1024, false><<<grid, 1024, lds, s>>>(cfg, c, dmx, ld, row_len, cap, kRowBucketsSmall, image_bound, env, st);
     }
     return true;
@@ -1116,7 +1180,7 @@ bool launch_env_rows(hipStream_t s, int cap, const DevConfig* cfg, const CloudVi
 //   arbitrary category weights.  The per-lane state is just the packed integer category counts plus the
 //   running Bhattacharyya numerator D = sum_c sqrt(a_c b_c); an event touches one category, so D is updated
 //   in O(1) from an LDS table of sqrt(k) and H^2 = 1 - D / sqrt(N_a N_b).  Where that cancellation form would
-//   lose accuracy (H^2 < 1e-3) the literal sum_c (sqrt(a_c/N_a) - sqrt(b_c/N_b))^2 / 2 is evaluated instead,
+//   lose accuracy (H^2 < kExactH2Below = 1e-6) the literal sum_c (sqrt(a_c/N_a) - sqrt(b_c/N_b))^2 / 2 is evaluated instead,
 //   which also gives exactly 0 for identical environments.
 // MODE_GEN: every other StatisticalDistance (statistical_distances.rs:4-78): weighted counts in registers,
 //   normalised like pmf.rs:65-83, distance through one out-of-line call.
@@ -1157,6 +1221,10 @@ constexpr int kDuoTileFwd = 224;  // = kDuoTile (k_sweep_duo, below)
 constexpr double kExactH2Below = 1e-6;
 constexpr int kSqrtTab = 512;  // LDSTAB kernels: environments of at most 512 points, sqrt tables entirely in LDS
 constexpr int kSweepWaves = LCHD_SWEEP_WAVES;  // anchor pairs (wavefronts) per workgroup
+
+// A sweep kernel reports a (rare) condition: plain store of 1 into the condition's word of the host-mapped mirror (every
+// writer stores the same value; no atomics on host memory, no device-to-host copy afterwards).
+__device__ __forceinline__ void sweep_report(HostStatus* h, uint32_t bit) { h->sweep_flags[__builtin_ctz(bit)] = 1u; }
 
 __device__ __forceinline__ void wave_sync_lds() {
     // LDS operations of one wavefront execute in issue order; this only stops the compiler from moving
@@ -1279,7 +1347,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
     // When pairs with at most kDuoTile merged events are the majority of a launch, k_sweep_duo sweeps them two per wavefront
     // and the INDIRECT instantiation of this kernel picks the remaining ones out of the pair records; otherwise the plain
     // instantiation sweeps everything.  All three decide from the same word (k_pair_meta: DeviceStatus::n_small).
-    {
+    if (!args.forced) {  // (forced: the host launched exactly the kernels that have to run)
         const bool duo_active = 2 * args.st->n_small >= (unsigned long long)args.n_pairs;
         if constexpr (INDIRECT) { if (!duo_active) return; }
         else { if (args.duo_enabled && duo_active) return; }
@@ -1401,7 +1469,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
         const uint8_t* __restrict__ tB = args.env_b.cat + eb * args.env_b.stride;
         const int wfi = args.wf_index ? args.wf_index[p] : 0;
         if (args.wf_index && (wfi < 0 || wfi >= n_wf)) {
-            if (lane == 0) { atomicOr(&args.st->flags, ST_BAD_WF); args.out[p] = nan(""); }
+            if (lane == 0) { sweep_report(args.hst, ST_BAD_WF); args.out[p] = nan(""); }
             take_next();
             continue;
         }
@@ -1411,7 +1479,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
             const WfEntry wfe = cfgp->wf[wfi];
             wf = wf_load(wfe, cfgp->wf_params + wfe.offset);
             if (kA[0] != 0ull || kB[0] != 0ull) {  // src/locohd.rs:74-77 (F_KEY: checked by the environment kernels)
-                if (lane == 0) { atomicOr(&args.st->flags, ST_FIRST_NOT_ZERO); args.out[p] = nan(""); }
+                if (lane == 0) { sweep_report(args.hst, ST_FIRST_NOT_ZERO); args.out[p] = nan(""); }
                 take_next();
                 continue;
             }
@@ -1811,7 +1879,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
         acc += (Finf - F_carry) * H_carry;
         const unsigned long long anyzero = __ballot(zero_norm);  // (categories were checked when the environments were built)
         if (lane == 0) {
-            if (anyzero) atomicOr(&args.st->flags, ST_ZERO_NORM);
+            if (anyzero) sweep_report(args.hst, ST_ZERO_NORM);
             args.out[p] = acc;
         }
         STAMP(7);
@@ -1865,7 +1933,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs arg
     __shared__ double t_sqrt[NT], t_rsqrt[NT];
     __shared__ uint64_t sA_[WPB][2][TILE], sB_[WPB][2][TILE];
     __shared__ uint8_t cA_[WPB][2][TILE], cB_[WPB][2][TILE];
-    if (2 * args.st->n_small < (unsigned long long)args.n_pairs) return;  // mostly larger pairs: k_sweep sweeps everything
+    if (!args.forced && 2 * args.st->n_small < (unsigned long long)args.n_pairs) return;  // mostly larger pairs: k_sweep sweeps everything
     const int tid = threadIdx.x, lane = tid & 63, tl = lane & 31, team = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const DevConfig* __restrict__ cfgp = args.cfg;
@@ -2143,7 +2211,7 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
         const uint8_t* __restrict__ tB = args.env_b.cat + eb * args.env_b.stride;
         const int wfi = args.wf_index ? args.wf_index[p] : 0;
         if (args.wf_index && (wfi < 0 || wfi >= n_wf)) {
-            if (lane == 0) { atomicOr(&args.st->flags, ST_BAD_WF); args.out[p] = nan(""); }
+            if (lane == 0) { sweep_report(args.hst, ST_BAD_WF); args.out[p] = nan(""); }
             take_next();
             continue;
         }
@@ -2153,7 +2221,7 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
             const WfEntry wfe = cfgp->wf[wfi];
             wf = wf_load(wfe, cfgp->wf_params + wfe.offset);
             if (kA[0] != 0ull || kB[0] != 0ull) {  // src/locohd.rs:74-77 (F_KEY: checked by the environment kernels)
-                if (lane == 0) { atomicOr(&args.st->flags, ST_FIRST_NOT_ZERO); args.out[p] = nan(""); }
+                if (lane == 0) { sweep_report(args.hst, ST_FIRST_NOT_ZERO); args.out[p] = nan(""); }
                 take_next();
                 continue;
             }
@@ -2338,8 +2406,8 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
         acc += (Finf - F_carry) * H_carry;
         const unsigned long long anybad = __ballot(bad_cat), anyzero = __ballot(zero_norm);
         if (lane == 0) {
-            if (anybad) { atomicOr(&args.st->flags, ST_BAD_CATEGORY); acc = nan(""); }
-            if (anyzero) atomicOr(&args.st->flags, ST_ZERO_NORM);
+            if (anybad) { sweep_report(args.hst, ST_BAD_CATEGORY); acc = nan(""); }
+            if (anyzero) sweep_report(args.hst, ST_ZERO_NORM);
             args.out[p] = acc;
         }
     }
@@ -2375,13 +2443,7 @@ static void launch_sweep_wide(hipStream_t s, int n_cat, int64_t n_pairs, int fmo
         else k_sweep_wide<MODE, F_ANY, 4><<<grid, 256, dyn, s>>>(a);
     } else {
         const unsigned grid = (unsigned)(n_pairs < 8192 ? n_pairs : 8192);
-        const size_t dyn = (size_t)n_cat * 256;
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_wide<MODE, F_KEY, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 256);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_wide<MODE, F_ANY, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 256);
-            attr = true;
-        }
+        const size_t dyn = (size_t)n_cat * 256;  // (> 64 KB from 257 categories' worth on: init_device_kernels raised the limit)
         if (fmode == F_KEY) k_sweep_wide<MODE, F_KEY, 1><<<grid, 64, dyn, s>>>(a);
         else k_sweep_wide<MODE, F_ANY, 1><<<grid, 64, dyn, s>>>(a);
     }
@@ -2391,7 +2453,7 @@ static void launch_sweep_wide(hipStream_t s, int n_cat, int64_t n_pairs, int fmo
 // n_B | category of anchor B << 24}; n = 0 marks a pair the sweep must answer with NaN (anchor index out of range -- already
 // flagged by k_mark_anchors -- or an environment that overflowed / is empty -- flagged by K1).
 __global__ void k_pair_meta(SweepArgs args) {
-    int n_small = 0;
+    int n_small = 0, biggest = 0;
     for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < args.n_pairs; p += (int64_t)gridDim.x * blockDim.x) {
         int64_t ea = p, eb = p;
         bool ok = true;
@@ -2412,71 +2474,97 @@ __global__ void k_pair_meta(SweepArgs args) {
             }
         }
         args.meta[p] = make_int4((int)ea, (int)eb, nA | (c0a << 24), nB | (c0b << 24));
+        biggest = max(biggest, max(nA, nB));
         // pairs k_sweep_duo takes: everything that fits its tile, and the unusable ones (it writes their NaN)
         n_small += (nA + nB - 2 <= kDuoTileFwd) ? 1 : 0;
     }
     // pairs that fit one 32-lane tile: if they are the majority, k_sweep_duo sweeps them and k_sweep only the rest.  One
-    // partial count per workgroup, summed by k_pair_meta_sum: thousands of atomics on one word would cost more than this kernel
-    __shared__ int part_s[4];
-    for (int m = 32; m > 0; m >>= 1) n_small += __shfl_xor(n_small, m);
-    if ((threadIdx.x & 63) == 0) part_s[threadIdx.x >> 6] = n_small;
+    // partial count per workgroup (thousands of atomics on one word would cost more than this kernel); the workgroup that
+    // finishes LAST folds them, publishes what the host wants to know into the host-mapped mirror and resets the device
+    // status for the next pass -- no separate summing kernel, no memset before a pass, no copy after it.
+    __shared__ int part_s[4], big_s[4];
+    __shared__ bool last_s;
+    for (int m = 32; m > 0; m >>= 1) { n_small += __shfl_xor(n_small, m); biggest = max(biggest, __shfl_xor(biggest, m)); }
+    if ((threadIdx.x & 63) == 0) { part_s[threadIdx.x >> 6] = n_small; big_s[threadIdx.x >> 6] = biggest; }
     __syncthreads();
-    if (threadIdx.x == 0) args.partials[blockIdx.x] = (uint32_t)(part_s[0] + part_s[1] + part_s[2] + part_s[3]);
-}
-__global__ __launch_bounds__(256) void k_pair_meta_sum(const uint32_t* __restrict__ partials, int n, DeviceStatus* st) {
+    if (threadIdx.x == 0) {
+        // largest environment of the pass (an overflowed one reported its size from the environment kernel already): the
+        // host lets its capacity hint decay with it
+        atomicMax(&args.st->max_env, (uint32_t)max(max(big_s[0], big_s[1]), max(big_s[2], big_s[3])));
+        __hip_atomic_store(&args.partials[blockIdx.x], (uint32_t)(part_s[0] + part_s[1] + part_s[2] + part_s[3]), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last_s = atomicAdd(&args.st->meta_done, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last_s) return;
+    __threadfence();
     __shared__ unsigned long long red[4];
     unsigned long long v = 0;
-    for (int i = threadIdx.x; i < n; i += 256) v += partials[i];
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) v += __hip_atomic_load(&args.partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int m = 32; m > 0; m >>= 1) v += shfl_u64(v, (threadIdx.x & 63) ^ m);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x == 0) st->n_small = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) {
+        DeviceStatus* st = args.st;
+        const unsigned long long total = red[0] + red[1] + red[2] + red[3];
+        st->n_small = total;  // read by the sweep kernels of this pass when the host did not pick them itself
+        HostStatus* h = args.hst;
+        h->flags = __hip_atomic_load(&st->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        h->max_env = __hip_atomic_load(&st->max_env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        h->n_unique[0] = st->n_unique[0];
+        h->n_unique[1] = st->n_unique[1];
+        h->n_small = total;
+        h->snapshot_seq = args.seq;
+        st->flags = 0u;
+        st->max_env = 0u;
+        st->meta_done = 0u;
+    }
 }
 
-void launch_sweep(hipStream_t s, int n_categories, bool hellinger2, bool unit_weights, bool wf_pow, const SweepArgs& a_in) {
+void launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinger2, bool unit_weights, bool wf_pow, int sweep_hint,
+                  const SweepArgs& a_in) {
     if (a_in.n_pairs <= 0) return;
     SweepArgs a = a_in;
     a.duo_enabled = 0;
+    a.forced = 0;
     {
         const int64_t nb = (a.n_pairs + 255) / 256;
         const int mgrid = (int)(nb < kMetaPartials ? nb : kMetaPartials);
         k_pair_meta<<<mgrid, 256, 0, s>>>(a);
-        k_pair_meta_sum<<<1, 256, 0, s>>>(a.partials, mgrid, a.st);
     }
-    {
-        bool wide = n_categories > 32;
-        if (const char* f = getenv("LCHD_FORCE_WIDE")) wide = wide || atoi(f) != 0;  // test hook
-        if (wide) {
-            bool h2 = hellinger2;
-            if (const char* f = getenv("LCHD_FORCE_GENERIC")) h2 = h2 && atoi(f) == 0;
-            const int fmode = (a.env_a.cdf_keys && a.env_b.cdf_keys) ? F_KEY : F_ANY;
-            if (!h2) launch_sweep_wide<MODE_GEN>(s, n_categories, a.n_pairs, fmode, a);
-            else if (unit_weights) launch_sweep_wide<MODE_H2U>(s, n_categories, a.n_pairs, fmode, a);
-            else launch_sweep_wide<MODE_H2W>(s, n_categories, a.n_pairs, fmode, a);
-            return;
-        }
+    if (t.force_generic) hellinger2 = false;  // test hook
+    if (n_categories > 32 || t.force_wide) {
+        const int fmode = (a.env_a.cdf_keys && a.env_b.cdf_keys) ? F_KEY : F_ANY;
+        if (!hellinger2) launch_sweep_wide<MODE_GEN>(s, n_categories, a.n_pairs, fmode, a);
+        else if (unit_weights) launch_sweep_wide<MODE_H2U>(s, n_categories, a.n_pairs, fmode, a);
+        else launch_sweep_wide<MODE_H2W>(s, n_categories, a.n_pairs, fmode, a);
+        return;
     }
     const int64_t blocks = (a.n_pairs + kSweepWaves - 1) / kSweepWaves;
     // grid-stride: LDS tables are built once per block.  8192 workgroups = 8 rounds of the 1024 that are resident at a time: finer
     // than that the table loads show, coarser the last round's imbalance does (measured on C2a: 4096 +2.8 %, 16384 +0.5 %)
     const unsigned grid = (unsigned)(blocks < 8192 ? blocks : 8192);
-    int cmax = n_categories;
-    if (const char* f = getenv("LCHD_FORCE_CMAX")) cmax = atoi(f) > cmax ? atoi(f) : cmax;  // test hook
-    if (const char* f = getenv("LCHD_FORCE_GENERIC")) hellinger2 = hellinger2 && atoi(f) == 0;  // test hook
-    bool small = a.env_a.stride <= kSqrtTab && a.env_b.stride <= kSqrtTab;  // every count fits the LDS tables
-    if (const char* f = getenv("LCHD_FORCE_BIGENV")) small = small && atoi(f) == 0;  // test hook
+    const int cmax = std::max(n_categories, t.force_cmax);  // (force_cmax: test hook)
+    const bool small = a.env_a.stride <= kSqrtTab && a.env_b.stride <= kSqrtTab && !t.force_bigenv;  // every count fits the LDS tables
     const int fmode = (a.env_a.cdf_keys && a.env_b.cdf_keys) ? F_KEY : (wf_pow ? F_ANY : F_FAST);
-    if (hellinger2 && unit_weights && small && fmode == F_KEY && cmax <= 16 && !a.wf_index && !getenv("LCHD_NO_DUO")) {
-        // small environments: two pairs per wavefront; both kernels are launched, the device-side maximum of merged events
-        // per pair (k_pair_meta) decides which of them does the work
-        a.duo_enabled = 1;
-        const int64_t dblocks = (a.n_pairs + 2 * kSweepWaves - 1) / (2 * kSweepWaves);
-        const unsigned dgrid = (unsigned)(dblocks < 8192 ? dblocks : 8192);
-        const unsigned bgrid = grid < 1024 ? grid : 1024;  // the listed (larger) pairs are a minority whenever this launch does anything
-        constexpr int NTH = 64 * kSweepWaves;
-        if (cmax <= 8) { k_sweep_duo<8><<<dgrid, NTH, 0, s>>>(a); k_sweep<8, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
-        else if (cmax <= 12) { k_sweep_duo<12><<<dgrid, NTH, 0, s>>>(a); k_sweep<12, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
-        else { k_sweep_duo<16><<<dgrid, NTH, 0, s>>>(a); k_sweep<16, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+    if (hellinger2 && unit_weights && small && fmode == F_KEY && cmax <= 16 && !a.wf_index && !t.no_duo) {
+        // small environments: two pairs per wavefront.  Without a hint both kernels and the plain sweep are launched and the
+        // number of small pairs (k_pair_meta) decides on the device which of them do the work; with the hint of the previous
+        // pass only the kernels that will work are launched.
+        const int hint = t.no_sweep_hint ? 0 : sweep_hint;
+        a.forced = hint != 0;
+        if (hint != 2) {
+            a.duo_enabled = 1;
+            const int64_t dblocks = (a.n_pairs + 2 * kSweepWaves - 1) / (2 * kSweepWaves);
+            const unsigned dgrid = (unsigned)(dblocks < 8192 ? dblocks : 8192);
+            const unsigned bgrid = grid < 1024 ? grid : 1024;  // the listed (larger) pairs are a minority whenever this launch does anything
+            constexpr int NTH = 64 * kSweepWaves;
+            if (cmax <= 8) { k_sweep_duo<8><<<dgrid, NTH, 0, s>>>(a); k_sweep<8, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+            else if (cmax <= 12) { k_sweep_duo<12><<<dgrid, NTH, 0, s>>>(a); k_sweep<12, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+            else { k_sweep_duo<16><<<dgrid, NTH, 0, s>>>(a); k_sweep<16, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+            if (hint == 1) return;
+        }
     }
     if (!hellinger2) launch_sweep_f<MODE_GEN, false>(s, cmax, grid, fmode, a);
     else if (unit_weights) {
@@ -2486,6 +2574,26 @@ void launch_sweep(hipStream_t s, int n_categories, bool hellinger2, bool unit_we
         if (small) launch_sweep_f<MODE_H2W, true>(s, cmax, grid, fmode, a);
         else launch_sweep_f<MODE_H2W, false>(s, cmax, grid, fmode, a);
     }
+}
+
+// Kernels that may be launched with more than 64 KB of dynamic LDS need the limit raised per DEVICE: lchd_ctx_create calls this
+// with the context's device current (a process-wide "done once" flag would leave a second device without the attribute).
+void init_device_kernels() {
+    auto raise = [](const void* fn, int bytes) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); };
+    raise(reinterpret_cast<const void*>(&k_env_cells<1024, false>), 16384 * 9);
+    raise(reinterpret_cast<const void*>(&k_env_cells<1024, true>), 16384 * 9);
+    raise(reinterpret_cast<const void*>(&k_env_rows<1024, true>), (int)((kRowBucketsBig + 1) * sizeof(uint32_t) + 16));
+    raise(reinterpret_cast<const void*>(&k_env_rows<1024, false>), 16384 * 9 + 16 + (kRowBucketsSmall + 1) * 4);
+    raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_GEN, F_KEY, 1>), 256 * 256);
+    raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_GEN, F_ANY, 1>), 256 * 256);
+    raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_H2U, F_KEY, 1>), 256 * 256);
+    raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_H2U, F_ANY, 1>), 256 * 256);
+    raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_H2W, F_KEY, 1>), 256 * 256);
+    raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_H2W, F_ANY, 1>), 256 * 256);
+    raise(reinterpret_cast<const void*>(&k_prologue_fused), kStructCellsMax * 4 + kStructAtomsMax * 4);  // + ~3 KB static: above 64 KB in total
+    raise(reinterpret_cast<const void*>(&k_cells_struct2<1024>), kStructCellsMax * 4 + kStructAtomsMax * 4);
+    raise(reinterpret_cast<const void*>(&k_cells_struct2<256>), kStructCellsMax * 4 + kStructAtomsMax * 4);
+    (void)hipGetLastError();
 }
 
 // sum over pairs of n_A + n_B (algorithmic-bytes accounting for bench.py; not part of the scoring path)
