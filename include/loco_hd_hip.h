@@ -174,8 +174,43 @@ double lchd_frames_last_convert_ms(lchd_ctx *ctx, lchd_cloud *frames);
 /* Coordinates of a cloud / frames buffer back on the host as [n][3] f64 (n must equal the atoms it holds). */
 int lchd_cloud_get_coords(lchd_ctx *ctx, lchd_cloud *cloud, double *xyz_out, int64_t n);
 
+/* ---- multi-GPU ------------------------------------------------------------------------------------
+ * The reference's parallelism lives INSIDE the core call: a thread pool that is a field of `LoCoHD` (src/locohd.rs:53,
+ * 373-383) runs the anchor pairs of one call (:545-557, order-preserving collect).  The counterpart here is a GROUP of
+ * devices inside one process: lchd_group_from_primitives has the signature and the semantics of lchd_from_primitives and
+ * spreads the call's anchor pairs over the group's GPUs (both structures are replicated, pairs are binned by their side-A
+ * anchor so that every device builds ~1/n of side A's environments, every device scores its bin concurrently, out[i] is
+ * the score of anchors[i]).  A binding in any host language gets multi-GPU scoring from this one call; no torch, no MPI. */
+typedef struct lchd_group lchd_group;
+/* devices: HIP device ordinals (a device may be listed twice: two contexts on it); n_devices in [1, 64]. */
+int lchd_group_create(const int32_t *devices, int32_t n_devices, lchd_group **out);
+void lchd_group_destroy(lchd_group *group);
+int32_t lchd_group_size(const lchd_group *group);
+int lchd_group_from_primitives(lchd_group *group, const lchd_config *cfg, const double *xyz_a, const int32_t *cat_a,
+                               const int32_t *tag_a, int64_t n_a, const double *xyz_b, const int32_t *cat_b,
+                               const int32_t *tag_b, int64_t n_b, const int64_t *anchors, const int32_t *wf_index,
+                               int64_t n_pairs, double threshold_distance, double *out);
+/* Pairs the most recent lchd_group_from_primitives call gave to each device: counts_out[n_devices]. */
+int lchd_group_last_counts(const lchd_group *group, int64_t *counts_out);
+
+/* One process per GPU (torch.distributed / MPI style): every rank holds the whole pair list on its device and runs the
+ * SAME deterministic partition (a pure function of the list, so no communication is needed to agree on it):
+ *   bin(p) = floor(anchor_a(p) * 1024 / n_atoms_a),  rank(bin) = min(world - 1, floor(#pairs in lower bins * world / n_pairs)).
+ * lchd_shard_plan_dev computes it (one kernel + a wait) and returns the pair count of every rank;
+ * lchd_shard_select_dev compacts THIS rank's pairs (d_sel_anchors [counts[rank]][2], d_sel_index [counts[rank]] = their
+ * positions in the full list; enqueued on the context's stream, no wait);
+ * lchd_unshard_scores_dev, on the gathering rank, puts score k of rank r at its pair's original position:
+ * d_gathered is [world][2][stride] doubles -- rank r's scores, then its d_sel_index reinterpreted as doubles. */
+int lchd_shard_plan_dev(lchd_ctx *ctx, const int64_t *d_anchors, int64_t n_pairs, int64_t n_atoms_a, int32_t world,
+                        int64_t *counts_out);
+int lchd_shard_select_dev(lchd_ctx *ctx, const int64_t *d_anchors, int64_t n_pairs, int64_t n_atoms_a, int32_t rank,
+                          int64_t *d_sel_anchors, int64_t *d_sel_index);
+int lchd_unshard_scores_dev(lchd_ctx *ctx, const double *d_gathered, const int64_t *counts, int32_t world, int64_t stride,
+                            double *d_out, int64_t n_pairs);
+
 /* Per-kernel timing of the most recent *_dev / driver call, measured with hipEvents on the context's stream.
- * names: "cells", "anchors", "env", "sweep"; returns milliseconds, <0 if unknown name / timing disabled. */
+ * names: "cells" (cell lists + anchor de-duplication: one phase), "anchors" (always ~0, kept for callers of the first
+ * version), "env", "sweep"; returns milliseconds, <0 if unknown name / timing disabled. */
 int lchd_ctx_enable_timing(lchd_ctx *ctx, int32_t on);
 double lchd_ctx_last_ms(lchd_ctx *ctx, const char *phase);
 /* Environment statistics of the most recent call: sum over anchor pairs of (n_A + n_B) (points incl. anchors). */

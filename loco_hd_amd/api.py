@@ -175,12 +175,16 @@ class LoCoHD:
 
     Same constructor as the reference; ``n_of_threads`` is accepted and ignored (the rayon pool is
     replaced by the GPU).  ``device`` (keyword-only, additive) selects the HIP device; default = current.
+    ``devices`` (keyword-only, additive): a list of HIP device ordinals -- the counterpart of the reference's thread pool,
+    which is a field of the instance (src/locohd.rs:53,373-383): ``from_primitives`` then spreads the anchor pairs of every
+    call over these GPUs inside the C library (lchd_group_from_primitives), results in anchor-pair order as always.
     """
 
     def __init__(self, categories: Sequence[str], w_func: Union[None, WeightFunction, Dict[str, WeightFunction]] = None,
                  tag_pairing_rule: Optional[TagPairingRule] = None, n_of_threads: Optional[int] = None,
                  category_weights: Optional[Sequence[float]] = None,
-                 statistical_distance: Optional[StatisticalDistance] = None, *, device: Optional[int] = None) -> None:
+                 statistical_distance: Optional[StatisticalDistance] = None, *, device: Optional[int] = None,
+                 devices: Optional[Sequence[int]] = None) -> None:
         names = [str(c) for c in categories]
         cat_map: Dict[str, int] = {}
         for i, nm in enumerate(names):  # :312-316 HashMap collect: a repeated name keeps its last index
@@ -205,7 +209,13 @@ class LoCoHD:
             raise TypeError("statistical_distance must be a StatisticalDistance")
         self._n_threads = n_of_threads
         self._device = -1 if device is None else int(device)
+        self._devices = None if devices is None else [int(d) for d in devices]
+        if self._devices is not None and not self._devices:
+            raise ValueError("devices must name at least one HIP device")
+        if self._devices is not None and device is None:
+            self._device = self._devices[0]  # the single-device entry points (from_anchors, from_dmxs, from_coords)
         self._ctx = None
+        self._group = None
         self._wf_names = list(self._w_func) if isinstance(self._w_func, dict) else None
 
     # ---- getters (#[pyo3(get)], :45-52) -------------------------------------------------------------
@@ -233,13 +243,32 @@ class LoCoHD:
             self._ctx = h
         return self._ctx
 
+    def _device_group(self):
+        if self._group is None:
+            h = C.c_void_p()
+            devs = np.asarray(self._devices, dtype=np.int32)
+            N.check(N.lib().lchd_group_create(N.ip(devs), len(devs), C.byref(h)))
+            self._group = h
+        return self._group
+
+    def last_group_counts(self) -> List[int]:
+        """Anchor pairs each device of ``devices`` scored in the most recent from_primitives / from_packed call."""
+        if self._group is None:
+            return []
+        out = np.zeros(len(self._devices), dtype=np.int64)
+        N.check(N.lib().lchd_group_last_counts(self._group, N.lp(out)))
+        return out.tolist()
+
     def __del__(self):
         ctx, self._ctx = getattr(self, "_ctx", None), None
-        if ctx is not None:
-            try:
+        grp, self._group = getattr(self, "_group", None), None
+        try:
+            if ctx is not None:
                 N.lib().lchd_ctx_destroy(ctx)
-            except Exception:
-                pass
+            if grp is not None:
+                N.lib().lchd_group_destroy(grp)
+        except Exception:
+            pass
 
     def _cats(self, seq) -> np.ndarray:
         get = self._categories.get
@@ -403,6 +432,11 @@ class LoCoHD:
         if len(anchors) == 0:
             return out
         xa, xb = _f64(pa.xyz).reshape(-1, 3), _f64(pb.xyz).reshape(-1, 3)
+        if self._devices is not None and len(self._devices) > 1:  # the instance's device group (the reference: its thread pool)
+            N.check(N.lib().lchd_group_from_primitives(self._device_group(), C.byref(cfg), N.dp(xa), N.ip(pa.cat), N.ip(pa.tag), len(xa),
+                                                       N.dp(xb), N.ip(pb.cat), N.ip(pb.tag), len(xb), N.lp(anchors), N.ip(wf_index),
+                                                       len(anchors), float(threshold_distance), N.dp(out)))
+            return out
         N.check(N.lib().lchd_from_primitives(self._context(), C.byref(cfg), N.dp(xa), N.ip(pa.cat), N.ip(pa.tag), len(xa),
                                              N.dp(xb), N.ip(pb.cat), N.ip(pb.tag), len(xb), N.lp(anchors), N.ip(wf_index),
                                              len(anchors), float(threshold_distance), N.dp(out)))

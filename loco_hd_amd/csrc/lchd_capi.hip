@@ -174,7 +174,7 @@ struct lchd_ctx {
     int sweep_hint = 0;                // 0 unknown, 1 small pairs were the majority in the last pass, 2 they were not (launch_sweep)
     unsigned long long* d_points = nullptr;
     double* d_tabs = nullptr;  // sqrt(k) | 1/sqrt(k), 65536 entries each
-    uint32_t* d_partials = nullptr;  // scratch of k_pair_meta (kMetaPartials words)
+    DoneState* d_done = nullptr;     // 'last workgroup' counters / accumulators of k_pair_meta (zero between kernels)
     // host-pointer calls: one grow-only device block + pinned staging block per context (no allocation in the steady state)
     char *d_io = nullptr, *h_io = nullptr;
     size_t io_cap = 0;
@@ -197,6 +197,12 @@ struct lchd_ctx {
         int cap = 0;
         SweepArgs sw{};
     } pend;
+    // multi-GPU sharding helpers (lchd_shard_*): device state, host-mapped counts, the plan they belong to
+    ShardState* d_shard = nullptr;
+    int64_t* h_counts = nullptr;
+    uint32_t* d_bad = nullptr;
+    int shard_world = 0;
+    int64_t shard_pairs = 0, shard_atoms = 0;
     // most recent sweep (for lchd_ctx_last_env_points)
     SweepArgs last{};
     bool last_valid = false;
@@ -248,6 +254,7 @@ static Tuning tuning_from_env() {  // the ONLY place that reads LCHD_* hooks (te
     t.force_generic = env_int("LCHD_FORCE_GENERIC", 0) != 0;
     t.force_bigenv = env_int("LCHD_FORCE_BIGENV", 0) != 0;
     t.no_sweep_hint = getenv("LCHD_NO_SWEEP_HINT") != nullptr;
+    t.no_inline_meta = getenv("LCHD_NO_INLINE_META") != nullptr;
     t.no_count8 = getenv("LCHD_NO_COUNT8") != nullptr;
     t.no_tables = getenv("LCHD_NO_SD_TABLES") != nullptr;
     t.force_cmax = env_int("LCHD_FORCE_CMAX", 0);
@@ -308,7 +315,8 @@ extern "C" int lchd_ctx_create(int32_t device, lchd_ctx** out) {
     if ((e = hipHostMalloc(&c->h_status, sizeof(HostStatus))) != hipSuccess) return bail(e, "hipHostMalloc(status)");
     memset(c->h_status, 0, sizeof(HostStatus));
     if ((e = hipMalloc(&c->d_tabs, sizeof(double) * 2 * 65536)) != hipSuccess) return bail(e, "hipMalloc(tables)");
-    if ((e = hipMalloc(&c->d_partials, sizeof(uint32_t) * kMetaPartials)) != hipSuccess) return bail(e, "hipMalloc(partials)");
+    if ((e = hipMalloc(&c->d_done, sizeof(DoneState))) != hipSuccess) return bail(e, "hipMalloc(done)");
+    if ((e = hipMemset(c->d_done, 0, sizeof(DoneState))) != hipSuccess) return bail(e, "hipMemset(done)");
     init_device_kernels();  // per device, not per process
     launch_fill_sqrt_tables(c->stream, c->d_tabs, c->d_tabs + 65536);
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(e, "table fill");
@@ -328,8 +336,11 @@ extern "C" void lchd_ctx_destroy(lchd_ctx* c) {
     (void)hipFree(c->d_status);
     (void)hipFree(c->d_points);
     (void)hipFree(c->d_tabs);
-    (void)hipFree(c->d_partials);
+    (void)hipFree(c->d_done);
     (void)hipFree(c->d_io);
+    (void)hipFree(c->d_shard);
+    (void)hipFree(c->d_bad);
+    if (c->h_counts) (void)hipHostFree(c->h_counts);
     if (c->h_io) (void)hipHostFree(c->h_io);
     if (c->h_status) (void)hipHostFree(c->h_status);
     for (auto& ev : c->ev)
@@ -605,6 +616,7 @@ static int status_to_rc(uint32_t f, Driver drv) {
 static int begin_pass(lchd_ctx* c) {
     if (c->status_dirty) {
         HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(DeviceStatus), c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_done, 0, sizeof(DoneState), c->stream));
         c->status_dirty = false;
     }
     HostStatus* h = c->h_status;
@@ -763,7 +775,7 @@ static void fill_sweep_args(lchd_ctx* c, SweepArgs& sw) {
     sw.seq = c->seq;
     sw.sqrt_tab = c->d_tabs;
     sw.rsqrt_tab = c->d_tabs + 65536;
-    sw.partials = c->d_partials;
+    sw.done = c->d_done;
 }
 
 // Everything of one from_primitives pass; no host synchronisation (the workspace only grows between passes).
@@ -896,8 +908,8 @@ extern "C" int lchd_ctx_finish(lchd_ctx* c) {
         } else {
             c->shrink_votes = 0;
         }
-        if (c->h_cfg.n_categories <= 16)  // who swept the pairs this time is the hint for the next pass of this configuration
-            c->sweep_hint = (2 * c->h_status->n_small >= (unsigned long long)P.n_pairs) ? 1 : 2;
+        if (c->h_cfg.n_categories <= 16 && c->h_status->n_small != ~0ull)  // who swept the pairs this time is the hint for the next
+            c->sweep_hint = (2 * c->h_status->n_small >= (unsigned long long)P.n_pairs) ? 1 : 2;  // pass of this configuration
         c->last = P.sw;
         c->last_valid = true;
         return status_to_rc(f, DRV_PRIMS);
@@ -1179,53 +1191,261 @@ static int grow_io(lchd_ctx* c, size_t total) {
     return LCHD_OK;
 }
 
-extern "C" int lchd_from_primitives(lchd_ctx* c, const lchd_config* cfg, const double* xyz_a, const int32_t* cat_a,
-                                    const int32_t* tag_a, int64_t n_a, const double* xyz_b, const int32_t* cat_b,
-                                    const int32_t* tag_b, int64_t n_b, const int64_t* anchors, const int32_t* wf_index,
-                                    int64_t n_pairs, double thr, double* out) {
-    if (!c) return fail(LCHD_EVALUE, "null context");
+// One host-pointer from_primitives call on one context, split so that a device group can have every device's pass in flight
+// at the same time.  `subset` (or nullptr = all pairs) lists the positions in anchors / wf_index / out this context scores.
+struct HostCall {
+    lchd_cloud a, b;  // point into the context's device I/O block; referenced by the pending pass until it is finished
+    size_t o_out = 0;
+    bool direct = false;
+    int64_t n = 0;
+    bool enqueued = false;
+};
+static int host_call_enqueue(lchd_ctx* c, const lchd_config* cfg, const double* xyz_a, const int32_t* cat_a, const int32_t* tag_a, int64_t n_a,
+                             const double* xyz_b, const int32_t* cat_b, const int32_t* tag_b, int64_t n_b, const int64_t* anchors,
+                             const int32_t* wf_index, const int64_t* subset, int64_t n, double thr, HostCall& hc) {
+    hc.n = n;
+    hc.enqueued = false;
     if (c->pend.active) return fail(LCHD_EVALUE, "an asynchronous call has not been finished (lchd_ctx_finish)");
     CTX_GUARD(c);
     if (int rc = lchd_ctx_set_config(c, cfg)) return rc;
-    if (int rc = check_wf_index(cfg, wf_index, n_pairs)) return rc;
-    if (n_pairs == 0) return LCHD_OK;
-    if (n_a < 0 || n_b < 0 || n_a > ((int64_t)1 << 30) || n_b > ((int64_t)1 << 30)) return fail(LCHD_EUNSUPPORTED, "structure size out of range");
+    if (n == 0) return LCHD_OK;
     // Everything a call sends to the device travels as ONE block through pinned staging and ONE asynchronous copy; the block
     // and its staging twin belong to the context and only ever grow (the reference clones its arguments per call as well,
     // primitive_atom.rs:5, but a device allocation costs far more than a Vec).
-    lchd_cloud a, b;
-    size_t o_anchors = 0, o_wf = 0, o_out = 0, in_bytes = 0, total = 0;
+    size_t o_anchors = 0, o_wf = 0, in_bytes = 0, total = 0;
     for (int pass = 0; pass < 2; ++pass) {
         size_t off = 0;
         char* hb = pass ? c->h_io : nullptr;
-        if (int rc = stage_cloud(xyz_a, cat_a, tag_a, n_a, hb, c->d_io, off, a)) return rc;
-        if (int rc = stage_cloud(xyz_b, cat_b, tag_b, n_b, hb, c->d_io, off, b)) return rc;
+        if (int rc = stage_cloud(xyz_a, cat_a, tag_a, n_a, hb, c->d_io, off, hc.a)) return rc;
+        if (int rc = stage_cloud(xyz_b, cat_b, tag_b, n_b, hb, c->d_io, off, hc.b)) return rc;
         auto take = [&](size_t bytes) { off = (off + 255) & ~size_t(255); const size_t o = off; off += bytes; return o; };
-        o_anchors = take(sizeof(int64_t) * 2 * (size_t)n_pairs);
-        o_wf = take(wf_index ? sizeof(int32_t) * (size_t)n_pairs : 0);
+        o_anchors = take(sizeof(int64_t) * 2 * (size_t)n);
+        o_wf = take(wf_index ? sizeof(int32_t) * (size_t)n : 0);
         in_bytes = off;
-        o_out = take(sizeof(double) * (size_t)n_pairs);
+        hc.o_out = take(sizeof(double) * (size_t)n);
         total = off;
         if (pass == 0)
             if (int rc = grow_io(c, total)) return rc;
     }
-    memcpy(c->h_io + o_anchors, anchors, sizeof(int64_t) * 2 * (size_t)n_pairs);
-    if (wf_index) memcpy(c->h_io + o_wf, wf_index, sizeof(int32_t) * (size_t)n_pairs);
+    int64_t* ha = reinterpret_cast<int64_t*>(c->h_io + o_anchors);
+    int32_t* hw = reinterpret_cast<int32_t*>(c->h_io + o_wf);
+    if (!subset) {
+        memcpy(ha, anchors, sizeof(int64_t) * 2 * (size_t)n);
+        if (wf_index) memcpy(hw, wf_index, sizeof(int32_t) * (size_t)n);
+    } else {
+        for (int64_t k = 0; k < n; ++k) {
+            ha[2 * k] = anchors[2 * subset[k]];
+            ha[2 * k + 1] = anchors[2 * subset[k] + 1];
+            if (wf_index) hw[k] = wf_index[subset[k]];
+        }
+    }
     HIP_TRY(hipMemcpyAsync(c->d_io, c->h_io, in_bytes, hipMemcpyHostToDevice, c->stream));
     const int64_t* d_anchors = reinterpret_cast<const int64_t*>(c->d_io + o_anchors);
     const int32_t* d_wf = wf_index ? reinterpret_cast<const int32_t*>(c->d_io + o_wf) : nullptr;
-    const bool direct = n_pairs <= kDirectOutPairs;
-    double* d_out = reinterpret_cast<double*>((direct ? c->h_io : c->d_io) + o_out);
-    int rc = lchd_from_primitives_dev(c, &a, &b, d_anchors, d_wf, n_pairs, thr, d_out);
-    if (!rc && !direct) {
-        hipError_t e = hipMemcpyAsync(c->h_io + o_out, d_out, sizeof(double) * (size_t)n_pairs, hipMemcpyDeviceToHost, c->stream);
+    hc.direct = n <= kDirectOutPairs;
+    double* d_out = reinterpret_cast<double*>((hc.direct ? c->h_io : c->d_io) + hc.o_out);
+    if (int rc = lchd_from_primitives_dev_async(c, &hc.a, &hc.b, d_anchors, d_wf, n, thr, d_out)) return rc;
+    hc.enqueued = true;
+    return LCHD_OK;
+}
+static int host_call_finish(lchd_ctx* c, HostCall& hc, const int64_t* subset, double* out) {
+    if (!hc.enqueued) return LCHD_OK;
+    hc.enqueued = false;
+    CTX_GUARD(c);
+    int rc = lchd_ctx_finish(c);
+    if (!rc && !hc.direct) {
+        hipError_t e = hipMemcpyAsync(c->h_io + hc.o_out, c->d_io + hc.o_out, sizeof(double) * (size_t)hc.n, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) rc = fail(LCHD_EDEVICE, "HIP error %d in D2H scores", (int)e);
     }
-    if (!rc) memcpy(out, c->h_io + o_out, sizeof(double) * (size_t)n_pairs);
+    if (!rc) {
+        const double* h = reinterpret_cast<const double*>(c->h_io + hc.o_out);
+        if (!subset) memcpy(out, h, sizeof(double) * (size_t)hc.n);
+        else for (int64_t k = 0; k < hc.n; ++k) out[subset[k]] = h[k];
+    }
     c->last_valid = false;  // the anchors of this call live in the I/O block, which the next call overwrites
-    c->pend.a = c->pend.b = nullptr;  // the stack clouds are gone
+    c->pend.a = c->pend.b = nullptr;  // the clouds of the call are gone
     return rc;
+}
+
+extern "C" int lchd_from_primitives(lchd_ctx* c, const lchd_config* cfg, const double* xyz_a, const int32_t* cat_a,
+                                    const int32_t* tag_a, int64_t n_a, const double* xyz_b, const int32_t* cat_b,
+                                    const int32_t* tag_b, int64_t n_b, const int64_t* anchors, const int32_t* wf_index,
+                                    int64_t n_pairs, double thr, double* out) {
+    if (!c || !cfg) return fail(LCHD_EVALUE, "null context / configuration");
+    if (int rc = check_wf_index(cfg, wf_index, n_pairs)) return rc;
+    if (n_a < 0 || n_b < 0 || n_a > ((int64_t)1 << 30) || n_b > ((int64_t)1 << 30)) return fail(LCHD_EUNSUPPORTED, "structure size out of range");
+    HostCall hc;
+    if (int rc = host_call_enqueue(c, cfg, xyz_a, cat_a, tag_a, n_a, xyz_b, cat_b, tag_b, n_b, anchors, wf_index, nullptr, n_pairs, thr, hc)) return rc;
+    return host_call_finish(c, hc, nullptr, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sharding of an anchor-pair list by side-A anchor: the rule of lchd_kernels.hip (k_shard_plan), on the host
+// ------------------------------------------------------------------------------------------------
+static void shard_rule_host(const int64_t* anchors, int64_t n_pairs, int64_t n_atoms_a, int world, std::vector<uint16_t>& rank_of_bin) {
+    std::vector<uint64_t> hist(kShardBins, 0);
+    auto bin_of = [&](int64_t a) { a = a < 0 ? 0 : (a >= n_atoms_a ? n_atoms_a - 1 : a); return (int)((a * kShardBins) / n_atoms_a); };
+    for (int64_t p = 0; p < n_pairs; ++p) ++hist[bin_of(anchors[2 * p])];
+    rank_of_bin.assign(kShardBins, 0);
+    uint64_t pre = 0;
+    for (int b = 0; b < kShardBins; ++b) {
+        const uint64_t r = n_pairs > 0 ? (pre * (uint64_t)world) / (uint64_t)n_pairs : 0;
+        rank_of_bin[b] = (uint16_t)std::min<uint64_t>(r, (uint64_t)world - 1);
+        pre += hist[b];
+    }
+}
+
+struct lchd_group {
+    std::vector<lchd_ctx*> ctx;
+    std::vector<int64_t> last_counts;
+};
+
+extern "C" int lchd_group_create(const int32_t* devices, int32_t n_devices, lchd_group** out) {
+    if (!devices || !out || n_devices < 1 || n_devices > kShardMaxWorld) return fail(LCHD_EVALUE, "a device group needs 1..%d devices", kShardMaxWorld);
+    *out = nullptr;
+    lchd_group* g = new lchd_group();
+    for (int k = 0; k < n_devices; ++k) {
+        lchd_ctx* c = nullptr;
+        if (int rc = lchd_ctx_create(devices[k], &c)) { lchd_group_destroy(g); return rc; }
+        g->ctx.push_back(c);
+    }
+    g->last_counts.assign((size_t)n_devices, 0);
+    *out = g;
+    return LCHD_OK;
+}
+extern "C" void lchd_group_destroy(lchd_group* g) {
+    if (!g) return;
+    for (lchd_ctx* c : g->ctx) lchd_ctx_destroy(c);
+    delete g;
+}
+extern "C" int32_t lchd_group_size(const lchd_group* g) { return g ? (int32_t)g->ctx.size() : 0; }
+extern "C" int lchd_group_last_counts(const lchd_group* g, int64_t* counts_out) {
+    if (!g || !counts_out) return fail(LCHD_EVALUE, "null argument");
+    for (size_t k = 0; k < g->ctx.size(); ++k) counts_out[k] = g->last_counts[k];
+    return LCHD_OK;
+}
+
+extern "C" int lchd_group_from_primitives(lchd_group* g, const lchd_config* cfg, const double* xyz_a, const int32_t* cat_a,
+                                          const int32_t* tag_a, int64_t n_a, const double* xyz_b, const int32_t* cat_b,
+                                          const int32_t* tag_b, int64_t n_b, const int64_t* anchors, const int32_t* wf_index,
+                                          int64_t n_pairs, double thr, double* out) {
+    if (!g || !cfg || g->ctx.empty()) return fail(LCHD_EVALUE, "null group / configuration");
+    if (int rc = check_wf_index(cfg, wf_index, n_pairs)) return rc;
+    if (n_a < 0 || n_b < 0 || n_a > ((int64_t)1 << 30) || n_b > ((int64_t)1 << 30)) return fail(LCHD_EUNSUPPORTED, "structure size out of range");
+    const int world = (int)g->ctx.size();
+    std::fill(g->last_counts.begin(), g->last_counts.end(), 0);
+    if (n_pairs <= 0) {
+        for (lchd_ctx* c : g->ctx)
+            if (int rc = lchd_ctx_set_config(c, cfg)) return rc;  // the reference validates its arguments even for an empty list
+        return LCHD_OK;
+    }
+    // the pair list, binned by side-A anchor: device r gets the positions subset[r]
+    std::vector<std::vector<int64_t>> subset((size_t)world);
+    if (world == 1 || n_a <= 0) {
+        subset[0].resize((size_t)n_pairs);
+        for (int64_t p = 0; p < n_pairs; ++p) subset[0][(size_t)p] = p;
+    } else {
+        std::vector<uint16_t> rob;
+        shard_rule_host(anchors, n_pairs, n_a, world, rob);
+        for (int r = 0; r < world; ++r) subset[(size_t)r].reserve((size_t)(n_pairs / world + n_pairs / (4 * world) + 16));
+        for (int64_t p = 0; p < n_pairs; ++p) {
+            int64_t a = anchors[2 * p];
+            a = a < 0 ? 0 : (a >= n_a ? n_a - 1 : a);
+            subset[rob[(size_t)((a * kShardBins) / n_a)]].push_back(p);
+        }
+    }
+    // enqueue every device's pass (asynchronous), then collect: the devices work concurrently
+    std::vector<HostCall> calls((size_t)world);
+    int first_rc = LCHD_OK;
+    char first_msg[sizeof g_err] = "";
+    auto note = [&](int rc) {
+        if (rc && !first_rc) { first_rc = rc; memcpy(first_msg, g_err, sizeof g_err); }
+    };
+    for (int r = 0; r < world; ++r) {
+        g->last_counts[(size_t)r] = (int64_t)subset[(size_t)r].size();
+        note(host_call_enqueue(g->ctx[(size_t)r], cfg, xyz_a, cat_a, tag_a, n_a, xyz_b, cat_b, tag_b, n_b, anchors, wf_index,
+                               subset[(size_t)r].data(), (int64_t)subset[(size_t)r].size(), thr, calls[(size_t)r]));
+    }
+    for (int r = 0; r < world; ++r) note(host_call_finish(g->ctx[(size_t)r], calls[(size_t)r], subset[(size_t)r].data(), out));
+    if (first_rc) memcpy(g_err, first_msg, sizeof g_err);
+    return first_rc;
+}
+
+// ---- one process per GPU: the same partition on the device ------------------------------------------------------------
+static int ensure_shard_state(lchd_ctx* c) {
+    if (c->d_shard) return LCHD_OK;
+    HIP_TRY(hipMalloc(&c->d_shard, sizeof(ShardState)));
+    hipError_t e = hipMemset(c->d_shard, 0, sizeof(ShardState));
+    if (e == hipSuccess) e = hipHostMalloc(&c->h_counts, sizeof(int64_t) * kShardMaxWorld);
+    if (e == hipSuccess) e = hipMalloc(&c->d_bad, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(c->d_bad, 0, sizeof(uint32_t));
+    if (e != hipSuccess) {
+        (void)hipFree(c->d_shard); c->d_shard = nullptr;
+        if (c->h_counts) { (void)hipHostFree(c->h_counts); c->h_counts = nullptr; }
+        (void)hipFree(c->d_bad); c->d_bad = nullptr;
+        return fail(LCHD_EDEVICE, "HIP error %d (%s) while allocating the sharding state", (int)e, hipGetErrorName(e));
+    }
+    return LCHD_OK;
+}
+extern "C" int lchd_shard_plan_dev(lchd_ctx* c, const int64_t* d_anchors, int64_t n_pairs, int64_t n_atoms_a, int32_t world, int64_t* counts_out) {
+    if (!c || !counts_out) return fail(LCHD_EVALUE, "null argument");
+    if (world < 1 || world > kShardMaxWorld) return fail(LCHD_EVALUE, "world size %d outside [1, %d]", world, kShardMaxWorld);
+    if (n_pairs < 0 || n_atoms_a < 1) return fail(LCHD_EVALUE, "bad pair / atom count");
+    for (int r = 0; r < world; ++r) counts_out[r] = 0;
+    c->shard_world = 0;
+    if (n_pairs == 0) { c->shard_world = world; c->shard_pairs = 0; c->shard_atoms = n_atoms_a; return LCHD_OK; }
+    if (!d_anchors) return fail(LCHD_EVALUE, "null anchor pointer");
+    CTX_GUARD(c);
+    if (int rc = ensure_shard_state(c)) return rc;
+    launch_shard_plan(c->stream, d_anchors, n_pairs, n_atoms_a, world, c->d_shard, c->h_counts);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int64_t total = 0;
+    for (int r = 0; r < world; ++r) { counts_out[r] = c->h_counts[r]; total += counts_out[r]; }
+    if (total != n_pairs) return fail(LCHD_EDEVICE, "the shard plan accounts for %lld of %lld pairs", (long long)total, (long long)n_pairs);
+    c->shard_world = world; c->shard_pairs = n_pairs; c->shard_atoms = n_atoms_a;
+    return LCHD_OK;
+}
+extern "C" int lchd_shard_select_dev(lchd_ctx* c, const int64_t* d_anchors, int64_t n_pairs, int64_t n_atoms_a, int32_t rank,
+                                     int64_t* d_sel_anchors, int64_t* d_sel_index) {
+    if (!c) return fail(LCHD_EVALUE, "null context");
+    if (c->shard_world < 1 || n_pairs != c->shard_pairs || n_atoms_a != c->shard_atoms)
+        return fail(LCHD_EVALUE, "lchd_shard_plan_dev has not been called for this pair list");
+    if (rank < 0 || rank >= c->shard_world) return fail(LCHD_EVALUE, "rank %d outside the planned world of %d", rank, c->shard_world);
+    if (n_pairs == 0) return LCHD_OK;
+    if (!d_anchors || !d_sel_anchors || !d_sel_index) return fail(LCHD_EVALUE, "null pointer");
+    CTX_GUARD(c);
+    launch_shard_select(c->stream, d_anchors, n_pairs, n_atoms_a, rank, c->d_shard, d_sel_anchors, d_sel_index);
+    HIP_TRY(hipGetLastError());
+    return LCHD_OK;
+}
+extern "C" int lchd_unshard_scores_dev(lchd_ctx* c, const double* d_gathered, const int64_t* counts, int32_t world, int64_t stride,
+                                       double* d_out, int64_t n_pairs) {
+    if (!c || !counts) return fail(LCHD_EVALUE, "null argument");
+    if (world < 1 || world > kShardMaxWorld) return fail(LCHD_EVALUE, "world size %d outside [1, %d]", world, kShardMaxWorld);
+    ShardCounts sc{};
+    int64_t total = 0;
+    for (int r = 0; r < world; ++r) {
+        if (counts[r] < 0 || counts[r] > stride) return fail(LCHD_EVALUE, "rank %d holds %lld scores in a slot of %lld", r, (long long)counts[r], (long long)stride);
+        sc.n[r] = counts[r];
+        total += counts[r];
+    }
+    if (total != n_pairs) return fail(LCHD_EVALUE, "the ranks hold %lld scores for %lld pairs", (long long)total, (long long)n_pairs);
+    if (n_pairs == 0) return LCHD_OK;
+    if (!d_gathered || !d_out) return fail(LCHD_EVALUE, "null pointer");
+    CTX_GUARD(c);
+    if (int rc = ensure_shard_state(c)) return rc;
+    launch_unshard_scores(c->stream, d_gathered, sc, world, stride, d_out, n_pairs, c->d_bad);
+    HIP_TRY(hipGetLastError());
+    uint32_t bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, c->d_bad, sizeof bad, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (bad) {
+        (void)hipMemset(c->d_bad, 0, sizeof(uint32_t));
+        return fail(LCHD_EVALUE, "a gathered pair position lies outside [0, %lld)", (long long)n_pairs);
+    }
+    return LCHD_OK;
 }
 
 // Shared tail of from_anchors / from_dmxs / from_coords: environments are already sorted in `ea`/`eb`

@@ -9,7 +9,7 @@ namespace lchd {
 constexpr int kMaxCategories = 255;   // categories travel as u8 on the device
 constexpr int kSweepEPL = 6;          // merged events per lane per tile in the sweep kernel
 constexpr int kSweepTile = 64 * kSweepEPL;
-constexpr int kMetaPartials = 4096;   // workgroups of k_pair_meta (one partial count each)
+constexpr int kMetaPartials = 4096;   // most workgroups of k_pair_meta
 constexpr uint64_t kPadKey = ~0ull;   // sorts after every valid (non-negative, non-NaN) f64 bit pattern
 
 // status word written by kernels (device memory, zeroed per call)
@@ -23,15 +23,14 @@ enum : uint32_t {
     ST_BAD_DISTANCE = 1u << 6,    // negative / NaN distance in a matrix row    (reference: ValueError / panic)
     ST_BAD_WF = 1u << 7,          // weight-function index outside the table
 };
-// Device-resident status of a pass.  Invariant between passes: flags == max_env == meta_done == 0 -- the last workgroup of
+// Device-resident status of a pass.  Invariant between passes: flags == max_env == 0 -- the last workgroup of
 // k_pair_meta copies the words the host needs into the host-mapped HostStatus and resets them, so a pass needs neither a
 // memset in front of it nor a device-to-host copy behind it.  n_unique / n_small are plain-stored by every pass.
 struct DeviceStatus {
     uint32_t flags;
     uint32_t max_env;        // largest environment seen (for the overflow retry)
     uint32_t n_unique[2];    // unique anchors per side
-    uint32_t meta_done;      // workgroups of k_pair_meta that have finished (the last one folds the partial counts)
-    uint32_t pad;
+    uint32_t pad[2];
     unsigned long long n_small;     // pairs with at most kDuoTile merged events (k_pair_meta): who sweeps them is decided on the device
 };
 // Host-mapped (pinned, device-visible) mirror: written with plain stores only -- the snapshot by one thread of k_pair_meta,
@@ -57,6 +56,7 @@ struct Tuning {
     bool force_generic = false;     // LCHD_FORCE_GENERIC: MODE_GEN even for Hellinger-2
     bool force_bigenv = false;      // LCHD_FORCE_BIGENV: the !LDSTAB sweep instantiations
     bool no_sweep_hint = false;     // LCHD_NO_SWEEP_HINT: always launch all three sweep kernels and let the device decide
+    bool no_inline_meta = false;    // LCHD_NO_INLINE_META: small calls also run k_pair_meta + the regular sweep kernels
     bool no_count8 = false;         // LCHD_NO_COUNT8: never the 8-bit-count sweep
     bool no_tables = false;         // LCHD_NO_SD_TABLES: generic distances without the per-launch power / log tables
     int force_cmax = 0;             // LCHD_FORCE_CMAX: at least this many category slots
@@ -173,6 +173,12 @@ bool launch_env_rows(hipStream_t s, int cap, const DevConfig* cfg, const CloudVi
                      int64_t n_rows, int64_t row_len, double image_bound /* coords: >= largest squared distance, or 0 */, EnvStore env,
                      DeviceStatus* st);
 
+// "last workgroup" detection + hand-over through memory-side atomics (lchd_kernels.hip: last_workgroup_done)
+struct DoneState {
+    uint32_t ctr[65 * 32];
+    uint32_t acc_max[64 * 32];
+    unsigned long long acc_sum[64 * 16];
+};
 struct SweepArgs {
     const DevConfig* cfg;
     EnvStore env_a, env_b;
@@ -187,7 +193,7 @@ struct SweepArgs {
     const double* sqrt_tab;   // [65536] sqrt(k), context-owned
     const double* rsqrt_tab;  // [65536] 1/sqrt(k)
     int4* meta;               // [P] workspace: per-pair records written by k_pair_meta, read by the sweep kernels
-    uint32_t* partials;       // [kMetaPartials] context-owned scratch of k_pair_meta
+    DoneState* done;          // context-owned, zero between kernels: "last workgroup" counters and accumulators
     HostStatus* hst;          // host-mapped mirror (snapshot by k_pair_meta, error words by the sweep kernels)
     uint32_t seq;             // pass counter echoed into HostStatus::snapshot_seq
     int32_t duo_enabled;      // set by launch_sweep: k_sweep_duo was launched too and sweeps the small pairs when they are the majority
@@ -212,6 +218,26 @@ void launch_frames_centroids(hipStream_t s, const float* raw, int64_t n_src, con
 int centroid_tile_span();
 int bbox_parts_capacity();
 void launch_fill_sqrt_tables(hipStream_t s, double* sqrt_tab, double* rsqrt_tab);  // 65536 entries each
+
+// Multi-GPU sharding of an anchor-pair list by side-A anchor (see lchd_kernels.hip).  ShardState lives in device memory,
+// zero-initialised once; hist / cursor / done are zero again after every plan.
+constexpr int kShardBins = 1024, kShardMaxWorld = 64;
+struct ShardState {
+    uint32_t hist[kShardBins];
+    uint16_t rank_of_bin[kShardBins];
+    int64_t counts[kShardMaxWorld];
+    unsigned long long cursor;
+    DoneState done;
+};
+struct ShardCounts {
+    int64_t n[kShardMaxWorld];
+};
+void launch_shard_plan(hipStream_t s, const int64_t* anchors, int64_t n_pairs, int64_t n_atoms_a, int world, ShardState* st,
+                       int64_t* counts_host /* host-mapped [world] */);
+void launch_shard_select(hipStream_t s, const int64_t* anchors, int64_t n_pairs, int64_t n_atoms_a, int rank, ShardState* st,
+                         int64_t* sel_anchors, int64_t* sel_index);
+void launch_unshard_scores(hipStream_t s, const double* gathered, const ShardCounts& counts, int world, int64_t stride, double* out,
+                           int64_t n_pairs, uint32_t* bad);
 void launch_env_points(hipStream_t s, const SweepArgs& a, unsigned long long* out);
 
 }  // namespace lchd

@@ -267,14 +267,28 @@ __device__ __forceinline__ void cell_build_wg(const CloudView& c, const GridView
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int k = tid; k < cps; k += NT) hist[k] = 0u;
     __syncthreads();
-    for (int a = tid; a < size; a += NT) {
-        const int64_t i = base + a;
-        const int cx = cell_coord(c.x[i], g.min[0], g.inv[0], g.dim[0]);
-        const int cy = cell_coord(c.y[i], g.min[1], g.inv[1], g.dim[1]);
-        const int cz = cell_coord(c.z[i], g.min[2], g.inv[2], g.dim[2]);
-        const int cell = (cz * g.dim[1] + cy) * g.dim[0] + cx;
-        cid[a] = (uint16_t)cell;
-        rank_[a] = (uint16_t)atomicAdd(&hist[cell], 1u);
+    // (four atoms per thread and step: their coordinate loads are in flight together -- a single workgroup walking a
+    // structure of ten thousand atoms is bound by memory latency, not by bandwidth)
+    constexpr int U = 4;
+    for (int a0 = tid; a0 < size; a0 += U * NT) {
+        double X[U], Y[U], Z[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = base + min(a0 + u * NT, size - 1);
+            X[u] = c.x[i]; Y[u] = c.y[i]; Z[u] = c.z[i];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int a = a0 + u * NT;
+            if (a < size) {
+                const int cx = cell_coord(X[u], g.min[0], g.inv[0], g.dim[0]);
+                const int cy = cell_coord(Y[u], g.min[1], g.inv[1], g.dim[1]);
+                const int cz = cell_coord(Z[u], g.min[2], g.inv[2], g.dim[2]);
+                const int cell = (cz * g.dim[1] + cy) * g.dim[0] + cx;
+                cid[a] = (uint16_t)cell;
+                rank_[a] = (uint16_t)atomicAdd(&hist[cell], 1u);
+            }
+        }
     }
     __syncthreads();
     // exclusive scan of hist[0 .. cps): thread t owns the consecutive entries [t * per, (t + 1) * per)
@@ -294,17 +308,26 @@ __device__ __forceinline__ void cell_build_wg(const CloudView& c, const GridView
     }
     if (write_end && tid == NT - 1) cell_start[cell_base + cps] = (uint32_t)(base + size);
     __syncthreads();
-    for (int a = tid; a < size; a += NT) {
-        const int64_t i = base + a;
-        const uint32_t pos = (uint32_t)base + hist[cid[a]] + rank_[a];
-        CellRec r;
-        r.x = c.x[i];
-        r.y = c.y[i];
-        r.z = c.z[i];
-        r.tag = (uint32_t)c.tag[i];
-        r.cat = c.cat[i];
-        rec[pos] = r;
-        pos_of[i] = pos;
+    for (int a0 = tid; a0 < size; a0 += U * NT) {
+        CellRec r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = base + min(a0 + u * NT, size - 1);
+            r[u].x = c.x[i];
+            r[u].y = c.y[i];
+            r[u].z = c.z[i];
+            r[u].tag = (uint32_t)c.tag[i];
+            r[u].cat = c.cat[i];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int a = a0 + u * NT;
+            if (a < size) {
+                const uint32_t pos = (uint32_t)base + hist[cid[a]] + rank_[a];
+                rec[pos] = r[u];
+                pos_of[base + a] = pos;
+            }
+        }
     }
 }
 
@@ -354,10 +377,17 @@ __global__ __launch_bounds__(1024) void k_prologue_fused(const int64_t* __restri
     for (int w = tid; w <= kBitWordsMax; w += 1024) bits[w] = 0u;
     cell_build_wg<1024>(c, P.g, cps, 0, n, 0, true, P.rec, P.pos_of, P.cell_start, smem_pf, wsum);  // (its barriers order the clear above)
     bool bad = false;
-    for (int64_t p = tid; p < n_pairs; p += 1024) {
-        const int64_t a = anchors[2 * p + side];
-        if (a < 0 || a >= n) bad = true;
-        else atomicOr(&bits[a >> 5], 1u << (a & 31));
+    for (int64_t p0 = tid; p0 < n_pairs; p0 += 4 * 1024) {
+        int64_t av[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) av[u] = anchors[2 * min(p0 + u * 1024, n_pairs - 1) + side];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (p0 + u * 1024 < n_pairs) {
+                const int64_t a = av[u];
+                if (a < 0 || a >= n) bad = true;
+                else atomicOr(&bits[a >> 5], 1u << (a & 31));
+            }
     }
     if (__ballot(bad) && (tid & 63) == 0) atomicOr(&st->flags, ST_BAD_ANCHOR);
     __syncthreads();
@@ -1212,7 +1242,11 @@ enum { F_KEY = 0, F_FAST = 1, F_ANY = 2 };
 #ifndef LCHD_SWEEP_MINW
 #define LCHD_SWEEP_MINW 2
 #endif
+#ifndef LCHD_EPL_BIG
+#define LCHD_EPL_BIG 8   // merged events per lane per tile of the many-slot Hellinger-2 sweep (k_sweep<20..32>): tiles of 512
+#endif
 constexpr int kDuoTileFwd = 224;  // = kDuoTile (k_sweep_duo, below)
+constexpr int64_t kInlineMetaPairs = 4096;   // calls of at most this many pairs: the sweep works out the pair records itself (one launch)
 // H^2 = 1 - D / sqrt(N_a N_b) carries an absolute rounding error of a few 1e-16 (D is rebuilt from the exact integer counts at
 // every lane chunk, so nothing drifts); sqrt() turns that into an error of ~3e-16 / (2 sqrt(H^2)) in H.  Below this bound the
 // literal difference-of-roots form is evaluated instead (exactly 0 for identical environments); at the bound the cancellation
@@ -1225,6 +1259,55 @@ constexpr int kSweepWaves = LCHD_SWEEP_WAVES;  // anchor pairs (wavefronts) per 
 // A sweep kernel reports a (rare) condition: plain store of 1 into the condition's word of the host-mapped mirror (every
 // writer stores the same value; no atomics on host memory, no device-to-host copy afterwards).
 __device__ __forceinline__ void sweep_report(HostStatus* h, uint32_t bit) { h->sweep_flags[__builtin_ctz(bit)] = 1u; }
+
+// "Which workgroup finishes last, and what did all of them add up to?" -- without a fence.  An agent-scope release fence on
+// this part writes the XCD's whole L2 back (the L2s of the eight XCDs are not coherent with each other), and a kernel that
+// has just written 16 MB of pair records pays that per workgroup: 3 900 fences turned an 18 us kernel into a 137 us one.
+// Device-scope atomics are performed at the memory side and are coherent by themselves, so everything the workgroups
+// hand over travels IN atomics: up to 64 accumulators / counters on separate cache lines (thousands of atomics on one
+// word would cost ~11 ns each), a workgroup's counter increment carries a data dependency on the values its accumulator
+// atomics RETURNED (so they have been performed), and the workgroup that completes its counter bumps the top-level one.
+// Called by ONE thread per workgroup; returns true in exactly one workgroup, which then collects the accumulators with
+// atomic exchanges (resetting them).  Everything is left at zero.
+constexpr int kDoneStride = 32;  // u32 per slot: 128 bytes apart
+static_assert(sizeof(DoneState) == (65 + 64 + 64) * kDoneStride * 4, "DoneState layout (lchd_device.h)");
+__device__ __forceinline__ bool last_workgroup_done(DoneState* d, unsigned long long add_sum, uint32_t add_max) {
+    const uint32_t n = gridDim.x, G = n < 64u ? n : 64u, g = blockIdx.x % G;
+    const uint32_t gs = n / G + (g < n % G ? 1u : 0u);
+    const unsigned long long r0 = atomicAdd(&d->acc_sum[g * (kDoneStride / 2)], add_sum);
+    const uint32_t r1 = atomicMax(&d->acc_max[g * kDoneStride], add_max);
+    uint32_t dep = (uint32_t)r0 | r1;
+    asm volatile("v_and_b32 %0, 0, %0" : "+v"(dep));  // 0, but only known once both atomics have returned
+    const uint32_t c = atomicAdd(&d->ctr[g * kDoneStride], 1u + dep);
+    if (c != gs - 1u) return false;
+    uint32_t dep2 = atomicExch(&d->ctr[g * kDoneStride], 0u);  // (= gs: every workgroup of the group is through)
+    asm volatile("v_and_b32 %0, 0, %0" : "+v"(dep2));
+    if (atomicAdd(&d->ctr[64 * kDoneStride], 1u + dep2) != G - 1u) return false;
+    atomicExch(&d->ctr[64 * kDoneStride], 0u);
+    return true;
+}
+// by the threads of the LAST workgroup (slot k handled by thread k < 64): the totals, accumulators reset
+__device__ __forceinline__ void collect_done(DoneState* d, int k, unsigned long long& sum, uint32_t& mx) {
+    sum = atomicExch(&d->acc_sum[k * (kDoneStride / 2)], 0ull);
+    mx = atomicExch(&d->acc_max[k * kDoneStride], 0u);
+}
+
+// The end of a pass's record phase, by ONE thread of the last workgroup: what the host wants to know goes into the
+// host-mapped mirror (plain stores), the device status is reset for the next pass.
+__device__ __forceinline__ void publish_status(const SweepArgs& args, unsigned long long n_small, uint32_t biggest_env) {
+    DeviceStatus* st = args.st;
+    HostStatus* h = args.hst;
+    st->n_small = n_small;  // read by the sweep kernels of this pass when the host did not pick them itself
+    const uint32_t over = __hip_atomic_load(&st->max_env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // set by an overflowing environment
+    h->flags = __hip_atomic_load(&st->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    h->max_env = over > biggest_env ? over : biggest_env;
+    h->n_unique[0] = st->n_unique[0];
+    h->n_unique[1] = st->n_unique[1];
+    h->n_small = n_small;
+    h->snapshot_seq = args.seq;
+    st->flags = 0u;
+    st->max_env = 0u;
+}
 
 __device__ __forceinline__ void wave_sync_lds() {
     // LDS operations of one wavefront execute in issue order; this only stops the compiler from moving
@@ -1327,9 +1410,19 @@ __device__ unsigned long long g_sweep_stamps[8];
 #endif
 
 // register budget: 4 waves/SIMD (<= 128 VGPRs) up to 12 category slots, 3 (<= 168) up to 16, 2 beyond
-template <int CMAX, int MODE, int FMODE, bool LDSTAB, bool INDIRECT = false>
+// INLINE_META (small calls: a few thousand pairs, where launches cost more than arithmetic): the kernel works out every
+// pair's record itself instead of reading what k_pair_meta wrote, and its last workgroup publishes the status snapshot --
+// ONE launch does the whole sweep phase.
+template <int CMAX, int MODE, int FMODE, bool LDSTAB, bool INDIRECT = false, bool INLINE_META = false>
 __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 12 ? 4 : (CMAX <= LCHD_SWEEP_W3MAX ? 3 : 2)))) void k_sweep(SweepArgs args) {
-    constexpr int EPL = kSweepEPL, TILE = kSweepTile, WPB = kSweepWaves;
+    static_assert(!(INDIRECT && INLINE_META), "the indirect instantiation reads the records of k_pair_meta");
+    // Merged events per lane per tile.  The per-tile prologue (staging, merge path, scan of the packed counts, state reload)
+    // costs about as many instructions as the events of a 384-event tile themselves, and it grows with the category slots:
+    // the variants with many slots (25 categories at 0.05 atoms/A^3: ~416 events per pair) take tiles of 64 x LCHD_EPL_BIG so
+    // that such a pair is ONE tile instead of a full one plus a nearly empty one.
+    constexpr bool H2_ = (MODE != MODE_GEN);
+    constexpr int EPL = (H2_ && LDSTAB && CMAX > 16) ? LCHD_EPL_BIG : kSweepEPL, TILE = 64 * EPL, WPB = kSweepWaves;
+    static_assert(EPL <= 15, "4-bit chunk-local counters");
     constexpr int NW = CMAX / 4;          // u64 words of 16-bit count fields per side
     constexpr int NH = (CMAX + 15) / 16;  // u64 words of 4-bit histogram fields per side
     constexpr bool H2 = (MODE != MODE_GEN);
@@ -1412,11 +1505,37 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
     const int64_t pstride = (int64_t)gridDim.x * WPB;
     const int64_t total = args.n_pairs;
     int64_t q = (int64_t)blockIdx.x * WPB + wv;
+    int biggest_env = 0;  // INLINE_META: largest environment this wave has met
+    auto record_of = [&](int64_t pp) -> int4 {  // pp wave-uniform
+        if constexpr (INLINE_META) {  // the arithmetic of k_pair_meta
+            int64_t ea = pp, eb = pp;
+            bool ok = true;
+            if (args.anchors) {
+                const int64_t ia_ = args.anchors[2 * pp], ib_ = args.anchors[2 * pp + 1];
+                ok = !(ia_ < 0 || ib_ < 0 || ia_ >= args.n_slot_a || ib_ >= args.n_slot_b);
+                if (ok) { ea = args.slot_a[ia_]; eb = args.slot_b[ib_]; }
+            }
+            int nA_ = 0, nB_ = 0, c0a_ = 0, c0b_ = 0;
+            if (ok) {
+                nA_ = args.env_a.len[ea];
+                nB_ = args.env_b.len[eb];
+                if (nA_ > 0 && nB_ > 0) {
+                    c0a_ = args.env_a.cat[ea * args.env_a.stride];
+                    c0b_ = args.env_b.cat[eb * args.env_b.stride];
+                } else {
+                    nA_ = nB_ = 0;
+                }
+            }
+            return make_int4((int)ea, (int)eb, nA_ | (c0a_ << 24), nB_ | (c0b_ << 24));
+        } else {
+            return args.meta[pp];
+        }
+    };
     // the record lives in four scalar registers; the next one is moved there as soon as its (early) load has returned, so the
     // loop's back edge never waits on vector memory (in particular not on the score store of the pair just finished)
     int mx, my, mz, mw;
     {
-        const int4 m0 = args.meta[q < total ? q : 0];
+        const int4 m0 = record_of(q < total ? q : 0);
         mx = __builtin_amdgcn_readfirstlane(m0.x); my = __builtin_amdgcn_readfirstlane(m0.y);
         mz = __builtin_amdgcn_readfirstlane(m0.z); mw = __builtin_amdgcn_readfirstlane(m0.w);
     }
@@ -1448,7 +1567,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
     for (; INDIRECT ? ok : (q < total);
          INDIRECT ? (void)(ok = advance()) : (void)(q += pstride, mx = nx, my = ny, mz = nz, mw = nw)) {
         const int64_t p = INDIRECT ? p_cur : q;
-        const int4 mn = INDIRECT ? make_int4(0, 0, 0, 0) : args.meta[q + pstride < total ? q + pstride : q];
+        const int4 mn = INDIRECT ? make_int4(0, 0, 0, 0) : record_of(q + pstride < total ? q + pstride : q);
         auto take_next = [&]() {
             if constexpr (!INDIRECT) {
                 nx = __builtin_amdgcn_readfirstlane(mn.x); ny = __builtin_amdgcn_readfirstlane(mn.y);
@@ -1456,6 +1575,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
             }
         };
         const int nA = mz & 0xFFFFFF, nB = mw & 0xFFFFFF;
+        if constexpr (INLINE_META) biggest_env = max(biggest_env, max(nA, nB));
         if (nA <= 0 || nB <= 0) {  // anchor out of range (flagged by k_mark_anchors) or overflow / empty environment (flagged by K1)
             if (lane == 0) args.out[p] = nan("");
             take_next();
@@ -1674,7 +1794,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
             wave_sync_lds();
             STAMP(1);
             // lane l owns merged events [d0, d1); each lane searches the END of its chunk
-            const int epl = (T + 63) >> 6;  // <= EPL (= 6): the 4-bit histogram fields hold up to 15
+            const int epl = (T + 63) >> 6;  // <= EPL (<= 15: the 4-bit histogram fields)
             const int d0 = min(lane * epl, T), d1 = min(d0 + epl, T);
             const int i1 = merge_path(sA, nAt, sB, nBt, d1);
             int i0 = __shfl_up(i1, 1);
@@ -1888,6 +2008,28 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
     if (lane == 0)
         for (int k = 0; k < 8; ++k) atomicAdd(&g_sweep_stamps[k], stamp_acc[k]);
 #endif
+    if constexpr (INLINE_META) {
+        // what k_pair_meta's last workgroup does for the other sweeps: largest environment, status snapshot for the host,
+        // device status reset for the next pass (n_small is not counted here: the host keeps its previous hint)
+        __shared__ int big_s[WPB];
+        __shared__ bool last_s;
+        if (lane == 0) big_s[wv] = biggest_env;
+        __syncthreads();
+        if (tid == 0) {
+            int b = big_s[0];
+#pragma unroll
+            for (int k = 1; k < WPB; ++k) b = max(b, big_s[k]);
+            last_s = last_workgroup_done(args.done, 0ull, (uint32_t)b);
+        }
+        __syncthreads();
+        if (last_s && tid < 64) {
+            unsigned long long v_;
+            uint32_t mx_;
+            collect_done(args.done, tid, v_, mx_);
+            for (int m = 32; m > 0; m >>= 1) mx_ = max(mx_, (uint32_t)__shfl_xor((int)mx_, m));
+            if (tid == 0) publish_status(args, ~0ull, mx_);  // n_small is not counted here: the host keeps its previous hint
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2479,47 +2621,24 @@ __global__ void k_pair_meta(SweepArgs args) {
         n_small += (nA + nB - 2 <= kDuoTileFwd) ? 1 : 0;
     }
     // pairs that fit one 32-lane tile: if they are the majority, k_sweep_duo sweeps them and k_sweep only the rest.  One
-    // partial count per workgroup (thousands of atomics on one word would cost more than this kernel); the workgroup that
-    // finishes LAST folds them, publishes what the host wants to know into the host-mapped mirror and resets the device
-    // status for the next pass -- no separate summing kernel, no memset before a pass, no copy after it.
+    // partial count per workgroup; the workgroup that finishes LAST folds them, publishes what the host wants to know into
+    // the host-mapped mirror and resets the device status for the next pass -- no separate summing kernel, no memset before
+    // a pass, no copy after it.
     __shared__ int part_s[4], big_s[4];
     __shared__ bool last_s;
     for (int m = 32; m > 0; m >>= 1) { n_small += __shfl_xor(n_small, m); biggest = max(biggest, __shfl_xor(biggest, m)); }
     if ((threadIdx.x & 63) == 0) { part_s[threadIdx.x >> 6] = n_small; big_s[threadIdx.x >> 6] = biggest; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        // largest environment of the pass (an overflowed one reported its size from the environment kernel already): the
-        // host lets its capacity hint decay with it
-        atomicMax(&args.st->max_env, (uint32_t)max(max(big_s[0], big_s[1]), max(big_s[2], big_s[3])));
-        __hip_atomic_store(&args.partials[blockIdx.x], (uint32_t)(part_s[0] + part_s[1] + part_s[2] + part_s[3]), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        last_s = atomicAdd(&args.st->meta_done, 1u) == gridDim.x - 1;
-    }
+    if (threadIdx.x == 0)  // (largest environment of the pass: the host lets its capacity hint decay with it)
+        last_s = last_workgroup_done(args.done, (unsigned long long)(part_s[0] + part_s[1] + part_s[2] + part_s[3]),
+                                     (uint32_t)max(max(big_s[0], big_s[1]), max(big_s[2], big_s[3])));
     __syncthreads();
-    if (!last_s) return;
-    __threadfence();
-    __shared__ unsigned long long red[4];
-    unsigned long long v = 0;
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) v += __hip_atomic_load(&args.partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int m = 32; m > 0; m >>= 1) v += shfl_u64(v, (threadIdx.x & 63) ^ m);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        DeviceStatus* st = args.st;
-        const unsigned long long total = red[0] + red[1] + red[2] + red[3];
-        st->n_small = total;  // read by the sweep kernels of this pass when the host did not pick them itself
-        HostStatus* h = args.hst;
-        h->flags = __hip_atomic_load(&st->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        h->max_env = __hip_atomic_load(&st->max_env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        h->n_unique[0] = st->n_unique[0];
-        h->n_unique[1] = st->n_unique[1];
-        h->n_small = total;
-        h->snapshot_seq = args.seq;
-        st->flags = 0u;
-        st->max_env = 0u;
-        st->meta_done = 0u;
-    }
+    if (!last_s || threadIdx.x >= 64) return;
+    unsigned long long v;
+    uint32_t mx;
+    collect_done(args.done, threadIdx.x, v, mx);
+    for (int m = 32; m > 0; m >>= 1) { v += shfl_u64(v, threadIdx.x ^ m); mx = max(mx, (uint32_t)__shfl_xor((int)mx, m)); }
+    if (threadIdx.x == 0) publish_status(args, v, mx);
 }
 
 void launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinger2, bool unit_weights, bool wf_pow, int sweep_hint,
@@ -2528,12 +2647,27 @@ void launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool helling
     SweepArgs a = a_in;
     a.duo_enabled = 0;
     a.forced = 0;
+    if (t.force_generic) hellinger2 = false;  // test hook
+    if (a.n_pairs <= kInlineMetaPairs && !t.no_inline_meta && hellinger2 && unit_weights && n_categories <= 32 && !t.force_wide &&
+        a.env_a.cdf_keys && a.env_b.cdf_keys && a.env_a.stride <= kSqrtTab && a.env_b.stride <= kSqrtTab && !t.force_bigenv) {
+        // small call, default configuration: one launch (records worked out by the sweep itself, one pair per wavefront)
+        const int cm = std::max(n_categories, t.force_cmax);
+        const unsigned g = (unsigned)((a.n_pairs + kSweepWaves - 1) / kSweepWaves);
+        constexpr int NTH = 64 * kSweepWaves;
+        if (cm <= 8) k_sweep<8, MODE_H2U, F_KEY, true, false, true><<<g, NTH, 0, s>>>(a);
+        else if (cm <= 12) k_sweep<12, MODE_H2U, F_KEY, true, false, true><<<g, NTH, 0, s>>>(a);
+        else if (cm <= 16) k_sweep<16, MODE_H2U, F_KEY, true, false, true><<<g, NTH, 0, s>>>(a);
+        else if (cm <= 20) k_sweep<20, MODE_H2U, F_KEY, true, false, true><<<g, NTH, 0, s>>>(a);
+        else if (cm <= 24) k_sweep<24, MODE_H2U, F_KEY, true, false, true><<<g, NTH, 0, s>>>(a);
+        else if (cm <= 28) k_sweep<28, MODE_H2U, F_KEY, true, false, true><<<g, NTH, 0, s>>>(a);
+        else k_sweep<32, MODE_H2U, F_KEY, true, false, true><<<g, NTH, 0, s>>>(a);
+        return;
+    }
     {
         const int64_t nb = (a.n_pairs + 255) / 256;
         const int mgrid = (int)(nb < kMetaPartials ? nb : kMetaPartials);
         k_pair_meta<<<mgrid, 256, 0, s>>>(a);
     }
-    if (t.force_generic) hellinger2 = false;  // test hook
     if (n_categories > 32 || t.force_wide) {
         const int fmode = (a.env_a.cdf_keys && a.env_b.cdf_keys) ? F_KEY : F_ANY;
         if (!hellinger2) launch_sweep_wide<MODE_GEN>(s, n_categories, a.n_pairs, fmode, a);
@@ -2620,6 +2754,126 @@ void launch_env_points(hipStream_t s, const SweepArgs& a, unsigned long long* ou
     if (a.n_pairs > 0) k_env_points<<<1024, 256, 0, s>>>(a, out);
 }
 
+}  // namespace lchd
+
+namespace lchd {
+// ------------------------------------------------------------------------------------------------
+// Multi-GPU sharding of an anchor-pair list (one process per GPU, every rank holds the whole list and both structures).
+// A rank that scores a contiguous slice of RANDOM pairs builds almost every environment of both structures itself; pairs
+// binned by their side-A anchor make every rank build ~1/world of side A's environments.  The rule is a pure function of
+// the list, so every rank computes the same partition without talking to the others:
+//   bin(p)  = floor(a_p * kShardBins / n_atoms_a)                      (a_p = side-A anchor index, clamped into range)
+//   rank(b) = min(world - 1, floor(#pairs in bins < b * world / P))    (the rank in which the bin's first pair falls)
+// k_shard_plan: histogram of the bins (LDS-private per workgroup), the last workgroup turns it into rank(b) and the
+// per-rank pair counts (also stored into host-mapped memory) and zeroes the histogram and the selection cursor again;
+// k_shard_select: this rank's pairs, compacted (order = workgroup arrival, the original positions travel with them);
+// k_unshard_scores: on the gathering rank, score k of rank r goes to its pair's original position.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int shard_bin(int64_t a, int64_t n_atoms_a) {
+    a = a < 0 ? 0 : (a >= n_atoms_a ? n_atoms_a - 1 : a);
+    return (int)((a * kShardBins) / n_atoms_a);
+}
+__global__ __launch_bounds__(1024) void k_shard_plan(const int64_t* __restrict__ anchors, int64_t n_pairs, int64_t n_atoms_a, int world,
+                                                      ShardState* st, int64_t* counts_host) {
+    __shared__ uint32_t h[kShardBins];
+    __shared__ bool last_s;
+    __shared__ uint32_t wsum[16];
+    __shared__ unsigned long long cnt_s[kShardMaxWorld];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    h[tid] = 0u;  // kShardBins == blockDim.x == 1024
+    __syncthreads();
+    for (int64_t p = blockIdx.x * 1024ll + tid; p < n_pairs; p += (int64_t)gridDim.x * 1024)
+        atomicAdd(&h[shard_bin(anchors[2 * p], n_atoms_a)], 1u);
+    __syncthreads();
+    {   // returning form, and the value is consumed: the atomic has been PERFORMED when the wave passes this point
+        uint32_t r = 0;
+        if (h[tid]) r = atomicAdd(&st->hist[tid], h[tid]);
+        asm volatile("" ::"v"(r));
+    }
+    __syncthreads();
+    if (tid == 0) last_s = last_workgroup_done(&st->done, 0ull, 0u);  // (the workgroup's histogram atomics completed before the barrier)
+    __syncthreads();
+    if (!last_s) return;
+    // exclusive scan of the 1024 bins (one per thread), then rank(b) and the per-rank counts
+    const uint32_t v = __hip_atomic_load(&st->hist[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t incl = wave_incl_scan_u32(v);
+    if (lane == 63) wsum[wave] = incl;
+    if (tid < kShardMaxWorld) cnt_s[tid] = 0ull;
+    __syncthreads();
+    unsigned long long pre = incl - v;
+    for (int w = 0; w < wave; ++w) pre += wsum[w];
+    int r = (int)((pre * (unsigned long long)world) / (unsigned long long)n_pairs);
+    r = r < world - 1 ? r : world - 1;
+    st->rank_of_bin[tid] = (uint16_t)r;
+    if (v) atomicAdd(&cnt_s[r], (unsigned long long)v);
+    st->hist[tid] = 0u;
+    __syncthreads();
+    if (tid < world) { st->counts[tid] = (int64_t)cnt_s[tid]; counts_host[tid] = (int64_t)cnt_s[tid]; }
+    if (tid == 0) st->cursor = 0ull;
+}
+__global__ __launch_bounds__(256) void k_shard_select(const int64_t* __restrict__ anchors, int64_t n_pairs, int64_t n_atoms_a, int rank,
+                                                      ShardState* st, int64_t* __restrict__ sel_anchors, int64_t* __restrict__ sel_index) {
+    __shared__ uint32_t wcnt[4];
+    __shared__ unsigned long long base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int PER = 8;  // pairs per thread and round: one cursor atomic per 2048 pairs
+    const uint16_t* __restrict__ rob = st->rank_of_bin;
+    for (int64_t p0 = (int64_t)blockIdx.x * 256 * PER; p0 < n_pairs; p0 += (int64_t)gridDim.x * 256 * PER) {
+        longlong2 ab[PER];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int64_t p = p0 + (int64_t)tid * PER + u;  // a thread owns PER consecutive pairs: original order inside a round
+            if (p < n_pairs) {
+                ab[u] = reinterpret_cast<const longlong2*>(anchors)[p];
+                if (rob[shard_bin(ab[u].x, n_atoms_a)] == (uint16_t)rank) mine |= 1u << u;
+            }
+        }
+        const uint32_t c = (uint32_t)__popc(mine);
+        const uint32_t incl = wave_incl_scan_u32(c);
+        if (lane == 63) wcnt[wave] = incl;
+        __syncthreads();
+        if (tid == 0) base_s = atomicAdd(&st->cursor, (unsigned long long)(wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3]));
+        __syncthreads();
+        unsigned long long o = base_s + incl - c;
+        for (int w = 0; w < wave; ++w) o += wcnt[w];
+#pragma unroll
+        for (int u = 0; u < PER; ++u)
+            if ((mine >> u) & 1u) {
+                reinterpret_cast<longlong2*>(sel_anchors)[o] = ab[u];
+                sel_index[o] = p0 + (int64_t)tid * PER + u;
+                ++o;
+            }
+        __syncthreads();
+    }
+}
+__global__ void k_unshard_scores(const double* __restrict__ gathered, ShardCounts counts, int world, int64_t stride, double* __restrict__ out,
+                                 int64_t n_pairs, uint32_t* bad) {
+    // gathered: [world][2][stride] -- scores, then the original pair positions as int64 bit patterns
+    for (int r = 0; r < world; ++r) {
+        const double* sc = gathered + (int64_t)r * 2 * stride;
+        const int64_t* ix = reinterpret_cast<const int64_t*>(sc + stride);
+        for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < counts.n[r]; k += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t p = ix[k];
+            if (p < 0 || p >= n_pairs) { *bad = 1u; continue; }
+            out[p] = sc[k];
+        }
+    }
+}
+void launch_shard_plan(hipStream_t s, const int64_t* anchors, int64_t n_pairs, int64_t n_atoms_a, int world, ShardState* st,
+                       int64_t* counts_host) {
+    const int64_t nb = (n_pairs + 8191) / 8192;
+    k_shard_plan<<<(unsigned)(nb < 256 ? (nb > 0 ? nb : 1) : 256), 1024, 0, s>>>(anchors, n_pairs, n_atoms_a, world, st, counts_host);
+}
+void launch_shard_select(hipStream_t s, const int64_t* anchors, int64_t n_pairs, int64_t n_atoms_a, int rank, ShardState* st,
+                         int64_t* sel_anchors, int64_t* sel_index) {
+    const int64_t nb = (n_pairs + 2047) / 2048;
+    k_shard_select<<<(unsigned)(nb < 1024 ? (nb > 0 ? nb : 1) : 1024), 256, 0, s>>>(anchors, n_pairs, n_atoms_a, rank, st, sel_anchors, sel_index);
+}
+void launch_unshard_scores(hipStream_t s, const double* gathered, const ShardCounts& counts, int world, int64_t stride, double* out,
+                           int64_t n_pairs, uint32_t* bad) {
+    k_unshard_scores<<<1024, 256, 0, s>>>(gathered, counts, world, stride, out, n_pairs, bad);
+}
 }  // namespace lchd
 
 namespace lchd {

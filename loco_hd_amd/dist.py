@@ -1,50 +1,143 @@
 """Multi-GPU sharding of the anchor-pair list (one process per GPU, torch.distributed; backend "nccl" = RCCL).
 
 Anchor pairs are independent (the reference's rayon par_iter body shares no mutable state,
-/root/reference/src/locohd.rs:545-554), so the pair list is cut into `world` contiguous slices, every rank
-scores its slice against its own replica of the two structures, and the only communication is one gather of
-the f64 score slices to rank 0 (<= 1 MB per rank at 10^6 pairs: latency-bound on xGMI; no all-reduce).
+/root/reference/src/locohd.rs:545-554), so the path has no exchange step: every rank holds both structures and the whole
+pair list, scores its share, and the only communication is ONE gather of the score slices to rank 0 (8 B + 8 B of index per
+pair: latency-bound on xGMI; no all-reduce).
+
+Which share?  A rank that takes a contiguous slice of RANDOM pairs builds almost every environment of both structures
+itself, so the environment phase does not shrink with the number of GPUs.  Binning the pairs by their side-A anchor
+(`partition="anchor"`, the default) gives every rank ~1/world of side A's environments; the rule is a pure function of the
+pair list, so all ranks agree on it without communication, and the original positions travel with the scores so that
+output i still belongs to anchor pair i (order-preserving like the reference's indexed collect, src/locohd.rs:556).
+
+    bin(p)  = floor(a_p * 1024 / n_atoms_a)                            a_p = side-A anchor of pair p (clamped into range)
+    rank(b) = min(world - 1, floor(#pairs in bins < b * world / P))
+
+On CUDA tensors with a `DeviceSession` the partition runs in the library's own kernels (lchd_shard_plan_dev /
+lchd_shard_select_dev / lchd_unshard_scores_dev: two launches and one wait); the torch expressions below are the same rule
+for CPU tensors (the gloo tests) and the cross-check of the kernels.
 """
 from __future__ import annotations
 
-from typing import Callable, Optional, Tuple
+import ctypes as C
+from typing import Callable, List, Optional, Tuple
+
+SHARD_BINS = 1024
 
 
 def shard_bounds(n_pairs: int, world: int, rank: int) -> Tuple[int, int, int]:
-    """Contiguous slice [lo, hi) of rank `rank`; every rank's slice is padded to `chunk` for the gather."""
+    """Contiguous slice [lo, hi) of rank `rank` (partition="contiguous"); every rank's slice is padded to `chunk` for the gather."""
     chunk = (n_pairs + world - 1) // world
     lo = min(rank * chunk, n_pairs)
     return lo, min(lo + chunk, n_pairs), chunk
 
 
+def shard_rule(anchors, n_atoms_a: int, world: int):
+    """The partition rule in torch (any device): returns (rank_of_pair int64 [P], counts list[world])."""
+    import torch
+
+    p = anchors.shape[0]
+    a = anchors[:, 0].clamp(0, max(int(n_atoms_a) - 1, 0))
+    bins = (a * SHARD_BINS) // int(n_atoms_a)
+    hist = torch.bincount(bins, minlength=SHARD_BINS)
+    before = torch.cumsum(hist, 0) - hist
+    rank_of_bin = torch.clamp((before * world) // max(p, 1), max=world - 1)
+    counts = torch.zeros(world, dtype=torch.int64, device=anchors.device).index_add_(0, rank_of_bin, hist)
+    return rank_of_bin[bins], [int(v) for v in counts.tolist()]
+
+
+def select_shard(anchors, n_atoms_a: int, world: int, rank: int, session=None):
+    """This rank's pairs: (sel_anchors [n][2], sel_index [n] = positions in the full list, counts of every rank)."""
+    import torch
+
+    p = anchors.shape[0]
+    if session is not None and anchors.is_cuda and p > 0:
+        from . import _native as N
+
+        assert anchors.dtype == torch.int64 and anchors.is_contiguous()
+        counts = (C.c_int64 * world)()
+        N.check(N.lib().lchd_shard_plan_dev(session._ctx, C.c_void_p(anchors.data_ptr()), p, int(n_atoms_a), world, counts))
+        counts = [int(v) for v in counts]
+        n = counts[rank]
+        sel = torch.empty((n, 2), dtype=torch.int64, device=anchors.device)
+        idx = torch.empty(n, dtype=torch.int64, device=anchors.device)
+        N.check(N.lib().lchd_shard_select_dev(session._ctx, C.c_void_p(anchors.data_ptr()), p, int(n_atoms_a), rank,
+                                              C.c_void_p(sel.data_ptr()), C.c_void_p(idx.data_ptr())))
+        return sel, idx, counts
+    rank_of_pair, counts = shard_rule(anchors, n_atoms_a, world)
+    idx = (rank_of_pair == rank).nonzero().reshape(-1)
+    return anchors[idx].contiguous(), idx, counts
+
+
 def gather_scores(local, gathered, world: int, rank: int, group=None, force_collective: bool = False, async_op: bool = False):
-    """Gather equal-length score vectors to rank 0: gathered[r*len : (r+1)*len] = rank r's `local`.
+    """Gather equal-length vectors to rank 0: gathered[r*len : (r+1)*len] = rank r's `local`.
     With async_op=True the collective's work handle is returned (call .wait() before reusing `local`)."""
     import torch.distributed as dist
 
     if world == 1 and not force_collective:
         if gathered is not None:
-            gathered[: local.numel()].copy_(local)
+            gathered[: local.numel()].copy_(local.reshape(-1))
         return None
     n = local.numel()
     chunks = [gathered[r * n:(r + 1) * n] for r in range(world)] if rank == 0 else None
-    work = dist.gather(local, gather_list=chunks, dst=0, group=group, async_op=async_op)
+    work = dist.gather(local.reshape(-1), gather_list=chunks, dst=0, group=group, async_op=async_op)
     return work if async_op else None
 
 
-def score_sharded(score_fn: Callable, anchors, world: int, rank: int, group=None):
-    """Score anchors[lo:hi] on this rank with `score_fn(anchor_slice) -> 1-D float64 tensor` and gather.
+def unshard(gathered, counts: List[int], stride: int, n_pairs: int, out=None, session=None):
+    """Rank 0: gathered is [world][2][stride] float64 (scores, then the pair positions as int64 bit patterns)."""
+    import torch
 
-    `anchors` is the FULL [P][2] int64 tensor (same on every rank).  Returns the full [P] score tensor on
-    rank 0 (output i belongs to anchor pair i) and None elsewhere.
-    """
+    world = len(counts)
+    if out is None:
+        out = torch.empty(n_pairs, dtype=torch.float64, device=gathered.device)
+    if session is not None and gathered.is_cuda and n_pairs > 0:
+        from . import _native as N
+
+        cnt = (C.c_int64 * world)(*counts)
+        N.check(N.lib().lchd_unshard_scores_dev(session._ctx, C.c_void_p(gathered.data_ptr()), cnt, world, int(stride),
+                                                C.c_void_p(out.data_ptr()), int(n_pairs)))
+        return out
+    g = gathered.reshape(world, 2, stride)
+    for r, n in enumerate(counts):
+        out[g[r, 1, :n].view(torch.int64)] = g[r, 0, :n]
+    return out
+
+
+def score_sharded(score_fn: Callable, anchors, world: int, rank: int, group=None, n_atoms_a: Optional[int] = None, session=None,
+                  partition: str = "anchor", force_collective: bool = False):
+    """Score this rank's share of `anchors` with `score_fn(anchor_subset [n][2]) -> 1-D float64 tensor [n]` and gather.
+
+    `anchors` is the FULL [P][2] int64 tensor (same on every rank).  Returns the full [P] score tensor on rank 0 (output i
+    belongs to anchor pair i) and None elsewhere.  partition="anchor" needs n_atoms_a (the size of structure A);
+    "contiguous" is the plain slice (best when consecutive pairs share anchors already, e.g. (i, perm(i)) lists).
+    With `session` (a DeviceSession on this rank's GPU) partition and restore run in the library's kernels."""
     import torch
 
     p = anchors.shape[0]
-    lo, hi, chunk = shard_bounds(p, world, rank)
-    local = torch.zeros(chunk, dtype=torch.float64, device=anchors.device)
-    if hi > lo:
-        local[: hi - lo] = score_fn(anchors[lo:hi].contiguous())
-    gathered = torch.empty(chunk * world, dtype=torch.float64, device=anchors.device) if rank == 0 else None
-    gather_scores(local, gathered, world, rank, group)
-    return gathered[:p] if rank == 0 else None
+    dev = anchors.device
+    if partition == "contiguous":
+        lo, hi, chunk = shard_bounds(p, world, rank)
+        local = torch.zeros(chunk, dtype=torch.float64, device=dev)
+        if hi > lo:
+            local[: hi - lo] = score_fn(anchors[lo:hi].contiguous())
+        gathered = torch.empty(chunk * world, dtype=torch.float64, device=dev) if rank == 0 else None
+        gather_scores(local, gathered, world, rank, group, force_collective)
+        return gathered[:p] if rank == 0 else None
+    if partition != "anchor":
+        raise ValueError(f"unknown partition {partition!r}")
+    if n_atoms_a is None:
+        raise ValueError('partition="anchor" needs n_atoms_a')
+    sel, idx, counts = select_shard(anchors, n_atoms_a, world, rank, session)
+    stride = max(max(counts), 1)
+    local = torch.zeros((2, stride), dtype=torch.float64, device=dev)
+    n = counts[rank]
+    if n:
+        local[0, :n] = score_fn(sel)
+        local[1, :n] = idx.view(torch.float64)
+    gathered = torch.empty(world * 2 * stride, dtype=torch.float64, device=dev) if rank == 0 else None
+    gather_scores(local, gathered, world, rank, group, force_collective)
+    if rank != 0:
+        return None
+    return unshard(gathered, counts, stride, p, session=session)

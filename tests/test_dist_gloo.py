@@ -1,7 +1,9 @@
-"""world_size-2 CPU test (gloo) of the anchor-pair sharding + score gather used on N GPUs.
+"""world_size-2 CPU tests (gloo) of the anchor-pair sharding + score gather used on N GPUs.
 
-The compute inside each rank is a stand-in (the CPU oracle, test-only) because there is no GPU here; what is
-under test is loco_hd_amd.dist: slice bounds, padding, gather order (output i <-> anchor pair i)."""
+The compute inside each rank is a stand-in (the CPU oracle, test-only) because there is no GPU here; what is under test is
+loco_hd_amd.dist: the anchor-binned partition rule (every rank computes the same one without communication), the
+permutation that travels with the scores, the gather, and the restore to anchor-pair order (output i <-> anchor pair i).
+The same rule inside the library's kernels and a real DeviceSession under torch.distributed are in tests/test_gpu_dist.py."""
 import os
 import sys
 from pathlib import Path
@@ -13,11 +15,12 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = Path(__file__).resolve().parent.parent
+N_ATOMS = 120
 
 
 def _workload():
     rng = np.random.default_rng(7)
-    n = 120
+    n = N_ATOMS
     xa, xb = rng.uniform(-12, 12, (n, 3)), rng.uniform(-12, 12, (n, 3))
     ca, cb = rng.integers(0, 4, n).astype(np.int32), rng.integers(0, 4, n).astype(np.int32)
     pairs = np.stack([rng.integers(0, n, 257), rng.integers(0, n, 257)], 1).astype(np.int64)  # odd count: uneven shards
@@ -39,7 +42,7 @@ def _score_fn():
     return fn
 
 
-def _worker(rank, world, port, result_file):
+def _worker(rank, world, port, result_file, partition):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -47,7 +50,20 @@ def _worker(rank, world, port, result_file):
     from loco_hd_amd.dist import score_sharded
 
     anchors = torch.from_numpy(_workload()[4])
-    full = score_sharded(_score_fn(), anchors, world, rank)
+    seen = []
+    fn = _score_fn()
+
+    def counting(sub):
+        seen.append(sub.clone())
+        return fn(sub)
+
+    full = score_sharded(counting, anchors, world, rank, n_atoms_a=N_ATOMS, partition=partition)
+    if partition == "anchor":  # the two ranks' side-A anchors do not interleave: rank 0 has the low atoms, rank 1 the high ones
+        mine = torch.cat(seen)[:, 0]
+        edge = torch.tensor([int(mine.max()) if rank == 0 else int(mine.min())])
+        edges = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(edges, edge)
+        assert int(edges[0]) <= int(edges[1])
     if rank == 0:
         np.save(result_file, full.numpy())
     else:
@@ -68,11 +84,45 @@ def test_shard_bounds():
         assert covered == list(range(n))
 
 
+def test_anchor_partition_rule():
+    """Every pair belongs to exactly one rank, ranks are balanced for spread-out anchors, a rank's side-A anchors form one
+    contiguous range of atoms, and degenerate lists (one anchor for every pair, out-of-range indices) stay well defined."""
+    from loco_hd_amd.dist import select_shard, shard_rule
+
+    rng = np.random.default_rng(3)
+    for n_atoms, p, world in ((200_000, 300_000, 8), (1000, 5000, 3), (50, 7, 4), (10, 100, 1), (3000, 0, 2)):
+        a = torch.from_numpy(np.stack([rng.integers(0, n_atoms, p), rng.integers(0, n_atoms, p)], 1).astype(np.int64)).reshape(-1, 2)
+        rank_of_pair, counts = shard_rule(a, n_atoms, world)
+        assert sum(counts) == p and len(counts) == world
+        assert np.array_equal(np.bincount(rank_of_pair.numpy(), minlength=world), np.asarray(counts))
+        if p >= 1000:
+            assert max(counts) <= 1.05 * p / world + n_atoms / 1024 + 8, counts
+        covered = []
+        hi_prev = -1
+        for r in range(world):
+            sel, idx, c2 = select_shard(a, n_atoms, world, r)
+            assert c2 == counts and len(idx) == counts[r] and torch.equal(sel, a[idx])
+            covered.append(idx.numpy())
+            if len(sel):
+                assert int(sel[:, 0].min()) > hi_prev or int(sel[:, 0].min()) // max(n_atoms // 1024, 1) >= hi_prev // max(n_atoms // 1024, 1)
+                hi_prev = int(sel[:, 0].max())
+        assert np.array_equal(np.sort(np.concatenate(covered)) if covered else np.zeros(0), np.arange(p))
+    # KRas-scan shape (python_codes/kras_scan.py:46-52): one reference anchor against thousands -> one rank gets everything
+    a = torch.from_numpy(np.stack([np.zeros(4000, np.int64), np.arange(4000)], 1))
+    _, counts = shard_rule(a, 5000, 4)
+    assert sorted(counts) == [0, 0, 0, 4000]
+    # indices outside the structure are clamped into the first / last bin (the scoring pass reports them)
+    a = torch.tensor([[-5, 0], [10**9, 1], [3, 2]], dtype=torch.int64)
+    _, counts = shard_rule(a, 100, 2)
+    assert sum(counts) == 3
+
+
 @pytest.mark.timeout(180)
-def test_sharded_scores_match_single_process(tmp_path):
-    port = 29500 + (os.getpid() % 2000)
+@pytest.mark.parametrize("partition", ["anchor", "contiguous"])
+def test_sharded_scores_match_single_process(tmp_path, partition):
+    port = 29500 + (os.getpid() % 2000) + (7 if partition == "anchor" else 0)
     out = tmp_path / "scores.npy"
-    mp.spawn(_worker, args=(2, port, str(out)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(out), partition), nprocs=2, join=True)
     got = np.load(out)
     want = _score_fn()(torch.from_numpy(_workload()[4])).numpy()
     assert got.shape == want.shape and np.array_equal(got, want)

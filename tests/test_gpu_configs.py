@@ -326,12 +326,47 @@ def test_small_pair_kernel_with_a_minority_of_large_pairs(lh, oracle, monkeypatc
         if events is not None:  # the intended mix of pair sizes
             small = np.mean(events <= 224)
             assert (small >= 0.5) == expect_small_majority and 0.02 < small < 0.98, small
+        inline, _ = run(lh)  # a call this small: the one-launch sweep (records inline, one pair per wavefront)
+        assert np.max(np.abs(inline - want)) < TIGHT
+        monkeypatch.setenv("LCHD_NO_INLINE_META", "1")  # the regular pipeline: k_pair_meta, then the device picks the kernels
         got, _ = run(lh)
         assert np.max(np.abs(got - want)) < TIGHT
         monkeypatch.setenv("LCHD_NO_DUO", "1")
         plain, _ = run(lh)
         monkeypatch.delenv("LCHD_NO_DUO")
-        assert np.max(np.abs(got - plain)) < 1e-13
+        monkeypatch.delenv("LCHD_NO_INLINE_META")
+        assert np.max(np.abs(got - plain)) < 1e-13 and np.max(np.abs(inline - plain)) < 1e-13
+
+
+def test_sweep_hint_follows_the_workload(lh, oracle, monkeypatch):
+    """One context scores workloads whose pair sizes flip between 'mostly small' and 'mostly large': the first pass launches
+    every candidate sweep kernel and lets the device decide, later passes launch what the PREVIOUS pass's outcome suggests
+    (k_sweep_duo + indirect k_sweep, or the plain k_sweep).  Any choice must give the oracle's scores for any input."""
+    import torch
+    from loco_hd_amd.device import DeviceSession
+
+    monkeypatch.setenv("LCHD_NO_INLINE_META", "1")
+    rng = np.random.default_rng(77)
+    cats = [f"c{i}" for i in range(7)]
+    wf = ("hyper_exp", [1.0, 0.2])
+    lchd = lh.LoCoHD(cats, lh.WeightFunction(*wf))
+    lo = oracle.LoCoHD(cats, oracle.WeightFunction(*wf))
+    sess = DeviceSession(lchd)
+    clouds = {}
+    for name, density in (("sparse", 0.02), ("dense", 0.05)):  # ~84 / ~209 points per environment at threshold 10
+        n = 2500
+        side = (n / density) ** (1 / 3)
+        xa, xb = rng.uniform(0, side, (n, 3)), rng.uniform(0, side, (n, 3))
+        ca, cb = rng.integers(0, 7, n).astype(np.int32), rng.integers(0, 7, n).astype(np.int32)
+        pairs = np.stack([rng.integers(0, n, 3000), rng.integers(0, n, 3000)], 1).astype(np.int64)
+        tag = np.zeros(n, dtype=np.int32)
+        want = np.asarray(lo.from_arrays(xa, ca, tag, xb, cb, tag, pairs, 10.0))
+        clouds[name] = (sess.upload(xa, ca), sess.upload(xb, cb), torch.from_numpy(pairs).cuda(), want)
+    for name in ("sparse", "sparse", "dense", "dense", "sparse", "dense", "sparse"):  # every hint transition
+        a, b, anchors, want = clouds[name]
+        got = sess.from_primitives(a, b, anchors, 10.0).cpu().numpy()
+        assert np.max(np.abs(got - want)) < TIGHT, name
+    sess.close()
 
 
 def test_regular_batch_of_large_structures_uses_the_per_structure_cell_build(lh, oracle):

@@ -1,0 +1,144 @@
+"""Multi-GPU plumbing on ONE GPU: the library's partition kernels against the torch rule, the restore, `score_sharded` with a
+real DeviceSession under torch.distributed (backend nccl = RCCL, world size 1, the collective forced), every rank of an
+emulated world on the same device, and the single-process device group of the C ABI (two contexts on device 0)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TIGHT = 1e-11
+
+
+@pytest.fixture(scope="module")
+def setup(oracle):
+    import torch
+
+    import loco_hd_amd as lh
+    from loco_hd_amd.device import DeviceSession
+
+    rng = np.random.default_rng(5)
+    n, c = 4000, 9
+    side = (n / 0.04) ** (1 / 3)
+    xa, xb = rng.uniform(0, side, (n, 3)), rng.uniform(0, side, (n, 3))
+    ca, cb = rng.integers(0, c, n).astype(np.int32), rng.integers(0, c, n).astype(np.int32)
+    cats = [f"c{i}" for i in range(c)]
+    pairs = np.stack([rng.integers(0, n, 30_000), rng.integers(0, n, 30_000)], 1).astype(np.int64)
+    lchd = lh.LoCoHD(cats, lh.WeightFunction("hyper_exp", [1.0, 0.15]))
+    sess = DeviceSession(lchd)
+    a, b = sess.upload(xa, ca), sess.upload(xb, cb)
+    anchors = torch.from_numpy(pairs).cuda()
+    tag = np.zeros(n, dtype=np.int32)
+    want = np.asarray(oracle.LoCoHD(cats, oracle.WeightFunction("hyper_exp", [1.0, 0.15])).from_arrays(xa, ca, tag, xb, cb, tag, pairs, 10.0))
+    direct = sess.from_primitives(a, b, anchors, 10.0).clone()
+    assert np.max(np.abs(direct.cpu().numpy() - want)) < TIGHT
+    yield dict(lh=lh, sess=sess, a=a, b=b, anchors=anchors, n=n, want=want, direct=direct, xa=xa, xb=xb, ca=ca, cb=cb, cats=cats, pairs=pairs)
+    sess.close()
+
+
+def test_partition_kernels_equal_the_torch_rule(setup):
+    import torch
+    from loco_hd_amd.dist import select_shard, shard_rule, unshard
+
+    sess = setup["sess"]
+    rng = np.random.default_rng(11)
+    lists = {
+        "random": (setup["anchors"], setup["n"]),
+        "big": (torch.from_numpy(np.stack([rng.integers(0, 200_000, 1_000_003), rng.integers(0, 200_000, 1_000_003)], 1)).cuda(), 200_000),
+        "one_anchor": (torch.from_numpy(np.stack([np.full(5000, 17), np.arange(5000)], 1)).cuda(), 6000),
+        "out_of_range": (torch.tensor([[-3, 0], [10**12, 1], [5, 2], [99, 3]], dtype=torch.int64).cuda(), 100),
+        "single_pair": (torch.tensor([[7, 7]], dtype=torch.int64).cuda(), 10),
+    }
+    for name, (anc, n_atoms) in lists.items():
+        anc = anc.contiguous()
+        p = anc.shape[0]
+        for world in (1, 2, 3, 8, 64):
+            rank_of_pair, counts = shard_rule(anc, n_atoms, world)
+            stride = max(max(counts), 1)
+            gathered = torch.zeros((world, 2, stride), dtype=torch.float64, device="cuda")
+            fake = torch.arange(p, dtype=torch.float64, device="cuda") * 0.5 + 1.0  # "score" of pair i
+            for r in range(world):
+                sel, idx, c2 = select_shard(anc, n_atoms, world, r, session=sess)
+                assert c2 == counts, (name, world, r)
+                want_idx = (rank_of_pair == r).nonzero().reshape(-1)
+                assert torch.equal(torch.sort(idx).values, want_idx), (name, world, r)  # same SET (the kernel's order is arrival order)
+                assert torch.equal(sel, anc[idx])
+                gathered[r, 0, : counts[r]] = fake[idx]
+                gathered[r, 1, : counts[r]] = idx.view(torch.float64)
+            out = unshard(gathered.reshape(-1), counts, stride, p, session=sess)
+            assert torch.equal(out, fake), (name, world)
+
+
+def test_every_rank_of_an_emulated_world_on_one_gpu(setup):
+    """What 4 ranks would do, one after the other on this GPU: bitwise the single call, in anchor-pair order."""
+    import torch
+    from loco_hd_amd.dist import select_shard, unshard
+
+    s = setup
+    world = 4
+    parts = []
+    for r in range(world):
+        sel, idx, counts = select_shard(s["anchors"], s["n"], world, r, session=s["sess"])
+        parts.append((s["sess"].from_primitives(s["a"], s["b"], sel, 10.0).clone(), idx))
+    stride = max(counts)
+    gathered = torch.zeros((world, 2, stride), dtype=torch.float64, device="cuda")
+    for r, (sc, idx) in enumerate(parts):
+        gathered[r, 0, : counts[r]] = sc
+        gathered[r, 1, : counts[r]] = idx.view(torch.float64)
+    out = unshard(gathered.reshape(-1), counts, stride, s["anchors"].shape[0], session=s["sess"])
+    assert torch.equal(out, s["direct"])
+    # each rank built about a quarter of side A's environments
+    uniq_a = [int(torch.unique(s["anchors"][idx][:, 0]).numel()) for _, idx in parts]
+    assert max(uniq_a) < 0.3 * s["n"], uniq_a
+
+
+def test_score_sharded_under_rccl_world_of_one(setup):
+    """DeviceSession + torch.distributed (backend nccl = RCCL): world size 1 with the collective forced, both partitions."""
+    import torch
+    import torch.distributed as dist
+    from loco_hd_amd.dist import score_sharded
+
+    s = setup
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(29700 + os.getpid() % 1000)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        fn = lambda sub: s["sess"].from_primitives(s["a"], s["b"], sub, 10.0)
+        for partition in ("anchor", "contiguous"):
+            full = score_sharded(fn, s["anchors"], 1, 0, n_atoms_a=s["n"], session=s["sess"], partition=partition, force_collective=True)
+            torch.cuda.synchronize()
+            assert torch.equal(full, s["direct"]), partition
+    finally:
+        dist.destroy_process_group()
+
+
+def test_device_group_of_the_c_abi(setup, oracle):
+    """lchd_group_from_primitives with two contexts on device 0: the call a Rust / C binding would make for multi-GPU."""
+    s, lh = setup, setup["lh"]
+    tag = np.zeros(s["n"], dtype=np.int32)
+    pa, pb = lh.api._Packed(s["xa"], s["ca"], tag), lh.api._Packed(s["xb"], s["cb"], tag)
+    single = lh.LoCoHD(s["cats"], lh.WeightFunction("hyper_exp", [1.0, 0.15]))
+    ref = single.from_packed(pa, pb, s["pairs"], 10.0)
+    for devices in ([0], [0, 0], [0, 0, 0]):
+        grp = lh.LoCoHD(s["cats"], lh.WeightFunction("hyper_exp", [1.0, 0.15]), devices=devices)
+        got = grp.from_packed(pa, pb, s["pairs"], 10.0)
+        assert np.array_equal(got, ref), devices
+        if len(devices) > 1:
+            counts = grp.last_group_counts()
+            assert sum(counts) == len(s["pairs"]) and min(counts) > 0.25 * len(s["pairs"]) / len(devices), counts
+        # errors come back as the reference's classes from whichever device meets them
+        bad = s["pairs"][:100].copy()
+        bad[37, 1] = s["n"] + 5
+        with pytest.raises(lh.PanicException):
+            grp.from_packed(pa, pb, bad, 10.0)
+        assert np.array_equal(grp.from_packed(pa, pb, s["pairs"][:1000], 10.0), ref[:1000])  # and the group keeps working
+    assert np.max(np.abs(ref - s["want"])) < TIGHT
+    # the reference's call shape with lists of PrimitiveAtoms and a dictionary of weight functions (per-pair keys travel too)
+    multi = {"near": lh.WeightFunction("uniform", [0.0, 6.0]), "far": lh.WeightFunction("hyper_exp", [1.0, 0.1])}
+    omulti = {"near": oracle.WeightFunction("uniform", [0.0, 6.0]), "far": oracle.WeightFunction("hyper_exp", [1.0, 0.1])}
+    prims = lambda mod, x, c: [mod.PrimitiveAtom(s["cats"][k], "", xyz) for k, xyz in zip(c[:600], x[:600])]
+    keyed = [(int(i) % 600, int(j) % 600, "near" if k % 3 else "far") for k, (i, j) in enumerate(s["pairs"][:900])]
+    got = lh.LoCoHD(s["cats"], multi, devices=[0, 0]).from_primitives(prims(lh, s["xa"], s["ca"]), prims(lh, s["xb"], s["cb"]), keyed, 9.0)
+    want = oracle.LoCoHD(s["cats"], omulti).from_primitives(prims(oracle, s["xa"], s["ca"]), prims(oracle, s["xb"], s["cb"]), keyed, 9.0)
+    assert np.max(np.abs(np.asarray(got) - np.asarray(want))) < TIGHT

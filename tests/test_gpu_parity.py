@@ -277,6 +277,36 @@ def test_big_environments_block_kernel(lh, oracle):
     assert np.max(np.abs(got - want)) < TIGHT
 
 
+def test_two_contexts_and_capacity_decay(lh, oracle):
+    """Two contexts alive at once: the dynamic-LDS attributes and the hooks belong to a context / its device, not to the
+    process, so a > 4096-point environment (the 1024-thread environment kernel with > 64 KB of LDS) must work on the SECOND
+    context as well; a context whose capacity hint was raised by one dense call keeps giving right answers while the hint
+    decays again over the following small calls."""
+    rng = np.random.default_rng(53)
+    sa, xa = cloud(rng, 7000, box=6.0)
+    sb, xb = cloud(rng, 6500, box=6.0)
+    big_anchors = [(int(i), int(j)) for i, j in zip(rng.integers(0, 7000, 4), rng.integers(0, 6500, 4))]
+    ss, xs = cloud(rng, 400, box=12.0)
+    small_anchors = [(i, i) for i in range(0, 400, 3)]
+
+    def big(mod, lchd):
+        return np.asarray(lchd.from_primitives(prims(mod, sa, xa), prims(mod, sb, xb), big_anchors, 11.0))
+
+    def small(mod, lchd):
+        return np.asarray(lchd.from_primitives(prims(mod, ss, xs), prims(mod, ss, xs[::-1].copy()), small_anchors, 9.0))
+
+    mk = lambda mod: mod.LoCoHD(CATS, mod.WeightFunction("hyper_exp", [1.0, 0.2]))
+    first, second = mk(lh), mk(lh)
+    ref = mk(oracle)
+    want_big, want_small = big(oracle, ref), small(oracle, ref)
+    assert np.max(np.abs(small(lh, first) - want_small)) < TIGHT   # creates context 1
+    assert np.max(np.abs(big(lh, second) - want_big)) < TIGHT      # context 2: capacity 8192 on its first call
+    assert np.max(np.abs(big(lh, first) - want_big)) < TIGHT
+    for _ in range(40):  # the raised capacity hint halves every eight small passes: 8192 -> ... -> 512
+        assert np.max(np.abs(small(lh, second) - want_small)) < TIGHT
+    assert np.max(np.abs(big(lh, second) - want_big)) < TIGHT
+
+
 def test_too_many_categories_is_loud(lh):
     with pytest.raises(NotImplementedError):
         lh.LoCoHD([f"c{i}" for i in range(256)]).from_anchors(["c0"], ["c0"], [0.0], [0.0])
@@ -333,8 +363,17 @@ def test_every_sweep_kernel_variant(lh, oracle, hook, monkeypatch):
             lchd = mod.LoCoHD(CATS, mod.WeightFunction(*wf), category_weights=w)
             return np.asarray(lchd.from_primitives(prims(mod, sa, xa), prims(mod, sb, xb), anchors, 9.0))
 
-        got, want = both(lh, oracle, run)
-        assert np.max(np.abs(got - want)) < TIGHT, (hook, wf)
+        want = run(oracle)
+        # a call this small takes the one-launch sweep (records worked out inline) where the configuration allows it; the
+        # second round forces the regular pipeline (k_pair_meta + k_sweep / k_sweep_duo) onto the same inputs, the third the
+        # regular pipeline without the two-pairs-per-wavefront kernel
+        for extra in ({}, {"LCHD_NO_INLINE_META": "1"}, {"LCHD_NO_INLINE_META": "1", "LCHD_NO_DUO": "1"}):
+            for k, v in extra.items():
+                monkeypatch.setenv(k, v)
+            got = run(lh)
+            for k in extra:
+                monkeypatch.delenv(k)
+            assert np.max(np.abs(got - want)) < TIGHT, (hook, extra, wf)
 
 
 def test_near_identical_environments(lh, oracle):
