@@ -908,7 +908,7 @@ extern "C" int lchd_ctx_finish(lchd_ctx* c) {
         } else {
             c->shrink_votes = 0;
         }
-        if (c->h_cfg.n_categories <= 16 && c->h_status->n_small != ~0ull)  // who swept the pairs this time is the hint for the next
+        if (c->h_status->n_small != ~0ull)  // who swept the pairs this time is the hint for the next
             c->sweep_hint = (2 * c->h_status->n_small >= (unsigned long long)P.n_pairs) ? 1 : 2;  // pass of this configuration
         c->last = P.sw;
         c->last_valid = true;
@@ -1413,7 +1413,7 @@ extern "C" int lchd_shard_select_dev(lchd_ctx* c, const int64_t* d_anchors, int6
     if (c->shard_world < 1 || n_pairs != c->shard_pairs || n_atoms_a != c->shard_atoms)
         return fail(LCHD_EVALUE, "lchd_shard_plan_dev has not been called for this pair list");
     if (rank < 0 || rank >= c->shard_world) return fail(LCHD_EVALUE, "rank %d outside the planned world of %d", rank, c->shard_world);
-    if (n_pairs == 0) return LCHD_OK;
+    if (n_pairs == 0 || c->h_counts[rank] == 0) return LCHD_OK;  // nothing for this rank: the outputs may be null
     if (!d_anchors || !d_sel_anchors || !d_sel_index) return fail(LCHD_EVALUE, "null pointer");
     CTX_GUARD(c);
     launch_shard_select(c->stream, d_anchors, n_pairs, n_atoms_a, rank, c->d_shard, d_sel_anchors, d_sel_index);

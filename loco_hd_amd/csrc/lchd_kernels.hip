@@ -348,19 +348,30 @@ __device__ __forceinline__ void dedupe_finish_wg(const uint32_t* bits, uint32_t*
     if (tid < nw) wpre[tid] = pre;
     if (tid == nw - 1) { wpre[nw] = pre + v; *n_unique_out = pre + v; slot[c.n] = pre + v; }
     __syncthreads();
-    for (int i = tid; i < c.n; i += NT) {
-        const uint32_t w = bits[i >> 5];
-        if ((w >> (i & 31)) & 1u) {
-            const uint32_t sl = wpre[i >> 5] + (uint32_t)__popc(w & ((1u << (i & 31)) - 1u));
-            slot[i] = sl;
-            AnchorRec r;
-            r.x = c.x[i]; r.y = c.y[i]; r.z = c.z[i];
-            r.tag = (uint32_t)c.tag[i];
-            r.apos = apos_of(i);
-            r.sid = c.sid ? c.sid[i] : 0;
-            r.atom = (uint32_t)i;
-            uniq[sl] = r;
+    // four atoms per thread and step, their loads in flight together (one workgroup, latency-bound: see cell_build_wg)
+    constexpr int U = 4;
+    for (int i0 = tid; i0 < c.n; i0 += U * NT) {
+        AnchorRec r[U];
+        uint32_t sl[U];
+        bool on[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = min(i0 + u * NT, c.n - 1);
+            const uint32_t w = bits[i >> 5];
+            on[u] = (i0 + u * NT < c.n) && ((w >> (i & 31)) & 1u);
+            sl[u] = wpre[i >> 5] + (uint32_t)__popc(w & ((1u << (i & 31)) - 1u));
+            r[u].x = c.x[i]; r[u].y = c.y[i]; r[u].z = c.z[i];
+            r[u].tag = (uint32_t)c.tag[i];
+            r[u].apos = apos_of(i);
+            r[u].sid = c.sid ? c.sid[i] : 0;
+            r[u].atom = (uint32_t)i;
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (on[u]) {
+                slot[i0 + u * NT] = sl[u];
+                uniq[sl[u]] = r[u];
+            }
     }
 }
 
@@ -449,10 +460,13 @@ __global__ __launch_bounds__(1024) void k_dedupe_finish_small(PrepSide pa, PrepS
     const PrepSide& P = side ? pb : pa;
     const int n = P.c.n, nw = (n + 31) >> 5;
     const uint32_t* __restrict__ flag = P.slot;
-    for (int w = tid; w < nw; w += 1024) {
-        uint32_t m = 0;
-        for (int k = 0; k < 32; ++k) { const int i = 32 * w + k; m |= (i < n && flag[i]) ? (1u << k) : 0u; }
-        bits[w] = m;
+    for (int i0 = (tid >> 6) * 64; i0 < n; i0 += 1024) {  // coalesced flag reads, 64 flags -> two words per wavefront ballot
+        const int i = i0 + (tid & 63);
+        const unsigned long long m = __ballot(i < n && flag[i] != 0u);
+        if ((tid & 63) == 0) {
+            bits[i0 >> 5] = (uint32_t)m;
+            if ((i0 >> 5) + 1 <= kBitWordsMax) bits[(i0 >> 5) + 1] = (uint32_t)(m >> 32);
+        }
     }
     __syncthreads();
     const uint32_t* __restrict__ pos_of = P.pos_of;
@@ -1242,10 +1256,17 @@ enum { F_KEY = 0, F_FAST = 1, F_ANY = 2 };
 #ifndef LCHD_SWEEP_MINW
 #define LCHD_SWEEP_MINW 2
 #endif
+#ifndef LCHD_EPL_C8
+#define LCHD_EPL_C8 7    // ... of the 8-bit-count sweep: tiles of 448 (two environments of <= 255 points rarely merge to more)
+#endif
+#ifndef LCHD_C8_WAVES
+#define LCHD_C8_WAVES 3  // waves per SIMD the 8-bit-count sweep with more than 16 category slots is compiled for
+#endif
 #ifndef LCHD_EPL_BIG
 #define LCHD_EPL_BIG 8   // merged events per lane per tile of the many-slot Hellinger-2 sweep (k_sweep<20..32>): tiles of 512
 #endif
 constexpr int kDuoTileFwd = 224;  // = kDuoTile (k_sweep_duo, below)
+constexpr int kCount8MaxEnv = 255;        // the 8-bit-count sweep takes pairs whose environments both have at most this many points
 constexpr int64_t kInlineMetaPairs = 4096;   // calls of at most this many pairs: the sweep works out the pair records itself (one launch)
 // H^2 = 1 - D / sqrt(N_a N_b) carries an absolute rounding error of a few 1e-16 (D is rebuilt from the exact integer counts at
 // every lane chunk, so nothing drifts); sqrt() turns that into an error of ~3e-16 / (2 sqrt(H^2)) in H.  Below this bound the
@@ -1337,6 +1358,16 @@ __device__ __forceinline__ uint64_t spread4(uint64_t x) {
     return ((uint64_t)hi << 32) | lo;
 }
 
+// spread the eight 4-bit fields of the low 32 bits of x into eight 8-bit fields
+__device__ __forceinline__ uint64_t spread8(uint64_t x) {
+    const uint32_t v = (uint32_t)x;
+    auto half = [](uint32_t h) -> uint32_t {  // four nibbles (16 bits) -> four bytes
+        const uint32_t t = (h | (h << 8)) & 0x00FF00FFu;
+        return (t | (t << 4)) & 0x0F0F0F0Fu;
+    };
+    return ((uint64_t)half(v >> 16) << 32) | half(v & 0xFFFFu);
+}
+
 // One pair's weight function.  hyper_exp with <= 4 terms and uniform keep their parameters in (scalar)
 // registers; everything else goes through the out-of-line evaluator with the parameter pointer.
 struct WfRegs {
@@ -1413,21 +1444,29 @@ __device__ unsigned long long g_sweep_stamps[8];
 // INLINE_META (small calls: a few thousand pairs, where launches cost more than arithmetic): the kernel works out every
 // pair's record itself instead of reading what k_pair_meta wrote, and its last workgroup publishes the status snapshot --
 // ONE launch does the whole sweep phase.
-template <int CMAX, int MODE, int FMODE, bool LDSTAB, bool INDIRECT = false, bool INLINE_META = false>
-__global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 12 ? 4 : (CMAX <= LCHD_SWEEP_W3MAX ? 3 : 2)))) void k_sweep(SweepArgs args) {
+// CNT8 (environments of at most 255 points on both sides, i.e. most pairs at protein-like densities): the packed category
+// counts are 8-bit fields, eight per word instead of four -- half the words to scan across the wavefront, to unpack at every
+// tile and to keep per lane, and 3 KB less LDS per wavefront, which lets the many-slot variants run at 3 waves per SIMD
+// instead of 2.  Pairs with a larger environment are left to the INDIRECT instantiation of the 16-bit kernel.
+template <int CMAX, int MODE, int FMODE, bool LDSTAB, bool INDIRECT = false, bool INLINE_META = false, bool CNT8 = false>
+__global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 12 ? 4 : (CMAX <= LCHD_SWEEP_W3MAX ? 3 : (CNT8 ? LCHD_C8_WAVES : 2))))) void k_sweep(SweepArgs args) {
     static_assert(!(INDIRECT && INLINE_META), "the indirect instantiation reads the records of k_pair_meta");
+    static_assert(!CNT8 || (MODE == MODE_H2U && FMODE == F_KEY && LDSTAB && !INDIRECT && !INLINE_META), "8-bit counts: default configuration only");
     // Merged events per lane per tile.  The per-tile prologue (staging, merge path, scan of the packed counts, state reload)
     // costs about as many instructions as the events of a 384-event tile themselves, and it grows with the category slots:
     // the variants with many slots (25 categories at 0.05 atoms/A^3: ~416 events per pair) take tiles of 64 x LCHD_EPL_BIG so
     // that such a pair is ONE tile instead of a full one plus a nearly empty one.
     constexpr bool H2_ = (MODE != MODE_GEN);
-    constexpr int EPL = (H2_ && LDSTAB && CMAX > 16) ? LCHD_EPL_BIG : kSweepEPL, TILE = 64 * EPL, WPB = kSweepWaves;
+    constexpr int EPL = CNT8 ? LCHD_EPL_C8 : ((H2_ && LDSTAB && CMAX > 16) ? LCHD_EPL_BIG : kSweepEPL), TILE = 64 * EPL, WPB = kSweepWaves;
     static_assert(EPL <= 15, "4-bit chunk-local counters");
-    constexpr int NW = CMAX / 4;          // u64 words of 16-bit count fields per side
+    constexpr int FB = CNT8 ? 8 : 16;     // bits per count field
+    constexpr int FPW = 64 / FB;          // count fields per u64 word
+    constexpr uint64_t FMASK = CNT8 ? 0xFFull : 0xFFFFull;
+    constexpr int NW = (CMAX + FPW - 1) / FPW;  // u64 words of count fields per side
     constexpr int NH = (CMAX + 15) / 16;  // u64 words of 4-bit histogram fields per side
     constexpr bool H2 = (MODE != MODE_GEN);
     constexpr int NV = H2 ? 1 : CMAX;     // only the generic path keeps per-category values in registers
-    constexpr int NT = LDSTAB ? kSqrtTab + 8 : 1;  // sqrt(k), 1/sqrt(k) for k <= 512 in LDS; otherwise read from the global tables
+    constexpr int NT = LDSTAB ? (CNT8 ? 256 + 8 : kSqrtTab + 8) : 1;  // sqrt(k), 1/sqrt(k) for k <= 512 (255) in LDS; otherwise read from the global tables
     __shared__ double t_sqrt[NT], t_rsqrt[NT];
     __shared__ double w_s[32], sw_s[32];
     __shared__ uint64_t sA_[WPB][TILE], sB_[WPB][TILE];
@@ -1435,14 +1474,14 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
     // per-lane category counts of the event loop: [side][word][lane] u64 of four 16-bit fields (a lane only ever touches its own)
     // (13 and more category slots only: up to 12 the register form runs at 4 waves/SIMD, which the extra 3 KB of LDS per wave
     // would cut to 3 -- measured 2-6 % slower -- while from 13 on the LDS form is 4-13 % faster at unchanged occupancy)
-    constexpr bool LDSCNT = H2 && LDSTAB && CMAX > 12 && (LCHD_LDS_COUNTS != 0);
+    constexpr bool LDSCNT = H2 && LDSTAB && NW > 3 && (LCHD_LDS_COUNTS != 0);  // (16-bit fields: from 13 category slots on)
     __shared__ uint64_t lc_[LDSCNT ? WPB : 1][LDSCNT ? 2 * NW * 64 : 1];
     // When pairs with at most kDuoTile merged events are the majority of a launch, k_sweep_duo sweeps them two per wavefront
     // and the INDIRECT instantiation of this kernel picks the remaining ones out of the pair records; otherwise the plain
     // instantiation sweeps everything.  All three decide from the same word (k_pair_meta: DeviceStatus::n_small).
     if (!args.forced) {  // (forced: the host launched exactly the kernels that have to run)
         const bool duo_active = 2 * args.st->n_small >= (unsigned long long)args.n_pairs;
-        if constexpr (INDIRECT) { if (!duo_active) return; }
+        if constexpr (INDIRECT || CNT8) { if (!duo_active) return; }  // (the small-pair kernels and their companion: only when small pairs are the majority)
         else { if (args.duo_enabled && duo_active) return; }
     }
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1552,7 +1591,10 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
             if (blk * 64 >= total) return false;
             const int64_t pp = blk * 64 + lane;
             mm = pp < total ? args.meta[pp] : make_int4(0, 0, 0, 0);
-            todo = __ballot((mm.z & 0xFFFFFF) > 0 && (mm.z & 0xFFFFFF) + (mm.w & 0xFFFFFF) - 2 > kDuoTileFwd);
+            // the pairs the small-pair kernel of this launch leaves over: more than kDuoTile merged events (k_sweep_duo), or an
+            // environment of more than 255 points (the 8-bit-count k_sweep)
+            const int za = mm.z & 0xFFFFFF, zb = mm.w & 0xFFFFFF;
+            todo = __ballot(za > 0 && (args.small_rule ? max(za, zb) > kCount8MaxEnv : za + zb - 2 > kDuoTileFwd));
             p_cur = blk * 64;
             blk += pstride;
         }
@@ -1580,6 +1622,12 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
             if (lane == 0) args.out[p] = nan("");
             take_next();
             continue;
+        }
+        if constexpr (CNT8) {
+            if (max(nA, nB) > kCount8MaxEnv) {  // a count could leave its 8-bit field: the indirect 16-bit kernel takes this pair
+                take_next();
+                continue;
+            }
         }
         const int64_t ea = mx, eb = my;
         const int c0a = (mz >> 24) & 255, c0b = (mw >> 24) & 255;  // categories of the two anchors
@@ -1615,8 +1663,8 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
         {
 #pragma unroll
             for (int k = 0; k < NW; ++k) {
-                cntA[k] = ((c0a >> 2) == k) ? (1ull << ((c0a & 3) * 16)) : 0ull;
-                cntB[k] = ((c0b >> 2) == k) ? (1ull << ((c0b & 3) * 16)) : 0ull;
+                cntA[k] = ((c0a / FPW) == k) ? (1ull << ((c0a % FPW) * FB)) : 0ull;
+                cntB[k] = ((c0b / FPW) == k) ? (1ull << ((c0b % FPW) * FB)) : 0ull;
             }
         }
 
@@ -1632,7 +1680,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
         double va[NV], vb[NV];       // GEN: weighted category counts (pmf.rs:16-17)
 
         auto field = [&](const uint64_t (&ex)[NW], int c) -> int {  // static c
-            return (int)((ex[c >> 2] >> ((c & 3) * 16)) & 0xFFFFull);
+            return (int)((ex[c / FPW] >> ((c % FPW) * FB)) & FMASK);
         };
         auto load_state = [&]() {  // registers <- packed counts exA/exB and totals totA/totB
             if constexpr (H2) {
@@ -1641,8 +1689,9 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
 #pragma unroll
                 for (int k = 0; k < NW; ++k) {  // padded categories have count 0 on both sides: contribute 0
 #pragma unroll
-                    for (int f = 0; f < 4; ++f) {
-                        const int c = 4 * k + f;
+                    for (int f = 0; f < FPW; ++f) {
+                        const int c = FPW * k + f;
+                        if (c >= CMAX) continue;
                         const int ca = field(exA, c), cb = field(exB, c);
                         if constexpr (MODE == MODE_H2W) {
                             D += w_s[c] * (sqrt_cnt(ca) * sqrt_cnt(cb));
@@ -1654,7 +1703,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
                     }
                     // <= 16 slots run at 3-4 waves/SIMD on a tight register budget: one word's table look-ups in flight at a time;
                     // the larger variants (2 waves/SIMD, 256 registers) profit from every second word's being in flight together
-                    if constexpr (CMAX <= 16) __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (CMAX <= 16 || CNT8) __builtin_amdgcn_sched_barrier(0);
                     else if ((k & 1) == 1) __builtin_amdgcn_sched_barrier(0);
                 }
                 if constexpr (MODE == MODE_H2W) { ra = 1.0 / sqrt(na); rb = 1.0 / sqrt(nb); }
@@ -1678,15 +1727,21 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
                 uint64_t ea = exA[k], eb = exB[k];
                 if constexpr (!LDSCNT) asm volatile("" : "+v"(ea), "+v"(eb));
 #pragma unroll
-                for (int f = 0; f < 4; ++f) {
-                    const int c = 4 * k + f;
+                for (int f = 0; f < FPW; ++f) {
+                    const int c = FPW * k + f;
+                    if (c >= CMAX) continue;
                     int ca, cb;
                     if constexpr (LDSCNT) {
-                        ca = *reinterpret_cast<const uint16_t*>(lcl + (c >> 2) * 512 + (c & 3) * 2);
-                        cb = *reinterpret_cast<const uint16_t*>(lcl + kLcSide + (c >> 2) * 512 + (c & 3) * 2);
+                        if constexpr (CNT8) {
+                            ca = *reinterpret_cast<const uint8_t*>(lcl + k * 512 + f);
+                            cb = *reinterpret_cast<const uint8_t*>(lcl + kLcSide + k * 512 + f);
+                        } else {
+                            ca = *reinterpret_cast<const uint16_t*>(lcl + k * 512 + f * 2);
+                            cb = *reinterpret_cast<const uint16_t*>(lcl + kLcSide + k * 512 + f * 2);
+                        }
                     } else {
-                        ca = (int)((ea >> (f * 16)) & 0xFFFFull) + (int)((dA[c >> 4] >> ((c & 15) * 4)) & 15ull);
-                        cb = (int)((eb >> (f * 16)) & 0xFFFFull) + (int)((dB[c >> 4] >> ((c & 15) * 4)) & 15ull);
+                        ca = (int)((ea >> (f * FB)) & FMASK) + (int)((dA[c >> 4] >> ((c & 15) * 4)) & 15ull);
+                        cb = (int)((eb >> (f * FB)) & FMASK) + (int)((dB[c >> 4] >> ((c & 15) * 4)) & 15ull);
                     }
                     const double d = root_of(c, ca) * ra - root_of(c, cb) * rb;  // equal inputs cancel exactly
                     acc2 = fma(d, d, acc2);
@@ -1844,8 +1899,8 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
             // widen to 16-bit fields and exclusive-scan across the wavefront
 #pragma unroll
             for (int k = 0; k < NW; ++k) {
-                const uint64_t va_ = spread4(hA[(k * 4) / 16] >> (((k * 4) % 16) * 4));
-                const uint64_t vb_ = spread4(hB[(k * 4) / 16] >> (((k * 4) % 16) * 4));
+                const uint64_t va_ = CNT8 ? spread8(hA[(k * 8) / 16] >> (((k * 8) % 16) * 4)) : spread4(hA[(k * 4) / 16] >> (((k * 4) % 16) * 4));
+                const uint64_t vb_ = CNT8 ? spread8(hB[(k * 8) / 16] >> (((k * 8) % 16) * 4)) : spread4(hB[(k * 4) / 16] >> (((k * 4) % 16) * 4));
                 const uint64_t sa_ = wave_incl_scan_fields(va_), sb_ = wave_incl_scan_fields(vb_);
                 exA[k] = cntA[k] + sa_ - va_;
                 exB[k] = cntB[k] + sb_ - vb_;
@@ -1919,23 +1974,30 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
                             // counts of category ct on both sides: two 16-bit LDS reads at one address (+ an immediate for side
                             // B); the side that took the event writes its count back incremented.  LDS serves a wave's requests
                             // in order, so the next event of this lane sees the update.
+                            if constexpr (CNT8) {
+                                unsigned char* pf = lcl + ((ct >> 3) << 9) + (ct & 7);
+                                cntA_ = *pf;
+                                cntB_ = *(pf + kLcSide);
+                                *(pf + (takeA ? 0 : kLcSide)) = (unsigned char)((takeA ? cntA_ : cntB_) + 1);
+                            } else {
                             unsigned char* pf = lcl + ((ct >> 2) << 9) + ((ct & 3) << 1);
                             cntA_ = *reinterpret_cast<const uint16_t*>(pf);
                             cntB_ = *reinterpret_cast<const uint16_t*>(pf + kLcSide);
                             *reinterpret_cast<uint16_t*>(pf + (takeA ? 0 : kLcSide)) = (uint16_t)((takeA ? cntA_ : cntB_) + 1);
+                            }
                         } else {
-                        const int sh = (ct & 3) * 16, sh4 = (ct & 15) * 4;
+                        const int sh = (ct % FPW) * FB, sh4 = (ct & 15) * 4;
                         uint64_t wA = exA[0], wB = exB[0];  // (every category is inside the map: checked at the environment build)
 #pragma unroll
                         for (int k = 1; k < NW; ++k) {
-                            const bool hit = ((ct >> 2) == k);
+                            const bool hit = ((ct / FPW) == k);
                             wA = hit ? exA[k] : wA;
                             wB = hit ? exB[k] : wB;
                         }
                         uint64_t qA = dA[0], qB = dB[0];
                         if constexpr (NH == 2) { qA = (ct & 16) ? dA[1] : qA; qB = (ct & 16) ? dB[1] : qB; }
-                        cntA_ = (int)((wA >> sh) & 0xFFFFull) + (int)((qA >> sh4) & 15ull);  // before the update
-                        cntB_ = (int)((wB >> sh) & 0xFFFFull) + (int)((qB >> sh4) & 15ull);
+                        cntA_ = (int)((wA >> sh) & FMASK) + (int)((qA >> sh4) & 15ull);  // before the update
+                        cntB_ = (int)((wB >> sh) & FMASK) + (int)((qB >> sh4) & 15ull);
                         const uint64_t inc4 = 1ull << sh4;
                         if constexpr (NH == 2) {
                             dA[0] += (takeA && !(ct & 16)) ? inc4 : 0ull;
@@ -2618,7 +2680,7 @@ __global__ void k_pair_meta(SweepArgs args) {
         args.meta[p] = make_int4((int)ea, (int)eb, nA | (c0a << 24), nB | (c0b << 24));
         biggest = max(biggest, max(nA, nB));
         // pairs k_sweep_duo takes: everything that fits its tile, and the unusable ones (it writes their NaN)
-        n_small += (nA + nB - 2 <= kDuoTileFwd) ? 1 : 0;
+        n_small += (args.small_rule ? (max(nA, nB) <= kCount8MaxEnv) : (nA + nB - 2 <= kDuoTileFwd)) ? 1 : 0;
     }
     // pairs that fit one 32-lane tile: if they are the majority, k_sweep_duo sweeps them and k_sweep only the rest.  One
     // partial count per workgroup; the workgroup that finishes LAST folds them, publishes what the host wants to know into
@@ -2663,18 +2725,7 @@ void launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool helling
         else k_sweep<32, MODE_H2U, F_KEY, true, false, true><<<g, NTH, 0, s>>>(a);
         return;
     }
-    {
-        const int64_t nb = (a.n_pairs + 255) / 256;
-        const int mgrid = (int)(nb < kMetaPartials ? nb : kMetaPartials);
-        k_pair_meta<<<mgrid, 256, 0, s>>>(a);
-    }
-    if (n_categories > 32 || t.force_wide) {
-        const int fmode = (a.env_a.cdf_keys && a.env_b.cdf_keys) ? F_KEY : F_ANY;
-        if (!hellinger2) launch_sweep_wide<MODE_GEN>(s, n_categories, a.n_pairs, fmode, a);
-        else if (unit_weights) launch_sweep_wide<MODE_H2U>(s, n_categories, a.n_pairs, fmode, a);
-        else launch_sweep_wide<MODE_H2W>(s, n_categories, a.n_pairs, fmode, a);
-        return;
-    }
+    const bool wide = n_categories > 32 || t.force_wide;
     const int64_t blocks = (a.n_pairs + kSweepWaves - 1) / kSweepWaves;
     // grid-stride: LDS tables are built once per block.  8192 workgroups = 8 rounds of the 1024 that are resident at a time: finer
     // than that the table loads show, coarser the last round's imbalance does (measured on C2a: 4096 +2.8 %, 16384 +0.5 %)
@@ -2682,21 +2733,46 @@ void launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool helling
     const int cmax = std::max(n_categories, t.force_cmax);  // (force_cmax: test hook)
     const bool small = a.env_a.stride <= kSqrtTab && a.env_b.stride <= kSqrtTab && !t.force_bigenv;  // every count fits the LDS tables
     const int fmode = (a.env_a.cdf_keys && a.env_b.cdf_keys) ? F_KEY : (wf_pow ? F_ANY : F_FAST);
-    if (hellinger2 && unit_weights && small && fmode == F_KEY && cmax <= 16 && !a.wf_index && !t.no_duo) {
-        // small environments: two pairs per wavefront.  Without a hint both kernels and the plain sweep are launched and the
-        // number of small pairs (k_pair_meta) decides on the device which of them do the work; with the hint of the previous
-        // pass only the kernels that will work are launched.
+    // Two kernels for "small" pairs exist for the default configuration (Hellinger-2, unit weights, CDF-keyed environments):
+    // k_sweep_duo (two pairs of <= 224 merged events per wavefront, <= 16 category slots) and the 8-bit-count k_sweep (both
+    // environments <= 255 points, more than 16 slots); the INDIRECT 16-bit k_sweep takes what they leave over.
+    const bool fast_cfg = !wide && hellinger2 && unit_weights && small && fmode == F_KEY && !a.wf_index;
+    const bool use_duo = fast_cfg && cmax <= 16 && !t.no_duo, use_c8 = fast_cfg && cmax > 16 && !t.no_count8;
+    a.small_rule = use_c8 ? 1 : 0;
+    {
+        const int64_t nb = (a.n_pairs + 255) / 256;
+        const int mgrid = (int)(nb < kMetaPartials ? nb : kMetaPartials);
+        k_pair_meta<<<mgrid, 256, 0, s>>>(a);
+    }
+    if (wide) {
+        const int fm = (a.env_a.cdf_keys && a.env_b.cdf_keys) ? F_KEY : F_ANY;
+        if (!hellinger2) launch_sweep_wide<MODE_GEN>(s, n_categories, a.n_pairs, fm, a);
+        else if (unit_weights) launch_sweep_wide<MODE_H2U>(s, n_categories, a.n_pairs, fm, a);
+        else launch_sweep_wide<MODE_H2W>(s, n_categories, a.n_pairs, fm, a);
+        return;
+    }
+    if (use_duo || use_c8) {
+        // Without a hint the small-pair kernel, its companion and the plain sweep are all launched and the number of small
+        // pairs (k_pair_meta) decides on the device which of them do the work; with the hint of the previous pass only the
+        // kernels that will work are launched.
         const int hint = t.no_sweep_hint ? 0 : sweep_hint;
         a.forced = hint != 0;
         if (hint != 2) {
             a.duo_enabled = 1;
-            const int64_t dblocks = (a.n_pairs + 2 * kSweepWaves - 1) / (2 * kSweepWaves);
-            const unsigned dgrid = (unsigned)(dblocks < 8192 ? dblocks : 8192);
             const unsigned bgrid = grid < 1024 ? grid : 1024;  // the listed (larger) pairs are a minority whenever this launch does anything
             constexpr int NTH = 64 * kSweepWaves;
-            if (cmax <= 8) { k_sweep_duo<8><<<dgrid, NTH, 0, s>>>(a); k_sweep<8, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
-            else if (cmax <= 12) { k_sweep_duo<12><<<dgrid, NTH, 0, s>>>(a); k_sweep<12, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
-            else { k_sweep_duo<16><<<dgrid, NTH, 0, s>>>(a); k_sweep<16, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+            if (use_duo) {
+                const int64_t dblocks = (a.n_pairs + 2 * kSweepWaves - 1) / (2 * kSweepWaves);
+                const unsigned dgrid = (unsigned)(dblocks < 8192 ? dblocks : 8192);
+                if (cmax <= 8) { k_sweep_duo<8><<<dgrid, NTH, 0, s>>>(a); k_sweep<8, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+                else if (cmax <= 12) { k_sweep_duo<12><<<dgrid, NTH, 0, s>>>(a); k_sweep<12, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+                else { k_sweep_duo<16><<<dgrid, NTH, 0, s>>>(a); k_sweep<16, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+            } else {
+                if (cmax <= 20) { k_sweep<20, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); k_sweep<20, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+                else if (cmax <= 24) { k_sweep<24, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); k_sweep<24, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+                else if (cmax <= 28) { k_sweep<28, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); k_sweep<28, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+                else { k_sweep<32, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); k_sweep<32, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+            }
             if (hint == 1) return;
         }
     }

@@ -338,6 +338,38 @@ def test_small_pair_kernel_with_a_minority_of_large_pairs(lh, oracle, monkeypatc
         assert np.max(np.abs(got - plain)) < 1e-13 and np.max(np.abs(inline - plain)) < 1e-13
 
 
+def test_eight_bit_count_sweep_with_a_minority_of_large_environments(lh, oracle, monkeypatch):
+    """More than 16 category slots: pairs whose environments both have <= 255 points go to the 8-bit-count k_sweep, the
+    others to the INDIRECT 16-bit instantiation.  A cloud at protein-like density with one dense blob gives both kinds in one
+    call (and environments of exactly 255 / 256 points sit on the boundary); a mostly dense cloud makes the large pairs the
+    majority, where the plain kernel does everything.  Against the oracle and against the call with the 8-bit kernel disabled."""
+    monkeypatch.setenv("LCHD_NO_INLINE_META", "1")
+    rng = np.random.default_rng(27)
+    for ncat in (17, 25, 32):
+        cats = [f"k{i}" for i in range(ncat)]
+        for n_sparse, n_dense, expect_small_majority in ((4000, 500, True), (300, 1200, False)):
+            def cloud():
+                pts = np.concatenate([rng.uniform(0, 43, (n_sparse, 3)), rng.normal(21, 2.6, (n_dense, 3))])
+                return rng.integers(0, ncat, len(pts)).astype(np.int32), pts
+
+            (ca, xa), (cb, xb) = cloud(), cloud()
+            n = len(xa)
+            pairs = np.stack([np.arange(n), rng.permutation(n)], 1).astype(np.int64)
+            tag = np.zeros(n, dtype=np.int32)
+            lo = oracle.LoCoHD(cats, oracle.WeightFunction("hyper_exp", [1.0, 0.2]))
+            want, sizes = lo.from_arrays(xa, ca, tag, xb, cb, tag, pairs, 10.0, return_env_sizes=True)
+            want, sizes = np.asarray(want), np.asarray(sizes)
+            small = np.mean(sizes.max(axis=1) <= 255)
+            assert (small >= 0.5) == expect_small_majority and 0.02 < small < 0.98, small
+            pk = lambda x, c: lh.api._Packed(x, c, tag)
+            got = lh.LoCoHD(cats, lh.WeightFunction("hyper_exp", [1.0, 0.2])).from_packed(pk(xa, ca), pk(xb, cb), pairs, 10.0)
+            assert np.max(np.abs(got - want)) < TIGHT, (ncat, n_dense)
+            monkeypatch.setenv("LCHD_NO_COUNT8", "1")
+            plain = lh.LoCoHD(cats, lh.WeightFunction("hyper_exp", [1.0, 0.2])).from_packed(pk(xa, ca), pk(xb, cb), pairs, 10.0)
+            monkeypatch.delenv("LCHD_NO_COUNT8")
+            assert np.max(np.abs(got - plain)) < 1e-13
+
+
 def test_sweep_hint_follows_the_workload(lh, oracle, monkeypatch):
     """One context scores workloads whose pair sizes flip between 'mostly small' and 'mostly large': the first pass launches
     every candidate sweep kernel and lets the device decide, later passes launch what the PREVIOUS pass's outcome suggests
