@@ -256,6 +256,7 @@ static Tuning tuning_from_env() {  // the ONLY place that reads LCHD_* hooks (te
     t.no_sweep_hint = getenv("LCHD_NO_SWEEP_HINT") != nullptr;
     t.no_inline_meta = getenv("LCHD_NO_INLINE_META") != nullptr;
     t.no_count8 = getenv("LCHD_NO_COUNT8") != nullptr;
+    t.old_rows = getenv("LCHD_OLD_ROWS") != nullptr;
     t.no_tables = getenv("LCHD_NO_SD_TABLES") != nullptr;
     t.force_cmax = env_int("LCHD_FORCE_CMAX", 0);
     t.cap_hint = env_int("LCHD_CAP_HINT", 0);
@@ -395,21 +396,33 @@ extern "C" int lchd_ctx_set_config(lchd_ctx* c, const lchd_config* cfg) {
         if (int rc = lchd_wf_validate(w.kind, w.params, w.n_params)) return rc;
         n_params += (size_t)w.n_params;
     }
-    // blob: [cat_w][wf entries][wf params][F(+inf) per wf][tag pairs]
+    // blob: [cat_w][wf entries][wf params][F(+inf) per wf][reciprocal of the CDF's constant divisor per wf][tag pairs]
     const size_t o_w = 0, o_e = o_w + sizeof(double) * C, o_p = o_e + sizeof(WfEntry) * cfg->n_weight_functions;
-    const size_t o_f = o_p + sizeof(double) * n_params, o_t = o_f + sizeof(double) * cfg->n_weight_functions;
+    const size_t o_f = o_p + sizeof(double) * n_params, o_i = o_f + sizeof(double) * cfg->n_weight_functions;
+    const size_t o_t = o_i + sizeof(double) * cfg->n_weight_functions;
     const size_t total = o_t + sizeof(uint64_t) * (size_t)cfg->n_tag_pairs;
     std::vector<char> blob(total + 8);
     memcpy(blob.data() + o_w, cfg->category_weights, sizeof(double) * C);
     WfEntry* ent = reinterpret_cast<WfEntry*>(blob.data() + o_e);
     double* prm = reinterpret_cast<double*>(blob.data() + o_p);
     double* finf = reinterpret_cast<double*>(blob.data() + o_f);
+    double* winv = reinterpret_cast<double*>(blob.data() + o_i);
     int off = 0;
     for (int i = 0; i < cfg->n_weight_functions; ++i) {
         const lchd_weight_function& w = cfg->weight_functions[i];
         ent[i] = WfEntry{w.kind, w.n_params, off, 0};
         memcpy(prm + off, w.params, sizeof(double) * w.n_params);
         finf[i] = cdf_eval(w.kind, w.params, w.n_params, (double)INFINITY);
+        // hyper_exp divides by sum_i a_i, uniform / kumaraswamy by (x_max - x_min) (cdfs.rs:15-20,44,61): constants of the
+        // weight function, so the kernels multiply by the reciprocal (<= 1 ulp from the quotient) instead of dividing per point
+        winv[i] = 1.0;
+        if (w.kind == LCHD_WF_HYPER_EXP) {
+            double norm = 0.0;
+            for (int k = 0; k < w.n_params / 2; ++k) norm += w.params[k];
+            winv[i] = 1.0 / norm;
+        } else if (w.kind == LCHD_WF_UNIFORM || w.kind == LCHD_WF_KUMARASWAMY) {
+            winv[i] = 1.0 / (w.params[1] - w.params[0]);
+        }
         off += w.n_params;
     }
     uint64_t* tp = reinterpret_cast<uint64_t*>(blob.data() + o_t);
@@ -449,6 +462,7 @@ extern "C" int lchd_ctx_set_config(lchd_ctx* c, const lchd_config* cfg) {
     h.wf = reinterpret_cast<const WfEntry*>(c->d_blob + o_e);
     h.wf_params = reinterpret_cast<const double*>(c->d_blob + o_p);
     h.wf_finf = reinterpret_cast<const double*>(c->d_blob + o_f);
+    h.wf_inv = reinterpret_cast<const double*>(c->d_blob + o_i);
     h.tag_pairs = reinterpret_cast<const uint64_t*>(c->d_blob + o_t);
     HIP_TRY(hipMemcpy(c->d_cfg, &h, sizeof h, hipMemcpyHostToDevice));
     c->h_cfg = h;
@@ -1451,7 +1465,7 @@ extern "C" int lchd_unshard_scores_dev(lchd_ctx* c, const double* d_gathered, co
 // Shared tail of from_anchors / from_dmxs / from_coords: environments are already sorted in `ea`/`eb`
 // (one per row), pair p = (row p, row p).
 static int sweep_rows(lchd_ctx* c, const EnvStore& ea, const EnvStore& eb, const int32_t* d_wf, int64_t rows, double* d_out,
-                      int4* d_meta, Driver drv) {
+                      int4* d_meta, Driver drv, uint32_t* flags_out = nullptr) {
     SweepArgs sw{};
     fill_sweep_args(c, sw);
     sw.env_a = ea;
@@ -1467,6 +1481,8 @@ static int sweep_rows(lchd_ctx* c, const EnvStore& ea, const EnvStore& eb, const
     uint32_t f = 0;
     if (int rc = wait_pass(c, &f)) return rc;
     collect_times(c, 2, 4);
+    if (flags_out) *flags_out = f;
+    if (f & ST_ROW_RETRY) return LCHD_OK;  // the caller repeats the pass with the other row kernel
     return status_to_rc(f, drv);
 }
 
@@ -1490,7 +1506,8 @@ static int dense_driver(lchd_ctx* c, const lchd_config* cfg, const int32_t* seq_
     int rc = lchd_cloud_create(c, xyz_a, seq_a, nullptr, cols_a, &a);
     if (!rc) rc = lchd_cloud_create(c, xyz_b, seq_b, nullptr, cols_b, &b);
     if (rc) { lchd_cloud_destroy(c, a); lchd_cloud_destroy(c, b); return rc; }
-    auto body = [&]() -> int {
+    auto body = [&](bool old_rows, bool& retry) -> int {
+        retry = false;
         EnvStore ea{}, eb{};
         double *d_ma = nullptr, *d_mb = nullptr, *d_out = nullptr;
         int32_t* d_wf = nullptr;
@@ -1529,15 +1546,21 @@ static int dense_driver(lchd_ctx* c, const lchd_config* cfg, const int32_t* seq_
             for (int k = 0; k < 3; ++k) { const double e = cl->bbmax[k] - cl->bbmin[k]; s2 += e * e; }
             return s2 * (1.0 + 1e-9) + 1e-300;
         };
-        if (!launch_env_rows(s, cap_a, c->d_cfg, a->view(), d_ma, cols_a, rows, cols_a, diag2(a), ea, c->d_status) ||
-            !launch_env_rows(s, cap_b, c->d_cfg, b->view(), d_mb, cols_b, rows, cols_b, diag2(b), eb, c->d_status))
-            return fail(LCHD_EUNSUPPORTED, "no dense environment kernel for this row length");
+        const RowSide rsa{a->view(), d_ma, cols_a, cols_a, diag2(a), ea}, rsb{b->view(), d_mb, cols_b, cols_b, diag2(b), eb};
+        if (old_rows || !launch_env_rows2(s, c->d_cfg, rsa, rsb, rows, c->d_status))  // (rows beyond 20480 points: keys sorted in global memory)
+            if (!launch_env_rows(s, cap_a, c->d_cfg, a->view(), d_ma, cols_a, rows, cols_a, diag2(a), ea, c->d_status) ||
+                !launch_env_rows(s, cap_b, c->d_cfg, b->view(), d_mb, cols_b, rows, cols_b, diag2(b), eb, c->d_status))
+                return fail(LCHD_EUNSUPPORTED, "no dense environment kernel for this row length");
         mark(c, 3);
-        if (int rc2 = sweep_rows(c, ea, eb, wf_index ? d_wf : nullptr, rows, d_out, d_meta, DRV_DMXS)) return rc2;
+        uint32_t f = 0;
+        if (int rc2 = sweep_rows(c, ea, eb, wf_index ? d_wf : nullptr, rows, d_out, d_meta, DRV_DMXS, &f)) return rc2;
+        if (f & ST_ROW_RETRY) { retry = true; return LCHD_OK; }
         HIP_TRY(hipMemcpy(out, d_out, sizeof(double) * rows, hipMemcpyDeviceToHost));
         return LCHD_OK;
     };
-    rc = body();
+    bool retry = false;
+    rc = body(c->tune.old_rows, retry);
+    if (!rc && retry) rc = body(true, retry);  // a row defeated the segmented in-LDS sort: the global-memory row sort takes the call
     lchd_cloud_destroy(c, a);
     lchd_cloud_destroy(c, b);
     return rc;

@@ -22,6 +22,7 @@ enum : uint32_t {
     ST_ZERO_NORM = 1u << 5,       // PMF norm 0                                 (reference: ValueError, pmf.rs:70-76)
     ST_BAD_DISTANCE = 1u << 6,    // negative / NaN distance in a matrix row    (reference: ValueError / panic)
     ST_BAD_WF = 1u << 7,          // weight-function index outside the table
+    ST_ROW_RETRY = 1u << 8,       // a dense row of more than 16384 points defeated the segmented sort: repeat the call with k_env_rows
 };
 // Device-resident status of a pass.  Invariant between passes: flags == max_env == 0 -- the last workgroup of
 // k_pair_meta copies the words the host needs into the host-mapped HostStatus and resets them, so a pass needs neither a
@@ -57,6 +58,7 @@ struct Tuning {
     bool force_bigenv = false;      // LCHD_FORCE_BIGENV: the !LDSTAB sweep instantiations
     bool no_sweep_hint = false;     // LCHD_NO_SWEEP_HINT: always launch all three sweep kernels and let the device decide
     bool no_inline_meta = false;    // LCHD_NO_INLINE_META: small calls also run k_pair_meta + the regular sweep kernels
+    bool old_rows = false;          // LCHD_OLD_ROWS: dense rows through k_env_rows (three distance passes) for every length
     bool no_count8 = false;         // LCHD_NO_COUNT8: never the 8-bit-count sweep
     bool no_tables = false;         // LCHD_NO_SD_TABLES: generic distances without the per-launch power / log tables
     int force_cmax = 0;             // LCHD_FORCE_CMAX: at least this many category slots
@@ -79,6 +81,7 @@ struct DevConfig {
     const WfEntry* wf;          // [n_wf]
     const double* wf_params;    // concatenated
     const double* wf_finf;      // [n_wf] F(+inf) per weight function (host-evaluated; 1.0 except for degenerate dagum)
+    const double* wf_inv;       // [n_wf] 1 / (the CDF's constant divisor): 1 / sum a_i (hyper_exp), 1 / (x_max - x_min) (uniform, kumaraswamy)
     const uint64_t* tag_pairs;  // sorted, (anchor_tag << 32) | neighbour_tag
 };
 
@@ -179,6 +182,21 @@ struct DoneState {
     uint32_t acc_max[64 * 32];
     unsigned long long acc_sum[64 * 16];
 };
+// one side of a dense-row launch (lchd_kernels.hip: k_env_rows2 builds both structures' rows in one launch)
+struct RowSide {
+    CloudView c;           // categories (and coordinates when dmx == nullptr)
+    const double* dmx;     // given distance rows [n_rows][ld], or nullptr: distances from the coordinates of c
+    int64_t ld, row_len;
+    double image_bound;    // coordinates: >= largest squared distance (bounding-box diagonal^2); ignored for given rows
+    EnvStore env;
+};
+struct RowSides {
+    RowSide s[2];
+    int64_t n_rows;
+};
+// rows of at most 16384 points on both sides; returns false (nothing launched) otherwise
+bool launch_env_rows2(hipStream_t s, const DevConfig* cfg, const RowSide& a, const RowSide& b, int64_t n_rows, DeviceStatus* st);
+
 struct SweepArgs {
     const DevConfig* cfg;
     EnvStore env_a, env_b;

@@ -576,9 +576,20 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t* key, uint8_t* val, in
 
 // hyper_exp and uniform are the common weight functions and stay inline; the pow-based CDFs are called.
 __device__ __noinline__ double cdf_pow_based(int kind, const double* p, int np, double x) { return cdf_eval(kind, p, np, x); }
-__device__ __forceinline__ double cdf_lean(int kind, const double* __restrict__ p, int np, double x) {
-    if (kind == WF_HYPER_EXP) return cdf_hyper_exp(p, np, x);
-    if (kind == WF_UNIFORM) return cdf_uniform(p, x);
+// `inv` = DevConfig::wf_inv of the weight function: the reciprocal of the CDF's constant divisor (<= 1 ulp from the
+// reference's quotient; an f64 division costs about as much as half the exponential)
+__device__ __forceinline__ double cdf_lean(int kind, const double* __restrict__ p, int np, double inv, double x) {
+    if (kind == WF_HYPER_EXP) {  // cdfs.rs:5-21, same accumulation order
+        double sum = 0.0;
+        const int n = np / 2;
+        for (int i = 0; i < n; ++i) sum += p[i] * exp(-p[n + i] * x);
+        return 1.0 - sum * inv;
+    }
+    if (kind == WF_UNIFORM) {  // cdfs.rs:39-45
+        if (x < p[0]) return 0.0;
+        if (x > p[1]) return 1.0;
+        return (x - p[0]) * inv;
+    }
     return cdf_pow_based(kind, p, np, x);
 }
 
@@ -590,10 +601,11 @@ template <int NT>
 __device__ __forceinline__ void keys_to_cdf_lds(uint64_t* key, int n, int tid, const DevConfig* __restrict__ cfg) {
     const WfEntry wf = cfg->wf[0];
     const double* __restrict__ prm = cfg->wf_params + wf.offset;
+    const double winv = cfg->wf_inv[0];
     const int chunk = (n + NT - 1) / NT, lo = min(tid * chunk, n), hi = min(lo + chunk, n);
     uint64_t m = 0;
     for (int i = lo; i < hi; ++i) {
-        const uint64_t f = d2u(cdf_lean(wf.kind, prm, wf.n_params, u2d(key[i])) + 0.0);
+        const uint64_t f = d2u(cdf_lean(wf.kind, prm, wf.n_params, winv, u2d(key[i])) + 0.0);
         m = f > m ? f : m;
         key[i] = m;
     }
@@ -622,7 +634,8 @@ __device__ __forceinline__ void keys_to_cdf_lds(uint64_t* key, int n, int tid, c
 __device__ __forceinline__ void keys_to_cdf_wave(uint64_t* key, int n, int lane, const DevConfig* __restrict__ cfg) {
     const WfEntry wf = cfg->wf[0];
     const double* __restrict__ prm = cfg->wf_params + wf.offset;
-    for (int i = lane; i < n; i += 64) key[i] = d2u(cdf_lean(wf.kind, prm, wf.n_params, u2d(key[i])) + 0.0);
+    const double winv = cfg->wf_inv[0];
+    for (int i = lane; i < n; i += 64) key[i] = d2u(cdf_lean(wf.kind, prm, wf.n_params, winv, u2d(key[i])) + 0.0);
     __syncthreads();
     bool inv = false;
     for (int i = lane; i < n; i += 64) inv = inv || (i > 0 && key[i] < key[i - 1]);
@@ -1008,6 +1021,7 @@ bool launch_env_cells(hipStream_t s, int cap, const DevConfig* cfg, bool tag_lis
 // Dynamic LDS: n2 * 9 bytes.
 // ------------------------------------------------------------------------------------------------
 constexpr int kRowBucketsSmall = 2048;   // distance buckets of the dense-row sort (rows <= 16384 points)
+constexpr int kRowBucketsMax = 8192;     // ... of k_env_rows2 when the row leaves room for them
 constexpr int kRowBucketsBig = 16384;    // ... for rows of up to 65535 points (keys stay in global memory)
 constexpr int kRowCoarse = 256;       // uniform bins of the row's empirical distance CDF
 constexpr int kRowBucketLimit = 64;   // a fuller bucket sends the row to the bitonic network instead
@@ -1183,6 +1197,313 @@ __global__ __launch_bounds__(NT) void k_env_rows(const DevConfig* __restrict__ c
         }
         if (__ballot(bad_c) && (tid & 63) == 0) atomicOr(&st->flags, ST_BAD_CATEGORY);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 (dense), rows of at most 16 384 points: the same bucket sort with every point's distance image computed ONCE and held
+// in registers (EPT points per thread), one LDS atomic per histogram, a scatter without atomics (bucket start + the slot
+// the histogram atomic returned), and the last step done by ALL threads: every point ranks itself among the handful of
+// members of its bucket on the exact f64 key, then writes its (CDF-converted) key to its final place.  (k_env_rows
+// recomputes the distances in three passes and finishes the buckets with one thread each -- 3.6 ms for the 2 x 10^4 rows
+// of two 10^4-atom structures; this kernel builds both structures' rows in one launch.)
+// Dynamic LDS: n2 * 9 bytes (keys, categories) + the bucket histogram.
+// ------------------------------------------------------------------------------------------------
+constexpr int kRowSegCap = 14272;  // rows of more than 16384 points: most points of one distance segment (keys in LDS)
+template <int NT, int EPT, int NSEG>  // NSEG: distance segments the row is sorted in (2 for rows of more than 16384 points)
+__global__ __launch_bounds__(NT, 4) void k_env_rows2(const DevConfig* __restrict__ cfgp, RowSides sides, int n2, DeviceStatus* st) {
+    constexpr int n_seg = NSEG;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* key = reinterpret_cast<uint64_t*>(smem);
+    uint8_t* val = smem + (size_t)n2 * 8;
+    __shared__ double red_max[NT / 64];
+    __shared__ uint32_t red_cnt[NT / 64];
+    __shared__ uint32_t seg_tot[kRowBucketsMax / 64 + 1];
+    __shared__ uint32_t coarse[kRowCoarse + 1], cum[kRowCoarse + 1];
+    __shared__ uint32_t seg_n_s;
+    __shared__ uint64_t carry_key_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int side = (int64_t)blockIdx.x >= sides.n_rows ? 1 : 0;
+    const RowSide& S = sides.s[side];
+    const int64_t r = (int64_t)blockIdx.x - (side ? sides.n_rows : 0);
+    const CloudView c = S.c;
+    const EnvStore env = S.env;
+    const int n = (int)S.row_len;
+    // Buckets: as many as fit (up to kRowBucketsMax, ~1 point per bucket: the ranking step reads a bucket's members once
+    // per member).  The histogram lives in the part of the key array the row (or distance segment) does not need -- the
+    // array is sized for the bitonic fallback, a power of two --, or behind the categories when the row fills it.
+    int NB = kRowBucketsSmall;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem + (size_t)n2 * 9 + ((16 - (((size_t)n2 * 9) & 15)) & 15));  // [NB + 1]
+    if (n_seg > 1) {
+        NB = 4096;
+        hist = reinterpret_cast<uint32_t*>(key + kRowSegCap);
+    } else {
+        const int nk = (n + 63) & ~63;
+        while (NB > 64 && NB >= 4 * nk) NB >>= 1;  // short rows: no more than ~2 buckets per point
+        for (int cand = kRowBucketsMax; cand > kRowBucketsSmall; cand >>= 1)
+            if (cand <= 2 * nk && (size_t)(n2 - nk) * 8 >= (size_t)(cand + 1) * 4) {
+                NB = cand;
+                hist = reinterpret_cast<uint32_t*>(key + nk);
+                break;
+            }
+    }
+    const double* __restrict__ row = S.dmx ? S.dmx + r * S.ld : nullptr;
+    double ax = 0.0, ay = 0.0, az = 0.0;
+    if (!row) { ax = c.x[r]; ay = c.y[r]; az = c.z[r]; }
+#ifdef LCHD_SWEEP_STAMPS
+    unsigned long long estamp_last = __builtin_amdgcn_s_memtime();
+#endif
+
+    // 1. the distance image of this thread's points (d^2 for coordinates, utils.rs:1-8 order, uncontracted; the distance
+    //    itself for a given row) and their categories (four to a register).  Point i = tid + q * NT: coalesced.
+    double m[EPT];
+    uint32_t ct4[(EPT + 3) / 4];
+#pragma unroll
+    for (int q = 0; q < (EPT + 3) / 4; ++q) ct4[q] = 0u;
+    bool bad = false;
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int i = tid + q * NT;
+        const int ii = i < n ? i : 0;
+        ct4[q >> 2] |= (uint32_t)c.cat[ii] << ((q & 3) * 8);
+        if (row) {
+            double v = row[ii];
+            if (i < n && !(v >= 0.0)) { bad = true; v = 0.0; }  // negative or NaN
+            m[q] = v + 0.0;                                      // -0.0 -> +0.0
+        } else {
+            const double dx = ax - c.x[ii], dy = ay - c.y[ii], dz = az - c.z[ii];
+            double d2 = dx * dx;
+            d2 = d2 + dy * dy;
+            d2 = d2 + dz * dz;
+            m[q] = d2;
+        }
+    }
+    auto cat_of = [&](int q) -> uint8_t { return (uint8_t)(ct4[q >> 2] >> ((q & 3) * 8)); };  // q static
+    if (__ballot(bad) && lane == 0) atomicOr(&st->flags, ST_BAD_DISTANCE);
+    ESTAMP(0);
+    // largest finite image -- or, for coordinates, the caller's bound (squared diagonal of the bounding box): any upper
+    // bound will do, the empirical CDF below adapts the buckets to wherever the points really are
+    double dmax = S.image_bound > 0.0 ? S.image_bound : 0.0;
+    if (!(S.image_bound > 0.0)) {
+#pragma unroll
+        for (int q = 0; q < EPT; ++q)
+            if (tid + q * NT < n && m[q] < 1.0e300 && m[q] > dmax) dmax = m[q];
+        for (int k = 32; k > 0; k >>= 1) dmax = fmax(dmax, shfl_xor_f64(dmax, k));
+        if (lane == 0) red_max[wave] = dmax;
+    }
+    for (int b = tid; b <= kRowCoarse; b += NT) coarse[b] = 0u;
+    if (tid == 0) carry_key_s = 0ull;
+    __syncthreads();
+    if (!(S.image_bound > 0.0))
+        for (int w = 0; w < NT / 64; ++w) dmax = fmax(dmax, red_max[w]);
+    // 2. empirical CDF of the row on kRowCoarse uniform bins of [0, dmax]
+    const double inv_w = dmax > 0.0 ? (double)kRowCoarse / dmax : 0.0;
+#pragma unroll
+    for (int q = 0; q < EPT; ++q)
+        if (tid + q * NT < n && m[q] <= dmax) atomicAdd(&coarse[min((int)(m[q] * inv_w), kRowCoarse - 1)], 1u);
+    __syncthreads();
+    if (wave == 0) {  // cum[b] = points below bin b
+        uint32_t carry = 0;
+        for (int base = 0; base < kRowCoarse; base += 64) {
+            const uint32_t v = coarse[base + lane];
+            const uint32_t incl = wave_incl_scan_u32(v);
+            cum[base + lane] = carry + incl - v;
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        if (lane == 0) cum[kRowCoarse] = carry;
+    }
+    __syncthreads();
+    ESTAMP(1);
+    const DevConfig cfg = *cfgp;
+    const WfEntry wf = cfg.wf[0];
+    const double* __restrict__ prm = cfg.wf_params + wf.offset;
+    const double winv = cfg.wf_inv[0];
+    const int NBT = NB * n_seg;  // buckets of the whole row; distance segment sg owns buckets [sg * NB, (sg + 1) * NB)
+    const double rank_scale = n > 0 ? (double)NBT / (double)n : 0.0;
+    uint64_t* ok_ = env.key + r * env.stride;
+    uint8_t* oc_ = env.cat + r * env.stride;
+    bool bad_c = false;
+    int seg_base = 0;
+#pragma unroll
+    for (int sg = 0; sg < NSEG; ++sg) {
+        for (int b = tid; b <= NB; b += NT) hist[b] = 0u;
+        __syncthreads();
+        // 3. interpolated rank -> one of NBT balanced buckets; the histogram atomic returns the point's slot inside its bucket
+        uint32_t bs[EPT];  // bucket | slot << 13; ~0 = not in this segment
+        uint32_t biggest = 0;
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            bs[q] = ~0u;
+            if (tid + q * NT < n && m[q] >= 0.0) {  // (a point an earlier segment has placed carries -1)
+                int gb = NBT - 1;  // +inf entries of a distance matrix
+                if (m[q] <= dmax) {
+                    const double t = m[q] * inv_w;
+                    const int bin = min((int)t, kRowCoarse - 1);
+                    const double frac = fmin(t - (double)bin, 1.0);
+                    const double qq = ((double)cum[bin] + frac * (double)coarse[bin]) * rank_scale;
+                    gb = qq < (double)NBT ? (int)qq : NBT - 1;
+                }
+                const int b = gb - sg * NB;
+                if (b >= 0 && b < NB) {
+                    const uint32_t slot = atomicAdd(&hist[b], 1u);
+                    bs[q] = (uint32_t)b | (slot << 13);
+                    biggest = max(biggest, slot + 1u);
+                }
+            }
+        }
+        for (int k = 32; k > 0; k >>= 1) biggest = max(biggest, (uint32_t)__shfl_xor((int)biggest, k));
+        if (lane == 0) red_cnt[wave] = biggest;
+        __syncthreads();
+        for (int w = 0; w < NT / 64; ++w) biggest = max(biggest, red_cnt[w]);
+        __syncthreads();
+        ESTAMP(2);
+        if (biggest > (uint32_t)kRowBucketLimit) {
+            if (n_seg > 1) {  // (rows of more than 16384 points have no in-LDS fallback: the host repeats the call with k_env_rows)
+                if (tid == 0) { atomicOr(&st->flags, ST_ROW_RETRY); env.len[r] = 0; }
+                return;
+            }
+            // a pathological row (thousands of identical distances): the bitonic network on the exact keys
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) {
+                const int i = tid + q * NT;
+                if (i < n) { key[i] = d2u(row ? m[q] : sqrt(m[q])); val[i] = cat_of(q); }
+            }
+            for (int i = n + tid; i < n2; i += NT) { key[i] = kPadKey; val[i] = 0; }
+            __syncthreads();
+            bitonic_sort_lds<NT>(key, val, n2, tid);
+            if (tid == 0 && n > 0 && key[0] != 0ull) atomicOr(&st->flags, ST_FIRST_NOT_ZERO);  // src/locohd.rs:74-77
+            __syncthreads();
+            if (env.cdf_keys) keys_to_cdf_lds<NT>(key, n, tid, cfgp);
+            if (tid == 0) seg_n_s = (uint32_t)n;
+            __syncthreads();
+        } else {
+            // 4. exclusive scan in segments of 64 buckets (one wavefront scan each), then of the segment totals: afterwards
+            //    the first slot of bucket b is hist[b] + seg_tot[b >> 6]
+            const int n_grp = NB >> 6;
+            for (int gq = wave; gq < n_grp; gq += NT / 64) {
+                const uint32_t v = hist[gq * 64 + lane];
+                const uint32_t incl = wave_incl_scan_u32(v);
+                hist[gq * 64 + lane] = incl - v;
+                if (lane == 63) seg_tot[gq] = incl;
+            }
+            __syncthreads();
+            if (wave == 0) {
+                uint32_t carry = 0;
+                for (int base = 0; base < n_grp; base += 64) {
+                    const uint32_t v = base + lane < n_grp ? seg_tot[base + lane] : 0u;
+                    const uint32_t incl = wave_incl_scan_u32(v);
+                    if (base + lane < n_grp) seg_tot[base + lane] = carry + incl - v;
+                    carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                }
+                if (lane == 0) seg_n_s = carry;
+            }
+            __syncthreads();
+            const int seg_n = (int)seg_n_s;
+            if (n_seg > 1 && seg_n > kRowSegCap) {  // the empirical CDF balanced the segments badly: see above
+                if (tid == 0) { atomicOr(&st->flags, ST_ROW_RETRY); env.len[r] = 0; }
+                return;
+            }
+            ESTAMP(3);
+            // 5. scatter (no atomics): position = bucket start + slot; the exact distance replaces the image in the register
+#pragma unroll
+            for (int q = 0; q < EPT; ++q)
+                if (bs[q] != ~0u) {
+                    const uint32_t b = bs[q] & 8191u, pos = hist[b] + seg_tot[b >> 6] + (bs[q] >> 13);
+                    if (!row) m[q] = sqrt(m[q]);  // utils.rs:1-8
+                    key[pos] = d2u(m[q]);
+                    bs[q] = b | (pos << 13);
+                }
+            __syncthreads();
+            ESTAMP(4);
+            // 6. every point ranks itself among the members of its bucket on the exact key (ties: by position); four members
+            //    per step, their LDS reads in flight together (a bucket holds one or two points on average)
+#pragma unroll
+            for (int q = 0; q < EPT; ++q)
+                if (bs[q] != ~0u) {
+                    const uint32_t b = bs[q] & 8191u, pos = bs[q] >> 13;
+                    const uint32_t lo = hist[b] + seg_tot[b >> 6];
+                    const uint32_t hi = b + 1 < (uint32_t)NB ? hist[b + 1] + seg_tot[(b + 1) >> 6] : (uint32_t)seg_n;
+                    const uint64_t mine = d2u(m[q]);
+                    uint32_t rank = lo;
+                    for (uint32_t j = lo; j < hi; j += 4) {
+                        uint64_t kj[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) kj[u] = key[min(j + u, hi - 1)];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            rank += (j + u < hi) & ((kj[u] < mine) | ((kj[u] == mine) & (j + u < pos)));
+                    }
+                    bs[q] = rank;
+                }
+            __syncthreads();
+            ESTAMP(5);
+            // 7. final placement, keys converted to F(distance) for single-weight-function configurations
+            bool nz = false;
+#pragma unroll
+            for (int q = 0; q < EPT; ++q)
+                if (bs[q] != ~0u) {
+                    const uint32_t rank = bs[q];
+                    nz |= (sg == 0 && rank == 0u && m[q] != 0.0);  // src/locohd.rs:74-77, on the distance
+                    key[rank] = env.cdf_keys ? d2u(cdf_lean(wf.kind, prm, wf.n_params, winv, m[q]) + 0.0) : d2u(m[q]);
+                    val[rank] = cat_of(q);
+                    m[q] = -1.0;  // placed: the later segments skip it
+                }
+            if (__ballot(nz) && lane == 0) atomicOr(&st->flags, ST_FIRST_NOT_ZERO);
+            __syncthreads();
+            if (env.cdf_keys) {  // F is monotone; a last-bit inversion of its floating-point evaluation is repaired by a running maximum
+                bool inv = false;
+                for (int i = tid; i < seg_n; i += NT) inv |= key[i] < (i ? key[i - 1] : carry_key_s);
+                if (__syncthreads_or(inv ? 1 : 0)) {
+                    if (tid == 0) {
+                        uint64_t mx = carry_key_s;
+                        for (int i = 0; i < seg_n; ++i) { mx = key[i] > mx ? key[i] : mx; key[i] = mx; }
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        ESTAMP(6);
+        {   // 8. write-out; categories outside the map: reported here, stored as 0 (see k_env_cells)
+            const int seg_n = (int)seg_n_s, C = cfg.n_categories;
+            for (int i = tid; i < seg_n; i += NT) {
+                const uint8_t v = val[i];
+                bad_c |= (int)v >= C;
+                ok_[seg_base + i] = key[i];
+                oc_[seg_base + i] = (int)v < C ? v : (uint8_t)0;
+            }
+            __syncthreads();
+            if (tid == 0 && seg_n > 0) carry_key_s = key[seg_n - 1];
+            seg_base += seg_n;
+            __syncthreads();
+        }
+        ESTAMP(7);
+    }
+    if (tid == 0) env.len[r] = n;
+    if (__ballot(bad_c) && lane == 0) atomicOr(&st->flags, ST_BAD_CATEGORY);
+}
+
+bool launch_env_rows2(hipStream_t s, const DevConfig* cfg, const RowSide& a, const RowSide& b, int64_t n_rows, DeviceStatus* st) {
+    if (n_rows <= 0) return true;
+    const int64_t longest = std::max(a.row_len, b.row_len);
+    if (longest > 20480 || a.row_len < 1 || b.row_len < 1) return false;
+    int n2 = 64;
+    while (n2 < longest && n2 < 16384) n2 <<= 1;
+    // rows of 16385 .. 20480 points: sorted in distance segments of ~10^4 points each (the segment's keys in LDS)
+    const int n_seg = longest > 16384 ? 2 : 1;
+    if (n_seg > 1 && (std::min(a.row_len, b.row_len) <= 16384)) return false;  // (one launch, one segment count: both sides must be long)
+    RowSides sides;
+    sides.s[0] = a; sides.s[1] = b;
+    if (a.dmx) sides.s[0].image_bound = 0.0;  // given rows: the kernel finds the largest finite entry itself
+    if (b.dmx) sides.s[1].image_bound = 0.0;
+    sides.n_rows = n_rows;
+    const dim3 grid((unsigned)(2 * n_rows));
+    const size_t lds = (size_t)n2 * 9 + 16 + (size_t)(kRowBucketsSmall + 1) * sizeof(uint32_t);
+    if (n_seg > 1) k_env_rows2<1024, 20, 2><<<grid, 1024, lds, s>>>(cfg, sides, n2, st);
+    else if (n2 <= 1024) k_env_rows2<64, 16, 1><<<grid, 64, lds, s>>>(cfg, sides, n2, st);
+    else if (n2 <= 4096) k_env_rows2<256, 16, 1><<<grid, 256, lds, s>>>(cfg, sides, n2, st);
+    else if (n2 <= 8192) k_env_rows2<1024, 8, 1><<<grid, 1024, lds, s>>>(cfg, sides, n2, st);
+    else if (longest <= 10240) k_env_rows2<1024, 10, 1><<<grid, 1024, lds, s>>>(cfg, sides, n2, st);
+    else k_env_rows2<1024, 16, 1><<<grid, 1024, lds, s>>>(cfg, sides, n2, st);
+    return true;
 }
 
 bool launch_env_rows(hipStream_t s, int cap, const DevConfig* cfg, const CloudView& c, const double* dmx, int64_t ld,
@@ -1374,10 +1695,12 @@ struct WfRegs {
     int kind, np, nterm;
     bool fast;
     double a[4], b[4];
+    double inv;  // DevConfig::wf_inv
     const double* p;
 };
-__device__ __forceinline__ WfRegs wf_load(const WfEntry& e, const double* p) {
+__device__ __forceinline__ WfRegs wf_load(const WfEntry& e, const double* p, double inv) {
     WfRegs w;
+    w.inv = inv;
     w.kind = e.kind;
     w.np = e.n_params;
     w.nterm = e.n_params / 2;
@@ -1397,17 +1720,14 @@ __device__ __forceinline__ double cdf_dev(const WfRegs& w, double x) {
     if (w.kind == WF_UNIFORM) {  // cdfs.rs:39-45
         if (x < w.a[0]) return 0.0;
         if (x > w.a[1]) return 1.0;
-        return (x - w.a[0]) / (w.a[1] - w.a[0]);
+        return (x - w.a[0]) * w.inv;
     }
     if (w.fast) {  // cdfs.rs:5-21, same accumulation order
-        double norm = 0.0, sum = 0.0;
+        double sum = 0.0;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (i < w.nterm) {
-                sum += w.a[i] * exp(-w.b[i] * x);
-                norm += w.a[i];
-            }
-        return 1.0 - sum / norm;
+            if (i < w.nterm) sum += w.a[i] * exp(-w.b[i] * x);
+        return 1.0 - sum * w.inv;
     }
     if constexpr (WFANY) return cdf_pow_based(w.kind, w.p, w.np, x);
     else return 0.0;  // unreachable: the host routes tables with other weight functions to the WFANY build
@@ -1457,7 +1777,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
     // the variants with many slots (25 categories at 0.05 atoms/A^3: ~416 events per pair) take tiles of 64 x LCHD_EPL_BIG so
     // that such a pair is ONE tile instead of a full one plus a nearly empty one.
     constexpr bool H2_ = (MODE != MODE_GEN);
-    constexpr int EPL = CNT8 ? LCHD_EPL_C8 : ((H2_ && LDSTAB && CMAX > 16) ? LCHD_EPL_BIG : kSweepEPL), TILE = 64 * EPL, WPB = kSweepWaves;
+    constexpr int EPL = (CNT8 && CMAX > 16) ? LCHD_EPL_C8 : ((H2_ && LDSTAB && CMAX > 16) ? LCHD_EPL_BIG : kSweepEPL), TILE = 64 * EPL, WPB = kSweepWaves;
     static_assert(EPL <= 15, "4-bit chunk-local counters");
     constexpr int FB = CNT8 ? 8 : 16;     // bits per count field
     constexpr int FPW = 64 / FB;          // count fields per u64 word
@@ -1645,7 +1965,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
         WfRegs wf{};
         if constexpr (FMODE != F_KEY) {
             const WfEntry wfe = cfgp->wf[wfi];
-            wf = wf_load(wfe, cfgp->wf_params + wfe.offset);
+            wf = wf_load(wfe, cfgp->wf_params + wfe.offset, cfgp->wf_inv[wfi]);
             if (kA[0] != 0ull || kB[0] != 0ull) {  // src/locohd.rs:74-77 (F_KEY: checked by the environment kernels)
                 if (lane == 0) { sweep_report(args.hst, ST_FIRST_NOT_ZERO); args.out[p] = nan(""); }
                 take_next();
@@ -2423,7 +2743,7 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
         WfRegs wf{};
         if constexpr (FMODE != F_KEY) {
             const WfEntry wfe = cfgp->wf[wfi];
-            wf = wf_load(wfe, cfgp->wf_params + wfe.offset);
+            wf = wf_load(wfe, cfgp->wf_params + wfe.offset, cfgp->wf_inv[wfi]);
             if (kA[0] != 0ull || kB[0] != 0ull) {  // src/locohd.rs:74-77 (F_KEY: checked by the environment kernels)
                 if (lane == 0) { sweep_report(args.hst, ST_FIRST_NOT_ZERO); args.out[p] = nan(""); }
                 take_next();
@@ -2737,7 +3057,11 @@ void launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool helling
     // k_sweep_duo (two pairs of <= 224 merged events per wavefront, <= 16 category slots) and the 8-bit-count k_sweep (both
     // environments <= 255 points, more than 16 slots); the INDIRECT 16-bit k_sweep takes what they leave over.
     const bool fast_cfg = !wide && hellinger2 && unit_weights && small && fmode == F_KEY && !a.wf_index;
+#ifdef LCHD_C8_ALL  // experiment: the 8-bit-count sweep for every slot count (instead of k_sweep_duo up to 16 slots)
+    const bool use_c8 = fast_cfg && !t.no_count8, use_duo = fast_cfg && cmax <= 16 && !t.no_duo && !use_c8;
+#else
     const bool use_duo = fast_cfg && cmax <= 16 && !t.no_duo, use_c8 = fast_cfg && cmax > 16 && !t.no_count8;
+#endif
     a.small_rule = use_c8 ? 1 : 0;
     {
         const int64_t nb = (a.n_pairs + 255) / 256;
@@ -2768,6 +3092,12 @@ void launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool helling
                 else if (cmax <= 12) { k_sweep_duo<12><<<dgrid, NTH, 0, s>>>(a); k_sweep<12, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
                 else { k_sweep_duo<16><<<dgrid, NTH, 0, s>>>(a); k_sweep<16, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
             } else {
+#ifdef LCHD_C8_ALL
+                if (cmax <= 8) { k_sweep<8, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); k_sweep<8, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+                else if (cmax <= 12) { k_sweep<12, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); k_sweep<12, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+                else if (cmax <= 16) { k_sweep<16, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); k_sweep<16, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+                else
+#endif
                 if (cmax <= 20) { k_sweep<20, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); k_sweep<20, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
                 else if (cmax <= 24) { k_sweep<24, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); k_sweep<24, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
                 else if (cmax <= 28) { k_sweep<28, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); k_sweep<28, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
@@ -2794,6 +3124,10 @@ void init_device_kernels() {
     raise(reinterpret_cast<const void*>(&k_env_cells<1024, true>), 16384 * 9);
     raise(reinterpret_cast<const void*>(&k_env_rows<1024, true>), (int)((kRowBucketsBig + 1) * sizeof(uint32_t) + 16));
     raise(reinterpret_cast<const void*>(&k_env_rows<1024, false>), 16384 * 9 + 16 + (kRowBucketsSmall + 1) * 4);
+    raise(reinterpret_cast<const void*>(&k_env_rows2<1024, 16, 1>), 16384 * 9 + 16 + (kRowBucketsSmall + 1) * 4);
+    raise(reinterpret_cast<const void*>(&k_env_rows2<1024, 10, 1>), 16384 * 9 + 16 + (kRowBucketsSmall + 1) * 4);
+    raise(reinterpret_cast<const void*>(&k_env_rows2<1024, 20, 2>), 16384 * 9 + 16 + (kRowBucketsSmall + 1) * 4);
+    raise(reinterpret_cast<const void*>(&k_env_rows2<1024, 8, 1>), 8192 * 9 + 16 + (kRowBucketsSmall + 1) * 4);
     raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_GEN, F_KEY, 1>), 256 * 256);
     raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_GEN, F_ANY, 1>), 256 * 256);
     raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_H2U, F_KEY, 1>), 256 * 256);

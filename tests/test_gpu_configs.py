@@ -259,6 +259,49 @@ def test_dense_rows_beyond_lds_capacity(lh, oracle):
     assert np.max(np.abs(same)) == 0.0
 
 
+def test_dense_row_kernels_agree(lh, oracle, monkeypatch):
+    """The dense-row paths against the oracle and each other: rows in one distance segment (k_env_rows2), rows of 16385 ..
+    20480 points in two segments, a long row that defeats the segmented sort (all distances equal: the call is repeated with
+    the global-memory row sort), rows beyond 20480 points, ragged / infinite entries, and the older kernel for every length."""
+    rng = np.random.default_rng(91)
+    cats = [f"c{i}" for i in range(7)]
+    wf = ("hyper_exp", [0.7, 0.3, 0.2, 0.05])
+
+    def rows(n_cols, n_rows, kind):
+        m = rng.uniform(0.0, 60.0, (n_rows, n_cols)) if kind != "equal" else np.full((n_rows, n_cols), 5.0)
+        if kind == "inf":
+            m[:, rng.integers(1, n_cols, n_cols // 50)] = np.inf
+        m[:, 0] = 0.0
+        return m
+
+    for n_cols, n_rows, kind in ((900, 6, "random"), (5000, 4, "inf"), (12_000, 3, "random"), (17_000, 3, "random"), (20_480, 2, "inf"),
+                                 (17_000, 2, "equal"), (21_000, 2, "random")):
+        sa, sb = rng.choice(cats, n_cols).tolist(), rng.choice(cats, n_cols).tolist()
+        ma, mb = rows(n_cols, n_rows, kind), rows(n_cols, n_rows, kind)
+        want = np.asarray(oracle.LoCoHD(cats, oracle.WeightFunction(*wf)).from_dmxs(sa, sb, ma.tolist(), mb.tolist()))
+        got = np.asarray(lh.LoCoHD(cats, lh.WeightFunction(*wf)).from_dmxs(sa, sb, ma, mb))
+        assert np.max(np.abs(got - want)) < TIGHT, (n_cols, kind)
+        if n_cols <= 17_000 and kind != "equal":
+            monkeypatch.setenv("LCHD_OLD_ROWS", "1")
+            old = np.asarray(lh.LoCoHD(cats, lh.WeightFunction(*wf)).from_dmxs(sa, sb, ma, mb))
+            monkeypatch.delenv("LCHD_OLD_ROWS")
+            assert np.max(np.abs(got - old)) < 1e-13, (n_cols, kind)
+    # from_coords, both kernels, a length with a partly filled last wavefront; two weight functions (distance keys, no CDF keys)
+    n = 3001
+    xa, xb = rng.uniform(0, 40, (n, 3)), rng.uniform(0, 40, (n, 3))
+    sa, sb = rng.choice(cats, n).tolist(), rng.choice(cats, n).tolist()
+    multi = lambda mod: {"a": mod.WeightFunction(*wf), "b": mod.WeightFunction("uniform", [2.0, 30.0])}
+    keys = ["a" if k % 3 else "b" for k in range(n)]
+    got = np.asarray(lh.LoCoHD(cats, multi(lh)).from_coords(sa, sb, xa, xb, keys))
+    monkeypatch.setenv("LCHD_OLD_ROWS", "1")
+    old = np.asarray(lh.LoCoHD(cats, multi(lh)).from_coords(sa, sb, xa, xb, keys))
+    monkeypatch.delenv("LCHD_OLD_ROWS")
+    assert np.max(np.abs(got - old)) < 1e-13
+    sample = list(range(0, n, 211))
+    want = np.asarray(oracle.LoCoHD(cats, multi(oracle)).from_coords(sa, sb, xa, xb, keys))[sample]
+    assert np.max(np.abs(got[sample] - want)) < TIGHT
+
+
 def test_from_primitives_batch_matches_single_calls(lh, oracle):
     """LoCoHD.from_primitives_batch (additive): several structure pairs in one device pass, bit-identical to
     the per-pair calls and equal to the oracle."""
