@@ -128,6 +128,8 @@ int lchd_cloud_create(lchd_ctx *ctx, const double *xyz, const int32_t *cat, cons
  * for all-vs-all). */
 int lchd_cloud_create_batch(lchd_ctx *ctx, const double *xyz, const int32_t *cat, const int32_t *tag, const int32_t *sid,
                             int64_t n, int32_t n_struct, lchd_cloud **out);
+/* Atoms a cloud / batch / frames buffer currently holds (-1 for a null handle). */
+int64_t lchd_cloud_size(const lchd_cloud *cloud);
 /* Replace the coordinates of an existing cloud (MD frames: same atoms, new positions). Host pointer [n][3]. */
 int lchd_cloud_set_coords(lchd_ctx *ctx, lchd_cloud *cloud, const double *xyz);
 void lchd_cloud_destroy(lchd_ctx *ctx, lchd_cloud *cloud);
@@ -138,6 +140,11 @@ void lchd_cloud_destroy(lchd_ctx *ctx, lchd_cloud *cloud);
  * d_out is complete on return.  Uses the configuration set by lchd_ctx_set_config. */
 int lchd_from_primitives_dev(lchd_ctx *ctx, lchd_cloud *a, lchd_cloud *b, const int64_t *d_anchors,
                              const int32_t *d_wf_index, int64_t n_pairs, double threshold_distance, double *d_out);
+
+/* LoCoHD::from_coords (src/locohd.rs:463-476) with both structures already on the device: pair r = (atom r of a, atom r of
+ * b), every environment is the whole structure (no threshold, no tag rule).  d_wf_index: DEVICE [n] int32 or NULL, d_out:
+ * DEVICE [n] double, complete on return.  Uses the configuration set by lchd_ctx_set_config. */
+int lchd_from_coords_dev(lchd_ctx *ctx, lchd_cloud *a, lchd_cloud *b, const int32_t *d_wf_index, double *d_out);
 
 /* Split form of lchd_from_primitives_dev: _async enqueues the whole pass on the context's stream and returns without
  * waiting; lchd_ctx_finish waits, re-runs the pass with a larger environment capacity if one overflowed, and returns
@@ -196,7 +203,8 @@ int lchd_group_last_counts(const lchd_group *group, int64_t *counts_out);
 /* One process per GPU (torch.distributed / MPI style): every rank holds the whole pair list on its device and runs the
  * SAME deterministic partition (a pure function of the list, so no communication is needed to agree on it):
  *   bin(p) = floor(anchor_a(p) * 1024 / n_atoms_a),  rank(bin) = min(world - 1, floor(#pairs in lower bins * world / n_pairs)).
- * lchd_shard_plan_dev computes it (one kernel + a wait) and returns the pair count of every rank;
+ * lchd_shard_plan_dev computes it (one kernel on a side stream of the context + a wait for that kernel only: the pair list
+ * must be complete in device memory when it is called) and returns the pair count of every rank;
  * lchd_shard_select_dev compacts THIS rank's pairs (d_sel_anchors [counts[rank]][2], d_sel_index [counts[rank]] = their
  * positions in the full list; enqueued on the context's stream, no wait);
  * lchd_unshard_scores_dev, on the gathering rank, puts score k of rank r at its pair's original position:

@@ -70,11 +70,13 @@ _PROTOS = {
     "lchd_from_primitives": (C.c_int, [_VP, C.POINTER(ConfigC), _DP, _IP, _IP, _i64, _DP, _IP, _IP, _i64, _LP, _IP, _i64, _f64, _DP]),
     "lchd_cloud_create": (C.c_int, [_VP, _DP, _IP, _IP, _i64, C.POINTER(_VP)]),
     "lchd_cloud_create_batch": (C.c_int, [_VP, _DP, _IP, _IP, _IP, _i64, _i32, C.POINTER(_VP)]),
+    "lchd_cloud_size": (C.c_int64, [_VP]),
     "lchd_cloud_set_coords": (C.c_int, [_VP, _VP, _DP]),
     "lchd_cloud_destroy": (None, [_VP, _VP]),
     "lchd_from_primitives_dev": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _i64, _f64, _VP]),
     "lchd_from_primitives_dev_async": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _i64, _f64, _VP]),
     "lchd_ctx_finish": (C.c_int, [_VP]),
+    "lchd_from_coords_dev": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
     "lchd_frames_create": (C.c_int, [_VP, _VP, _i32, C.POINTER(_VP)]),
     "lchd_frames_load": (C.c_int, [_VP, _VP, _DP, _i32, _VP]),
     "lchd_frames_set_sources": (C.c_int, [_VP, _VP, _IP, _IP, _i64]),

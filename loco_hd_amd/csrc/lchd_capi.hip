@@ -199,6 +199,10 @@ struct lchd_ctx {
     } pend;
     // multi-GPU sharding helpers (lchd_shard_*): device state, host-mapped counts, the plan they belong to
     ShardState* d_shard = nullptr;
+    hipStream_t shard_stream = nullptr;  // the plan kernel runs (and is waited for) here: the wait does not include the scoring passes
+    hipEvent_t shard_ev = nullptr;       // ... and the selection on the context's stream is ordered behind it
+    hipEvent_t shard_sel_ev = nullptr;   // the last selection (reads the plan's bin table): the next plan is ordered behind it
+    bool shard_sel_pending = false;
     int64_t* h_counts = nullptr;
     uint32_t* d_bad = nullptr;
     int shard_world = 0;
@@ -341,6 +345,9 @@ extern "C" void lchd_ctx_destroy(lchd_ctx* c) {
     (void)hipFree(c->d_io);
     (void)hipFree(c->d_shard);
     (void)hipFree(c->d_bad);
+    if (c->shard_stream) (void)hipStreamDestroy(c->shard_stream);
+    if (c->shard_ev) (void)hipEventDestroy(c->shard_ev);
+    if (c->shard_sel_ev) (void)hipEventDestroy(c->shard_sel_ev);
     if (c->h_counts) (void)hipHostFree(c->h_counts);
     if (c->h_io) (void)hipHostFree(c->h_io);
     if (c->h_status) (void)hipHostFree(c->h_status);
@@ -568,6 +575,8 @@ extern "C" int lchd_cloud_create_batch(lchd_ctx* c, const double* xyz, const int
     *out = cl;
     return LCHD_OK;
 }
+
+extern "C" int64_t lchd_cloud_size(const lchd_cloud* cl) { return cl ? cl->n : -1; }
 
 extern "C" int lchd_cloud_set_coords(lchd_ctx* c, lchd_cloud* cl, const double* xyz) {
     if (!c || !cl || !xyz) return fail(LCHD_EVALUE, "null argument");
@@ -1173,7 +1182,7 @@ static int stage_cloud(const double* xyz, const int32_t* cat, const int32_t* tag
     uint8_t* hc = reinterpret_cast<uint8_t*>(h_base + oc);
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int64_t i = 0; i < n; ++i) {
-        const double v[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+        const double v[3] = {xyz ? xyz[3 * i] : 0.0, xyz ? xyz[3 * i + 1] : 0.0, xyz ? xyz[3 * i + 2] : 0.0};  // (no coordinates: given distance rows)
         if (!std::isfinite(v[0]) || !std::isfinite(v[1]) || !std::isfinite(v[2])) return fail(LCHD_EVALUE, "non-finite coordinate at atom %lld", (long long)i);
         hx[i] = v[0]; hy[i] = v[1]; hz[i] = v[2];
         for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], v[k]); mx[k] = std::max(mx[k], v[k]); }
@@ -1394,7 +1403,13 @@ static int ensure_shard_state(lchd_ctx* c) {
     if (e == hipSuccess) e = hipHostMalloc(&c->h_counts, sizeof(int64_t) * kShardMaxWorld);
     if (e == hipSuccess) e = hipMalloc(&c->d_bad, sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(c->d_bad, 0, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->shard_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->shard_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->shard_sel_ev, hipEventDisableTiming);
     if (e != hipSuccess) {
+        if (c->shard_stream) { (void)hipStreamDestroy(c->shard_stream); c->shard_stream = nullptr; }
+        if (c->shard_ev) { (void)hipEventDestroy(c->shard_ev); c->shard_ev = nullptr; }
+        if (c->shard_sel_ev) { (void)hipEventDestroy(c->shard_sel_ev); c->shard_sel_ev = nullptr; }
         (void)hipFree(c->d_shard); c->d_shard = nullptr;
         if (c->h_counts) { (void)hipHostFree(c->h_counts); c->h_counts = nullptr; }
         (void)hipFree(c->d_bad); c->d_bad = nullptr;
@@ -1412,9 +1427,13 @@ extern "C" int lchd_shard_plan_dev(lchd_ctx* c, const int64_t* d_anchors, int64_
     if (!d_anchors) return fail(LCHD_EVALUE, "null anchor pointer");
     CTX_GUARD(c);
     if (int rc = ensure_shard_state(c)) return rc;
-    launch_shard_plan(c->stream, d_anchors, n_pairs, n_atoms_a, world, c->d_shard, c->h_counts);
+    // On the context's side stream: the pair list is an INPUT (the caller has it ready), so the plan neither waits for the
+    // scoring passes queued on the context's stream nor makes the host wait for them.
+    if (c->shard_sel_pending) { HIP_TRY(hipStreamWaitEvent(c->shard_stream, c->shard_sel_ev, 0)); c->shard_sel_pending = false; }
+    launch_shard_plan(c->shard_stream, d_anchors, n_pairs, n_atoms_a, world, c->d_shard, c->h_counts);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipEventRecord(c->shard_ev, c->shard_stream));
+    HIP_TRY(hipStreamSynchronize(c->shard_stream));
     int64_t total = 0;
     for (int r = 0; r < world; ++r) { counts_out[r] = c->h_counts[r]; total += counts_out[r]; }
     if (total != n_pairs) return fail(LCHD_EDEVICE, "the shard plan accounts for %lld of %lld pairs", (long long)total, (long long)n_pairs);
@@ -1430,8 +1449,11 @@ extern "C" int lchd_shard_select_dev(lchd_ctx* c, const int64_t* d_anchors, int6
     if (n_pairs == 0 || c->h_counts[rank] == 0) return LCHD_OK;  // nothing for this rank: the outputs may be null
     if (!d_anchors || !d_sel_anchors || !d_sel_index) return fail(LCHD_EVALUE, "null pointer");
     CTX_GUARD(c);
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->shard_ev, 0));
     launch_shard_select(c->stream, d_anchors, n_pairs, n_atoms_a, rank, c->d_shard, d_sel_anchors, d_sel_index);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->shard_sel_ev, c->stream));
+    c->shard_sel_pending = true;
     return LCHD_OK;
 }
 extern "C" int lchd_unshard_scores_dev(lchd_ctx* c, const double* d_gathered, const int64_t* counts, int32_t world, int64_t stride,
@@ -1486,6 +1508,61 @@ static int sweep_rows(lchd_ctx* c, const EnvStore& ea, const EnvStore& eb, const
     return status_to_rc(f, drv);
 }
 
+// One dense pass (from_coords / from_dmxs semantics: pair r = row r of A against row r of B, the environment is the whole
+// structure): row sort of both structures, sweep.  a / b: device-resident structures (coordinates used unless d_ma / d_mb,
+// DEVICE pointers to given distance rows, are set); d_wf: device weight-function indices or nullptr; d_out: device or
+// host-mapped scores.  `retry` reports that a long row defeated the segmented in-LDS sort (repeat with old_rows).
+static int dense_pass(lchd_ctx* c, const lchd_cloud& a, const lchd_cloud& b, const double* d_ma, const double* d_mb, int64_t rows,
+                      int64_t cols_a, int64_t cols_b, const int32_t* d_wf, double* d_out, bool old_rows, bool& retry,
+                      const double* h_ma = nullptr, const double* h_mb = nullptr) {
+    retry = false;
+    const int cap_a = next_pow2_host(cols_a), cap_b = next_pow2_host(cols_b);
+    EnvStore ea{}, eb{};
+    double *w_ma = nullptr, *w_mb = nullptr;
+    int4* d_meta = nullptr;
+    for (int dry = 1; dry >= 0; --dry) {
+        Arena ar(dry ? nullptr : c->ws, dry ? 0 : c->ws_cap, dry != 0);
+        ea.key = ar.take<uint64_t>((size_t)rows * cap_a);
+        ea.cat = ar.take<uint8_t>((size_t)rows * cap_a);
+        ea.len = ar.take<int32_t>((size_t)rows);
+        ea.stride = cap_a;
+        eb.key = ar.take<uint64_t>((size_t)rows * cap_b);
+        eb.cat = ar.take<uint8_t>((size_t)rows * cap_b);
+        eb.len = ar.take<int32_t>((size_t)rows);
+        eb.stride = cap_b;
+        ea.cdf_keys = eb.cdf_keys = (c->h_cfg.n_wf == 1 && !c->tune.no_cdf_keys) ? 1 : 0;
+        d_meta = ar.take<int4>((size_t)rows);
+        if (h_ma) {  // given distance matrices in host memory: straight from the caller's buffers into the workspace
+            w_ma = ar.take<double>((size_t)rows * cols_a);
+            w_mb = ar.take<double>((size_t)rows * cols_b);
+        }
+        if (dry) if (int rc2 = ensure_ws(c, ar.off + 4096)) return rc2;
+    }
+    hipStream_t s = c->stream;
+    if (h_ma) {
+        HIP_TRY(hipMemcpyAsync(w_ma, h_ma, sizeof(double) * rows * cols_a, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(w_mb, h_mb, sizeof(double) * rows * cols_b, hipMemcpyHostToDevice, s));
+        d_ma = w_ma;
+        d_mb = w_mb;
+    }
+    mark(c, 2);
+    auto diag2 = [](const lchd_cloud& cl) {  // squared diagonal of the bounding box, with a little headroom
+        double s2 = 0.0;
+        for (int k = 0; k < 3; ++k) { const double e = cl.bbmax[k] - cl.bbmin[k]; s2 += e * e; }
+        return s2 * (1.0 + 1e-9) + 1e-300;
+    };
+    const RowSide rsa{a.view(), d_ma, cols_a, cols_a, diag2(a), ea}, rsb{b.view(), d_mb, cols_b, cols_b, diag2(b), eb};
+    if (old_rows || !launch_env_rows2(s, c->d_cfg, rsa, rsb, rows, c->d_status))  // (rows beyond 20480 points: keys sorted in global memory)
+        if (!launch_env_rows(s, cap_a, c->d_cfg, a.view(), d_ma, cols_a, rows, cols_a, diag2(a), ea, c->d_status) ||
+            !launch_env_rows(s, cap_b, c->d_cfg, b.view(), d_mb, cols_b, rows, cols_b, diag2(b), eb, c->d_status))
+            return fail(LCHD_EUNSUPPORTED, "no dense environment kernel for this row length");
+    mark(c, 3);
+    uint32_t f = 0;
+    if (int rc2 = sweep_rows(c, ea, eb, d_wf, rows, d_out, d_meta, DRV_DMXS, &f)) return rc2;
+    if (f & ST_ROW_RETRY) retry = true;
+    return LCHD_OK;
+}
+
 static int dense_driver(lchd_ctx* c, const lchd_config* cfg, const int32_t* seq_a, int64_t len_seq_a, const int32_t* seq_b,
                         int64_t len_seq_b, const double* xyz_a, const double* xyz_b, const double* dmx_a, const double* dmx_b,
                         int64_t rows, int64_t cols_a, int64_t cols_b, const int32_t* wf_index, double* out) {
@@ -1498,72 +1575,71 @@ static int dense_driver(lchd_ctx* c, const lchd_config* cfg, const int32_t* seq_
     // utils.rs:25-39: the sort mask has row-length entries and indexes seq => a row longer than seq panics
     if (cols_a > len_seq_a || cols_b > len_seq_b) return fail(LCHD_EPANIC, "index out of bounds: a distance row is longer than its seq");
     if (cols_a == 0 || cols_b == 0) return fail(LCHD_EPANIC, "index out of bounds: empty distance row (src/locohd.rs:74)");
-    const int cap_a = next_pow2_host(cols_a), cap_b = next_pow2_host(cols_b);
     if (cols_a > 65535 || cols_b > 65535)
         return fail(LCHD_EUNSUPPORTED, "dense rows of more than 65535 points are not supported by this build (got %lld / %lld)",
                     (long long)cols_a, (long long)cols_b);
-    lchd_cloud *a = nullptr, *b = nullptr;
-    int rc = lchd_cloud_create(c, xyz_a, seq_a, nullptr, cols_a, &a);
-    if (!rc) rc = lchd_cloud_create(c, xyz_b, seq_b, nullptr, cols_b, &b);
-    if (rc) { lchd_cloud_destroy(c, a); lchd_cloud_destroy(c, b); return rc; }
-    auto body = [&](bool old_rows, bool& retry) -> int {
-        retry = false;
-        EnvStore ea{}, eb{};
-        double *d_ma = nullptr, *d_mb = nullptr, *d_out = nullptr;
-        int32_t* d_wf = nullptr;
-        int4* d_meta = nullptr;
-        for (int dry = 1; dry >= 0; --dry) {
-            Arena ar(dry ? nullptr : c->ws, dry ? 0 : c->ws_cap, dry != 0);
-            ea.key = ar.take<uint64_t>((size_t)rows * cap_a);
-            ea.cat = ar.take<uint8_t>((size_t)rows * cap_a);
-            ea.len = ar.take<int32_t>((size_t)rows);
-            ea.stride = cap_a;
-            eb.key = ar.take<uint64_t>((size_t)rows * cap_b);
-            eb.cat = ar.take<uint8_t>((size_t)rows * cap_b);
-            eb.len = ar.take<int32_t>((size_t)rows);
-            eb.stride = cap_b;
-            ea.cdf_keys = eb.cdf_keys = (c->h_cfg.n_wf == 1 && !c->tune.no_cdf_keys) ? 1 : 0;
-            d_out = ar.take<double>((size_t)rows);
-            d_wf = ar.take<int32_t>((size_t)rows);
-            d_meta = ar.take<int4>((size_t)rows);
-            if (dmx_a) {
-                d_ma = ar.take<double>((size_t)rows * cols_a);
-                d_mb = ar.take<double>((size_t)rows * cols_b);
-            }
-            if (dry) if (int rc2 = ensure_ws(c, ar.off + 4096)) return rc2;
-        }
-        hipStream_t s = c->stream;
+    // The two structures (SoA coordinates + categories), the weight-function indices and -- for calls of up to kDirectOutPairs
+    // rows -- the scores travel through the context's pinned staging block (one asynchronous copy in, none out); nothing is
+    // allocated per call.
+    lchd_cloud a, b;
+    size_t o_wf = 0, o_out = 0, in_bytes = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        size_t off = 0;
+        char* hb = pass ? c->h_io : nullptr;
+        if (int rc = stage_cloud(xyz_a, seq_a, nullptr, cols_a, hb, c->d_io, off, a)) return rc;
+        if (int rc = stage_cloud(xyz_b, seq_b, nullptr, cols_b, hb, c->d_io, off, b)) return rc;
+        auto take = [&](size_t bytes) { off = (off + 255) & ~size_t(255); const size_t o = off; off += bytes; return o; };
+        o_wf = take(wf_index ? sizeof(int32_t) * (size_t)rows : 0);
+        in_bytes = off;
+        o_out = take(sizeof(double) * (size_t)rows);
+        if (pass == 0)
+            if (int rc = grow_io(c, off)) return rc;
+    }
+    if (wf_index) memcpy(c->h_io + o_wf, wf_index, sizeof(int32_t) * (size_t)rows);
+    const bool direct = rows <= kDirectOutPairs;
+    const int32_t* d_wf = wf_index ? reinterpret_cast<const int32_t*>(c->d_io + o_wf) : nullptr;
+    double* d_out = reinterpret_cast<double*>((direct ? c->h_io : c->d_io) + o_out);
+    int rc = LCHD_OK;
+    bool retry = false;
+    for (int attempt = 0; attempt < 2; ++attempt) {  // (second attempt: a long row defeated the segmented in-LDS sort)
         if (int rc2 = begin_pass(c)) return rc2;
         c->status_dirty = true;  // until the record pass has been enqueued (sweep_rows)
-        if (dmx_a) {
-            HIP_TRY(hipMemcpyAsync(d_ma, dmx_a, sizeof(double) * rows * cols_a, hipMemcpyHostToDevice, s));
-            HIP_TRY(hipMemcpyAsync(d_mb, dmx_b, sizeof(double) * rows * cols_b, hipMemcpyHostToDevice, s));
-        }
-        if (wf_index) HIP_TRY(hipMemcpyAsync(d_wf, wf_index, sizeof(int32_t) * rows, hipMemcpyHostToDevice, s));
-        mark(c, 2);
-        auto diag2 = [](const lchd_cloud* cl) {  // squared diagonal of the bounding box, with a little headroom
-            double s2 = 0.0;
-            for (int k = 0; k < 3; ++k) { const double e = cl->bbmax[k] - cl->bbmin[k]; s2 += e * e; }
-            return s2 * (1.0 + 1e-9) + 1e-300;
-        };
-        const RowSide rsa{a->view(), d_ma, cols_a, cols_a, diag2(a), ea}, rsb{b->view(), d_mb, cols_b, cols_b, diag2(b), eb};
-        if (old_rows || !launch_env_rows2(s, c->d_cfg, rsa, rsb, rows, c->d_status))  // (rows beyond 20480 points: keys sorted in global memory)
-            if (!launch_env_rows(s, cap_a, c->d_cfg, a->view(), d_ma, cols_a, rows, cols_a, diag2(a), ea, c->d_status) ||
-                !launch_env_rows(s, cap_b, c->d_cfg, b->view(), d_mb, cols_b, rows, cols_b, diag2(b), eb, c->d_status))
-                return fail(LCHD_EUNSUPPORTED, "no dense environment kernel for this row length");
-        mark(c, 3);
-        uint32_t f = 0;
-        if (int rc2 = sweep_rows(c, ea, eb, wf_index ? d_wf : nullptr, rows, d_out, d_meta, DRV_DMXS, &f)) return rc2;
-        if (f & ST_ROW_RETRY) { retry = true; return LCHD_OK; }
-        HIP_TRY(hipMemcpy(out, d_out, sizeof(double) * rows, hipMemcpyDeviceToHost));
-        return LCHD_OK;
-    };
+        HIP_TRY(hipMemcpyAsync(c->d_io, c->h_io, in_bytes, hipMemcpyHostToDevice, c->stream));
+        rc = dense_pass(c, a, b, nullptr, nullptr, rows, cols_a, cols_b, d_wf, d_out, c->tune.old_rows || attempt > 0, retry, dmx_a, dmx_b);
+        if (rc || !retry) break;
+    }
+    if (rc) return rc;
+    if (!direct) {
+        HIP_TRY(hipMemcpyAsync(c->h_io + o_out, d_out, sizeof(double) * rows, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    memcpy(out, c->h_io + o_out, sizeof(double) * (size_t)rows);
+    return LCHD_OK;
+}
+
+/* from_coords with both structures already on the device (what bench.py --workload c2b measures): pair r = (atom r of a,
+ * atom r of b), the environments are the whole structures.  d_wf_index / d_out are device pointers ([n] int32 or NULL,
+ * [n] double).  Uses the configuration of lchd_ctx_set_config; d_out is complete on return. */
+extern "C" int lchd_from_coords_dev(lchd_ctx* c, lchd_cloud* a, lchd_cloud* b, const int32_t* d_wf_index, double* d_out) {
+    if (!c || !a || !b) return fail(LCHD_EVALUE, "null argument");
+    if (!c->cfg_set) return fail(LCHD_EVALUE, "lchd_ctx_set_config has not been called");
+    if (c->pend.active) return fail(LCHD_EVALUE, "an asynchronous call has not been finished (lchd_ctx_finish)");
+    if (a->sid || b->sid) return fail(LCHD_EVALUE, "from_coords takes single structures, not batches");
+    if (a->n != b->n)  // src/locohd.rs:420-428 via :472-475
+        return fail(LCHD_EVALUE, "Expected matrices with the same length, got lengths %lld and %lld!", (long long)a->n, (long long)b->n);
+    c->last_valid = false;
+    if (a->n == 0) return LCHD_OK;
+    if (!d_out) return fail(LCHD_EVALUE, "null score pointer");
+    if (a->n > 65535) return fail(LCHD_EUNSUPPORTED, "dense rows of more than 65535 points are not supported by this build (got %lld)", (long long)a->n);
+    CTX_GUARD(c);
     bool retry = false;
-    rc = body(c->tune.old_rows, retry);
-    if (!rc && retry) rc = body(true, retry);  // a row defeated the segmented in-LDS sort: the global-memory row sort takes the call
-    lchd_cloud_destroy(c, a);
-    lchd_cloud_destroy(c, b);
-    return rc;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (int rc = begin_pass(c)) return rc;
+        c->status_dirty = true;
+        if (int rc = dense_pass(c, *a, *b, nullptr, nullptr, a->n, a->n, b->n, d_wf_index, d_out, c->tune.old_rows || attempt > 0, retry)) return rc;
+        if (!retry) break;
+    }
+    return LCHD_OK;
 }
 
 extern "C" int lchd_from_coords(lchd_ctx* c, const lchd_config* cfg, const int32_t* seq_a, int64_t len_seq_a, const int32_t* seq_b,

@@ -576,13 +576,49 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t* key, uint8_t* val, in
 
 // hyper_exp and uniform are the common weight functions and stay inline; the pow-based CDFs are called.
 __device__ __noinline__ double cdf_pow_based(int kind, const double* p, int np, double x) { return cdf_eval(kind, p, np, x); }
+// exp(x) for x <= 0 (the weight-function CDFs only ever take exp(-b * distance)): x = n * ln2/64 + r, |r| <= ln2/128,
+// exp(x) = 2^(n >> 6) * 2^((n & 63) / 64) * exp(r) with a 64-entry table and a degree-5 polynomial (r^6/720 < 4e-17).
+// Within ~1.5 ulp of the correctly rounded value (libm / ocml: < 1 ulp) at a third of ocml's instruction count; exp(-inf) = 0.
+__device__ const double kExp2Tab[64] = {
+    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
+    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
+    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
+    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
+    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
+    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
+    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
+    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
+    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
+    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
+    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
+    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
+    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
+    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0,
+};
+__device__ __forceinline__ double exp_nonpos(double x) {
+    const double nd = rint(x * 0x1.71547652b82fep+6);  // 64 / ln 2
+    double r = fma(-nd, 0x1.62e42fefa39efp-7, x);       // ln 2 / 64, high part
+    r = fma(-nd, 0x1.abc9e3b39803fp-62, r);              // ... low part
+    const int n = (int)nd;
+    const double t = kExp2Tab[n & 63];
+    double q = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+    q = fma(q, r, 1.0 / 6.0);
+    q = fma(q, r, 0.5);
+    q = fma(q, r, 1.0);
+    q = q * r;  // exp(r) - 1
+    const double v = ldexp(fma(t, q, t), n >> 6);
+    return x < -746.0 ? 0.0 : v;  // (below the smallest subnormal; also x = -inf, where n is meaningless)
+}
+
 // `inv` = DevConfig::wf_inv of the weight function: the reciprocal of the CDF's constant divisor (<= 1 ulp from the
 // reference's quotient; an f64 division costs about as much as half the exponential)
 __device__ __forceinline__ double cdf_lean(int kind, const double* __restrict__ p, int np, double inv, double x) {
     if (kind == WF_HYPER_EXP) {  // cdfs.rs:5-21, same accumulation order
         double sum = 0.0;
         const int n = np / 2;
-        for (int i = 0; i < n; ++i) sum += p[i] * exp(-p[n + i] * x);
+        for (int i = 0; i < n; ++i) sum += p[i] * exp_nonpos(-p[n + i] * x);  // (b_i > 0, x >= 0: weight_function.rs:31-40,97-100)
         return 1.0 - sum * inv;
     }
     if (kind == WF_UNIFORM) {  // cdfs.rs:39-45
@@ -1210,7 +1246,7 @@ __global__ __launch_bounds__(NT) void k_env_rows(const DevConfig* __restrict__ c
 // ------------------------------------------------------------------------------------------------
 constexpr int kRowSegCap = 14272;  // rows of more than 16384 points: most points of one distance segment (keys in LDS)
 template <int NT, int EPT, int NSEG>  // NSEG: distance segments the row is sorted in (2 for rows of more than 16384 points)
-__global__ __launch_bounds__(NT, 4) void k_env_rows2(const DevConfig* __restrict__ cfgp, RowSides sides, int n2, DeviceStatus* st) {
+__global__ __launch_bounds__(NT, (NT == 512 ? 2 : 4)) void k_env_rows2(const DevConfig* __restrict__ cfgp, RowSides sides, int n2, DeviceStatus* st) {
     constexpr int n_seg = NSEG;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* key = reinterpret_cast<uint64_t*>(smem);
@@ -1376,8 +1412,8 @@ __global__ __launch_bounds__(NT, 4) void k_env_rows2(const DevConfig* __restrict
             if (tid == 0) seg_n_s = (uint32_t)n;
             __syncthreads();
         } else {
-            // 4. exclusive scan in segments of 64 buckets (one wavefront scan each), then of the segment totals: afterwards
-            //    the first slot of bucket b is hist[b] + seg_tot[b >> 6]
+            // 4. exclusive scan in groups of 64 buckets (one wavefront scan each), then of the group totals, then one
+            //    coalesced pass adds the group offsets: hist[b] = first slot of bucket b, hist[NB] = points of the segment
             const int n_grp = NB >> 6;
             for (int gq = wave; gq < n_grp; gq += NT / 64) {
                 const uint32_t v = hist[gq * 64 + lane];
@@ -1397,6 +1433,9 @@ __global__ __launch_bounds__(NT, 4) void k_env_rows2(const DevConfig* __restrict
                 if (lane == 0) seg_n_s = carry;
             }
             __syncthreads();
+            for (int b = tid; b < NB; b += NT) hist[b] += seg_tot[b >> 6];
+            if (tid == 0) hist[NB] = seg_n_s;
+            __syncthreads();
             const int seg_n = (int)seg_n_s;
             if (n_seg > 1 && seg_n > kRowSegCap) {  // the empirical CDF balanced the segments badly: see above
                 if (tid == 0) { atomicOr(&st->flags, ST_ROW_RETRY); env.len[r] = 0; }
@@ -1407,7 +1446,7 @@ __global__ __launch_bounds__(NT, 4) void k_env_rows2(const DevConfig* __restrict
 #pragma unroll
             for (int q = 0; q < EPT; ++q)
                 if (bs[q] != ~0u) {
-                    const uint32_t b = bs[q] & 8191u, pos = hist[b] + seg_tot[b >> 6] + (bs[q] >> 13);
+                    const uint32_t b = bs[q] & 8191u, pos = hist[b] + (bs[q] >> 13);
                     if (!row) m[q] = sqrt(m[q]);  // utils.rs:1-8
                     key[pos] = d2u(m[q]);
                     bs[q] = b | (pos << 13);
@@ -1420,8 +1459,7 @@ __global__ __launch_bounds__(NT, 4) void k_env_rows2(const DevConfig* __restrict
             for (int q = 0; q < EPT; ++q)
                 if (bs[q] != ~0u) {
                     const uint32_t b = bs[q] & 8191u, pos = bs[q] >> 13;
-                    const uint32_t lo = hist[b] + seg_tot[b >> 6];
-                    const uint32_t hi = b + 1 < (uint32_t)NB ? hist[b + 1] + seg_tot[(b + 1) >> 6] : (uint32_t)seg_n;
+                    const uint32_t lo = hist[b], hi = hist[b + 1];
                     const uint64_t mine = d2u(m[q]);
                     uint32_t rank = lo;
                     for (uint32_t j = lo; j < hi; j += 4) {
@@ -1501,6 +1539,9 @@ bool launch_env_rows2(hipStream_t s, const DevConfig* cfg, const RowSide& a, con
     else if (n2 <= 1024) k_env_rows2<64, 16, 1><<<grid, 64, lds, s>>>(cfg, sides, n2, st);
     else if (n2 <= 4096) k_env_rows2<256, 16, 1><<<grid, 256, lds, s>>>(cfg, sides, n2, st);
     else if (n2 <= 8192) k_env_rows2<1024, 8, 1><<<grid, 1024, lds, s>>>(cfg, sides, n2, st);
+#ifdef LCHD_ROWS_NT512
+    else if (longest <= 10240) k_env_rows2<512, 20, 1><<<grid, 512, lds, s>>>(cfg, sides, n2, st);
+#endif
     else if (longest <= 10240) k_env_rows2<1024, 10, 1><<<grid, 1024, lds, s>>>(cfg, sides, n2, st);
     else k_env_rows2<1024, 16, 1><<<grid, 1024, lds, s>>>(cfg, sides, n2, st);
     return true;
@@ -1582,6 +1623,9 @@ enum { F_KEY = 0, F_FAST = 1, F_ANY = 2 };
 #endif
 #ifndef LCHD_C8_WAVES
 #define LCHD_C8_WAVES 3  // waves per SIMD the 8-bit-count sweep with more than 16 category slots is compiled for
+#endif
+#ifndef LCHD_EPL_DENSE
+#define LCHD_EPL_DENSE 9   // ... of the sweeps without LDS tables (environments beyond 512 points: dense rows, thousands of events per pair)
 #endif
 #ifndef LCHD_EPL_BIG
 #define LCHD_EPL_BIG 8   // merged events per lane per tile of the many-slot Hellinger-2 sweep (k_sweep<20..32>): tiles of 512
@@ -1726,7 +1770,7 @@ __device__ __forceinline__ double cdf_dev(const WfRegs& w, double x) {
         double sum = 0.0;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (i < w.nterm) sum += w.a[i] * exp(-w.b[i] * x);
+            if (i < w.nterm) sum += w.a[i] * exp_nonpos(-w.b[i] * x);
         return 1.0 - sum * w.inv;
     }
     if constexpr (WFANY) return cdf_pow_based(w.kind, w.p, w.np, x);
@@ -1777,7 +1821,8 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
     // the variants with many slots (25 categories at 0.05 atoms/A^3: ~416 events per pair) take tiles of 64 x LCHD_EPL_BIG so
     // that such a pair is ONE tile instead of a full one plus a nearly empty one.
     constexpr bool H2_ = (MODE != MODE_GEN);
-    constexpr int EPL = (CNT8 && CMAX > 16) ? LCHD_EPL_C8 : ((H2_ && LDSTAB && CMAX > 16) ? LCHD_EPL_BIG : kSweepEPL), TILE = 64 * EPL, WPB = kSweepWaves;
+    constexpr int EPL = (CNT8 && CMAX > 16) ? LCHD_EPL_C8 : ((H2_ && LDSTAB && CMAX > 16) ? LCHD_EPL_BIG : ((H2_ && !LDSTAB) ? LCHD_EPL_DENSE : kSweepEPL)),
+                  TILE = 64 * EPL, WPB = kSweepWaves;
     static_assert(EPL <= 15, "4-bit chunk-local counters");
     constexpr int FB = CNT8 ? 8 : 16;     // bits per count field
     constexpr int FPW = 64 / FB;          // count fields per u64 word
@@ -3126,6 +3171,9 @@ void init_device_kernels() {
     raise(reinterpret_cast<const void*>(&k_env_rows<1024, false>), 16384 * 9 + 16 + (kRowBucketsSmall + 1) * 4);
     raise(reinterpret_cast<const void*>(&k_env_rows2<1024, 16, 1>), 16384 * 9 + 16 + (kRowBucketsSmall + 1) * 4);
     raise(reinterpret_cast<const void*>(&k_env_rows2<1024, 10, 1>), 16384 * 9 + 16 + (kRowBucketsSmall + 1) * 4);
+#ifdef LCHD_ROWS_NT512
+    raise(reinterpret_cast<const void*>(&k_env_rows2<512, 20, 1>), 16384 * 9 + 16 + (kRowBucketsSmall + 1) * 4);
+#endif
     raise(reinterpret_cast<const void*>(&k_env_rows2<1024, 20, 2>), 16384 * 9 + 16 + (kRowBucketsSmall + 1) * 4);
     raise(reinterpret_cast<const void*>(&k_env_rows2<1024, 8, 1>), 8192 * 9 + 16 + (kRowBucketsSmall + 1) * 4);
     raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_GEN, F_KEY, 1>), 256 * 256);

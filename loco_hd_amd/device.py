@@ -94,6 +94,21 @@ class DeviceSession:
                                                  float(threshold_distance), C.c_void_p(out.data_ptr())))
         return out
 
+    def from_coords(self, cloud_a, cloud_b, out=None, wf_index=None):
+        """LoCoHD.from_coords on two uploaded structures of equal size: pair r = (atom r, atom r), environments = the whole
+        structures.  Returns (or fills) a torch float64 CUDA tensor [n]."""
+        torch = self.torch
+        n = int(N.lib().lchd_cloud_size(cloud_a))
+        if out is None:
+            out = torch.empty(n, dtype=torch.float64, device=torch.device("cuda", self.device))
+        assert out.is_cuda and out.dtype == torch.float64 and out.is_contiguous() and out.numel() >= n
+        wf_ptr = None
+        if wf_index is not None:
+            assert wf_index.is_cuda and wf_index.dtype == torch.int32 and wf_index.is_contiguous() and wf_index.numel() >= n
+            wf_ptr = C.c_void_p(wf_index.data_ptr())
+        N.check(N.lib().lchd_from_coords_dev(self._ctx, cloud_a, cloud_b, wf_ptr, C.c_void_p(out.data_ptr())))
+        return out
+
     # ---- asynchronous form + trajectory streaming ----------------------------------------------------------------
     def from_primitives_async(self, cloud_a, cloud_b, anchors, threshold_distance: float, out, wf_index=None):
         """Enqueue one pass and return immediately; `finish()` waits for it and raises on errors."""
