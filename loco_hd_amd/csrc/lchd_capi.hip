@@ -547,6 +547,9 @@ extern "C" int lchd_cloud_create(lchd_ctx* c, const double* xyz, const int32_t* 
         else e = hipMemset(cl->tag, 0, sizeof(int32_t) * n);
         if (e != hipSuccess) return bail(e, "tags");
     }
+    // (the copies and fills above went through the null stream; the context may launch on a non-blocking stream that is not
+    // ordered behind it: creating a structure is rare, so simply wait for the device)
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return bail(e, "hipDeviceSynchronize");
     *out = cl;
     return LCHD_OK;
 }
@@ -724,14 +727,15 @@ static GridPlan plan_grid(const lchd_cloud* cl, double thr) {
 }
 
 struct SideBufs {
-    uint32_t *cell_of, *cell_count, *cursor, *cell_start, *pos_of, *slot, *scan_tmp;
+    uint32_t *cell_of, *cell_count, *cell_start, *pos_of, *slot, *scan_tmp, *bits, *wpre;
+    uint8_t* flag8;
     AnchorRec* uniq;
     CellRec* rec;
     EnvStore env;
 };
 
-// Workspace layout of one pass.  Everything that must be zero when the prologue starts -- the generic cell list's counters
-// and the anchor flags of both sides -- is carved as ONE contiguous region (slot_a, slot_b last), so at most one memset
+// Workspace layout of one pass.  Everything that must be zero when the prologue starts -- the general cell list's counters
+// and the anchor flags of both sides -- is carved as ONE contiguous region (flags_a, flags_b last), so at most one memset
 // (or none: the fused / per-structure prologue launches zero what they need themselves) precedes the kernels.
 struct PassBufs {
     SideBufs a, b;
@@ -745,11 +749,9 @@ static void carve_pass(Arena& ar, int64_t n_a, int cells_a, int64_t envs_a, int6
     ar.off = (ar.off + 255) & ~size_t(255);
     const size_t z0 = ar.off;
     pb.a.cell_count = ar.take<uint32_t>((size_t)cells_a + 1);
-    pb.a.cursor = ar.take<uint32_t>((size_t)cells_a + 1);
     pb.b.cell_count = ar.take<uint32_t>((size_t)cells_b + 1);
-    pb.b.cursor = ar.take<uint32_t>((size_t)cells_b + 1);
-    pb.a.slot = ar.take<uint32_t>(ma + 1);
-    pb.b.slot = ar.take<uint32_t>(mb + 1);
+    pb.a.flag8 = reinterpret_cast<uint8_t*>(ar.take<uint4>((ma + 31) / 32 * 2 + 2));  // one byte per atom, padded to whole 32-byte words
+    pb.b.flag8 = reinterpret_cast<uint8_t*>(ar.take<uint4>((mb + 31) / 32 * 2 + 2));
     pb.zero_base = ar.dry ? nullptr : ar.base + z0;
     pb.zero_bytes = ar.off - z0;
     for (int side = 0; side < 2; ++side) {
@@ -758,6 +760,9 @@ static void carve_pass(Arena& ar, int64_t n_a, int cells_a, int64_t envs_a, int6
         const int n_cells = side ? cells_b : cells_a;
         const size_t ne = (size_t)std::max<int64_t>(side ? envs_b : envs_a, 1);
         b.cell_of = ar.take<uint32_t>(m);
+        b.slot = ar.take<uint32_t>(m + 1);
+        b.bits = ar.take<uint32_t>((m + 31) / 32 + 1);
+        b.wpre = ar.take<uint32_t>((m + 31) / 32 + 2);
         b.cell_start = ar.take<uint32_t>((size_t)n_cells + 1);
         b.rec = ar.take<CellRec>(m);
         b.pos_of = ar.take<uint32_t>(m);
@@ -843,8 +848,8 @@ static int prims_enqueue(lchd_ctx* c) {
         PrepSide ps{};
         ps.c = cv; ps.g = gv;
         ps.cell_start = sbuf.cell_start; ps.rec = sbuf.rec; ps.pos_of = sbuf.pos_of;
-        ps.cell_of = sbuf.cell_of; ps.cell_count = sbuf.cell_count; ps.cursor = sbuf.cursor; ps.scan_tmp = sbuf.scan_tmp;
-        ps.slot = sbuf.slot; ps.uniq = sbuf.uniq;
+        ps.cell_of = sbuf.cell_of; ps.cell_count = sbuf.cell_count; ps.scan_tmp = sbuf.scan_tmp;
+        ps.flag8 = sbuf.flag8; ps.bits = sbuf.bits; ps.wpre = sbuf.wpre; ps.slot = sbuf.slot; ps.uniq = sbuf.uniq;
         return ps;
     };
     (void)launch_prologue(s, c->tune, P.anchors, n_pairs, prep_side(cva, gva, sa), prep_side(cvb, gvb, sb), pb.zero_base, pb.zero_bytes,
@@ -1398,14 +1403,18 @@ extern "C" int lchd_group_from_primitives(lchd_group* g, const lchd_config* cfg,
 // ---- one process per GPU: the same partition on the device ------------------------------------------------------------
 static int ensure_shard_state(lchd_ctx* c) {
     if (c->d_shard) return LCHD_OK;
-    HIP_TRY(hipMalloc(&c->d_shard, sizeof(ShardState)));
-    hipError_t e = hipMemset(c->d_shard, 0, sizeof(ShardState));
-    if (e == hipSuccess) e = hipHostMalloc(&c->h_counts, sizeof(int64_t) * kShardMaxWorld);
-    if (e == hipSuccess) e = hipMalloc(&c->d_bad, sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemset(c->d_bad, 0, sizeof(uint32_t));
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->shard_stream, hipStreamNonBlocking);
+    // The plan kernel runs on a NON-BLOCKING side stream, which is not ordered behind work of the null stream: the state is
+    // zeroed ON that stream (a plain hipMemset may still be pending when the first plan starts and would then wipe the
+    // plan's bin table under the selection kernel), and the call waits for it.
+    hipError_t e = hipStreamCreateWithFlags(&c->shard_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->shard_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->shard_sel_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc(&c->d_shard, sizeof(ShardState));
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_shard, 0, sizeof(ShardState), c->shard_stream);
+    if (e == hipSuccess) e = hipHostMalloc(&c->h_counts, sizeof(int64_t) * kShardMaxWorld);
+    if (e == hipSuccess) e = hipMalloc(&c->d_bad, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_bad, 0, sizeof(uint32_t), c->shard_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->shard_stream);
     if (e != hipSuccess) {
         if (c->shard_stream) { (void)hipStreamDestroy(c->shard_stream); c->shard_stream = nullptr; }
         if (c->shard_ev) { (void)hipEventDestroy(c->shard_ev); c->shard_ev = nullptr; }
@@ -1478,7 +1487,7 @@ extern "C" int lchd_unshard_scores_dev(lchd_ctx* c, const double* d_gathered, co
     HIP_TRY(hipMemcpyAsync(&bad, c->d_bad, sizeof bad, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (bad) {
-        (void)hipMemset(c->d_bad, 0, sizeof(uint32_t));
+        (void)hipMemsetAsync(c->d_bad, 0, sizeof(uint32_t), c->stream);
         return fail(LCHD_EVALUE, "a gathered pair position lies outside [0, %lld)", (long long)n_pairs);
     }
     return LCHD_OK;

@@ -143,14 +143,17 @@ struct PrepSide {
     uint32_t* cell_start;    // [n_cells + 1]
     CellRec* rec;            // [n] atoms permuted into cell order
     uint32_t* pos_of;        // [n] atom -> position in cell order
-    uint32_t *cell_of, *cell_count, *cursor;  // scratch of the generic cell-list build (cell_count, cursor inside the zero region)
-    uint32_t* scan_tmp;      // (n / 4096 + 4) u32 of scratch for the multi-block scan
-    uint32_t* slot;          // [n + 1] anchor flags (inside the zero region), then environment slots
+    uint32_t *cell_of, *cell_count;  // scratch of the general cell-list build (cell_count [n_cells + 1] inside the zero region)
+    uint32_t* scan_tmp;      // (n_cells / 4096 + 4) u32 of scratch for the multi-block scan
+    uint8_t* flag8;          // [n rounded up to 32, + 32] one byte per atom: "is an anchor" (inside the zero region, 16-byte aligned)
+    uint32_t* bits;          // [(n + 31) / 32 + 1] the same as a bit set (k_prep_scan / k_flags_to_bits)
+    uint32_t* wpre;          // [(n + 31) / 32 + 2] anchors before each bit-set word
+    uint32_t* slot;          // [n + 1] atom -> environment slot (anchors only)
     AnchorRec* uniq;         // [max_envs]
 };
 // Cell lists of both sides + anchor de-duplication (see lchd_kernels.hip).  [zero_base, zero_base + zero_bytes) is the
-// contiguous region holding cell_count / cursor of both sides followed by slot_a, slot_b (in this order, slot_b last): the
-// prologue zeroes what its launch tier needs with at most one operation.  Returns the number of stream operations enqueued.
+// contiguous region holding cell_count of both sides followed by flag8_a, flag8_b (in this order, flag8_b last): the prologue
+// zeroes what its launch tier needs with at most one operation.  Returns the number of stream operations enqueued.
 int launch_prologue(hipStream_t s, const Tuning& t, const int64_t* anchors, int64_t n_pairs, const PrepSide& a, const PrepSide& b,
                     void* zero_base, size_t zero_bytes, DeviceStatus* st);
 // Per-device function attributes (dynamic LDS above 64 KB): called by lchd_ctx_create with the context's device current.

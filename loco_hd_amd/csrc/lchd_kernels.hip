@@ -2,13 +2,13 @@
 //
 // Pipeline for one from_primitives call (reference: /root/reference/src/locohd.rs:479-567):
 //
-//   K0  cell list           regular batches / small structures: k_cell_build_struct (one workgroup per structure, histogram +
-//                           scan + scatter in LDS); otherwise k_cell_count / k_exclusive_scan (or the 3-phase multi-block
-//                           scan) / k_cell_scatter.  Atoms are permuted into cell order as 32-byte records {x, y, z, tag, cat}
+//   K0  cell list           regular batches / small structures: one workgroup per structure (histogram + scan + scatter in
+//                           LDS: k_prologue_fused, k_cells_struct2); otherwise k_prep_count / k_prep_scan / k_prep_scatter.
+//                           Atoms are permuted into cell order as 32-byte records {x, y, z, tag, cat}
 //                           (replaces KdTree::build_by_ordered_float, :504-510); batches of structures carry the structure id
 //                           as the slowest grid dimension
-//   K0' anchor de-dup       fused into the cell-list launch for small inputs (k_prologue_fused), otherwise k_mark_anchors2 +
-//                           k_dedupe_finish_small or scan + k_compact_anchors: an anchor that occurs in many pairs gets its environment built once; every
+//   K0' anchor de-dup       in the same launches (anchor bit sets, popcount scan, compaction): an anchor that occurs in
+//                           many pairs gets its environment built once; every
 //                           unique anchor gets a 40-byte record (coordinates, tag, position in cell order, structure)
 //   K1  environment build   k_env_cells<NT,TAGLIST>, both structures in one launch: radius search over the concatenated
 //                           neighbour-cell runs (full wavefronts of candidates, two 16-byte loads per candidate, no dependent
@@ -130,18 +130,6 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
 // ------------------------------------------------------------------------------------------------
 // K0: uniform grid.  Points keep their f64 coordinates; only the bucketing uses the grid.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_cell_count(CloudView c, GridView g, uint32_t* cell_of, uint32_t* cell_count) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < c.n; i += gridDim.x * blockDim.x) {
-        const int cx = cell_coord(c.x[i], g.min[0], g.inv[0], g.dim[0]);
-        const int cy = cell_coord(c.y[i], g.min[1], g.inv[1], g.dim[1]);
-        const int cz = cell_coord(c.z[i], g.min[2], g.inv[2], g.dim[2]);
-        const int sid = c.sid ? c.sid[i] : 0;
-        const uint32_t cell = (uint32_t)((((int64_t)sid * g.dim[2] + cz) * g.dim[1] + cy) * g.dim[0] + cx);
-        cell_of[i] = cell;
-        atomicAdd(&cell_count[cell], 1u);
-    }
-}
-
 // Exclusive scan of n u32 by ONE 1024-thread workgroup (n is a cell or atom count: small). out[n] = total.
 // In-place (out == in) is allowed.
 __global__ __launch_bounds__(1024) void k_exclusive_scan(const uint32_t* in, uint32_t* out, int n, uint32_t* total_out) {
@@ -172,22 +160,6 @@ __global__ __launch_bounds__(1024) void k_exclusive_scan(const uint32_t* in, uin
     if (tid == 0) {
         out[n] = carry_s;
         if (total_out) *total_out = carry_s;
-    }
-}
-
-__global__ void k_cell_scatter(CloudView c, const uint32_t* cell_of, const uint32_t* cell_start, uint32_t* cursor,
-                               CellRec* __restrict__ rec, uint32_t* __restrict__ pos_of) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < c.n; i += gridDim.x * blockDim.x) {
-        const uint32_t cell = cell_of[i];
-        const uint32_t pos = cell_start[cell] + atomicAdd(&cursor[cell], 1u);
-        CellRec r;
-        r.x = c.x[i];
-        r.y = c.y[i];
-        r.z = c.z[i];
-        r.tag = (uint32_t)c.tag[i];
-        r.cat = c.cat[i];
-        rec[pos] = r;
-        pos_of[i] = pos;
     }
 }
 
@@ -226,10 +198,6 @@ __global__ __launch_bounds__(1024) void k_scan_apply(const uint32_t* in, uint32_
     }
 }
 static void launch_exclusive_scan(hipStream_t s, const uint32_t* in, uint32_t* out, int n, uint32_t* total_out, uint32_t* tmp) {
-    if (n <= 2 * kScanItems || !tmp) {
-        k_exclusive_scan<<<1, 1024, 0, s>>>(in, out, n, total_out);
-        return;
-    }
     const int nb = (n + kScanItems - 1) / kScanItems;
     k_scan_block_sums<<<nb, 1024, 0, s>>>(in, n, tmp);
     k_exclusive_scan<<<1, 1024, 0, s>>>(tmp, tmp, nb, nullptr);
@@ -244,9 +212,10 @@ static void launch_exclusive_scan(hipStream_t s, const uint32_t* in, uint32_t* o
 //             an LDS bit set, scan, anchor records
 //   struct    equal-sized structures that fit LDS (trajectory frames, regular batches, one medium structure): one workgroup
 //             per structure, both sides in one launch, which also zeroes the anchor flags
-//   generic   k_cell_count / scan / k_cell_scatter with global atomics (the caller zeroes the counters with ONE memset)
-// followed, unless fused, by k_mark_anchors2 (both sides from one pass over the pair list) and either
-// k_dedupe_finish_small (both sides, one launch) or scan + k_compact_anchors per side.
+//   general   three launches, each parallel over the atoms / pairs of both sides: k_prep_count (cell + rank inside it through
+//             the returning atomic on the cell counter; anchors into two bit sets), k_prep_scan (one workgroup per side),
+//             k_prep_scatter (records into cell order, anchor slots + records); the caller zeroes counters and bit sets with
+//             ONE memset.  After a struct launch the same three kernels only do the anchor half of their work.
 // ------------------------------------------------------------------------------------------------
 constexpr int kStructCellsMax = 4096, kStructAtomsMax = 12000;  // 16 KB + 48 KB of dynamic LDS stay under the 64 KB launch limit
 constexpr int kFusedPairsMax = 1 << 16;                         // one workgroup per side reads the whole pair list
@@ -429,63 +398,145 @@ __global__ __launch_bounds__(NT) void k_cells_struct2(PrepSide pa, PrepSide pb, 
     cell_build_wg<NT>(P.c, P.g, cps, (int64_t)k * size, size, (int64_t)k * cps, k == ns - 1, P.rec, P.pos_of, P.cell_start, smem_cb, wsum);
 }
 
-// flag[a] = 1 for every anchor, both sides from one pass over the pair list (flags zeroed beforehand)
-__global__ void k_mark_anchors2(const int64_t* __restrict__ anchors, int64_t n_pairs, int32_t n_a, int32_t n_b, uint32_t* flag_a,
-                                uint32_t* flag_b, DeviceStatus* st) {
+// ---- the general prologue: three launches, each parallel over atoms / pairs of BOTH sides ------------------------------
+//   k_prep_count    atoms: cell of every atom + its rank inside the cell (the returning atomic on the cell's counter);
+//                   pairs: one byte flag per anchor, PLAIN stores (a million pairs over ten thousand atoms hammer a
+//                   handful of cache lines: as atomics on a bit set they serialise at the memory side -- 0.9 ms --, as
+//                   plain stores every XCD's L2 absorbs its share)
+//   k_prep_scan     one workgroup per side: exclusive scan of the cell counters (a few thousand cells; batches with more
+//                   than kPrepScanCells cells take the multi-block scan), byte flags -> bit set, scan of the words'
+//                   popcounts (sides of more than kPrepScanAtoms atoms convert in k_flags_to_bits first)
+//   k_prep_scatter  atoms: record into cell order, atom -> position; anchors: environment slot + anchor record
+// (the struct path builds the cell lists in k_cells_struct2 and skips the atom halves of k_prep_count / k_prep_scan)
+constexpr int kPrepScanCells = 1 << 16;  // cells one workgroup scans (64 per thread)
+constexpr int kPrepScanAtoms = 1 << 18;  // atoms whose byte flags one workgroup turns into the bit set (256 KB through one CU: ~10 us)
+__global__ void k_prep_count(const int64_t* __restrict__ anchors, int64_t n_pairs, PrepSide pa, PrepSide pb, int cells_a, int cells_b,
+                             DeviceStatus* st) {
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x, g0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    // atoms of side A, then of side B (a side whose cell list the struct path builds is skipped: cells_x == 0)
+    const int64_t na = cells_a ? pa.c.n : 0, nb = cells_b ? pb.c.n : 0;
+    for (int64_t t = g0; t < na + nb; t += gsz) {
+        const bool sb_ = t >= na;
+        const PrepSide& P = sb_ ? pb : pa;
+        const int64_t i = sb_ ? t - na : t;
+        const GridView& g = P.g;
+        const int cx = cell_coord(P.c.x[i], g.min[0], g.inv[0], g.dim[0]);
+        const int cy = cell_coord(P.c.y[i], g.min[1], g.inv[1], g.dim[1]);
+        const int cz = cell_coord(P.c.z[i], g.min[2], g.inv[2], g.dim[2]);
+        const int sid = P.c.sid ? P.c.sid[i] : 0;
+        const uint32_t cell = (uint32_t)((((int64_t)sid * g.dim[2] + cz) * g.dim[1] + cy) * g.dim[0] + cx);
+        P.cell_of[i] = cell;
+        P.pos_of[i] = atomicAdd(&P.cell_count[cell], 1u);  // rank inside the cell, replaced by the position in k_prep_scatter
+    }
     bool bad = false;
-    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n_pairs; p += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t n_a = pa.c.n, n_b = pb.c.n;
+    for (int64_t p = g0; p < n_pairs; p += gsz) {
         const longlong2 ab = reinterpret_cast<const longlong2*>(anchors)[p];
-        if (ab.x < 0 || ab.x >= n_a) bad = true; else flag_a[ab.x] = 1u;
-        if (ab.y < 0 || ab.y >= n_b) bad = true; else flag_b[ab.y] = 1u;
+        if (ab.x < 0 || ab.x >= n_a) bad = true; else pa.flag8[ab.x] = 1;
+        if (ab.y < 0 || ab.y >= n_b) bad = true; else pb.flag8[ab.y] = 1;
     }
     if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(&st->flags, ST_BAD_ANCHOR);
 }
-__global__ void k_compact_anchors(const uint32_t* slot, int32_t n_points, AnchorRec* uniq, CloudView c, const uint32_t* pos_of) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_points; i += gridDim.x * blockDim.x)
-        if (slot[i + 1] != slot[i]) {
+
+// exclusive scan of n u32 by the calling 1024-thread workgroup, each thread a run of consecutive items; out[n] = total
+__device__ __forceinline__ uint32_t scan_wg_1024(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int64_t n, bool popcount,
+                                                 uint32_t* wsum /* [16] */) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t per = (n + 1023) / 1024, lo = min((int64_t)tid * per, n), hi = min(lo + per, n);
+    uint32_t sum = 0;
+    for (int64_t k = lo; k < hi; ++k) sum += popcount ? (uint32_t)__popc(in[k]) : in[k];
+    const uint32_t incl = wave_incl_scan_u32(sum);
+    __syncthreads();
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t pre = incl - sum, total = 0;
+    for (int w = 0; w < 16; ++w) { if (w < wave) pre += wsum[w]; total += wsum[w]; }
+    for (int64_t k = lo; k < hi; ++k) {
+        const uint32_t v = popcount ? (uint32_t)__popc(in[k]) : in[k];
+        out[k] = pre;
+        pre += v;
+    }
+    if (tid == 1023) out[n] = total;
+    return total;
+}
+// 32 byte flags -> one word of the bit set (the flag array is padded to a multiple of 32 bytes, 16-byte aligned)
+__device__ __forceinline__ uint32_t flags_word(const uint8_t* __restrict__ flag8, int64_t w) {
+    const uint4 lo = reinterpret_cast<const uint4*>(flag8)[2 * w], hi = reinterpret_cast<const uint4*>(flag8)[2 * w + 1];
+    auto nib = [](uint32_t v) -> uint32_t {  // four byte flags (0 / 1) -> four bits
+        return (v & 1u) | ((v >> 7) & 2u) | ((v >> 14) & 4u) | ((v >> 21) & 8u);
+    };
+    return nib(lo.x) | (nib(lo.y) << 4) | (nib(lo.z) << 8) | (nib(lo.w) << 12) | (nib(hi.x) << 16) | (nib(hi.y) << 20) | (nib(hi.z) << 24) |
+           (nib(hi.w) << 28);
+}
+__global__ void k_flags_to_bits(PrepSide pa, PrepSide pb) {
+    const int64_t wa = ((int64_t)pa.c.n + 31) >> 5, wb = ((int64_t)pb.c.n + 31) >> 5;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < wa + wb; t += (int64_t)gridDim.x * blockDim.x) {
+        const bool sb_ = t >= wa;
+        const PrepSide& P = sb_ ? pb : pa;
+        const int64_t w = sb_ ? t - wa : t;
+        P.bits[w] = flags_word(P.flag8, w);
+    }
+}
+__global__ __launch_bounds__(1024) void k_prep_scan(PrepSide pa, PrepSide pb, int cells_a, int cells_b, int bits_ready, DeviceStatus* st) {
+    __shared__ uint32_t wsum[16];
+    const int side = blockIdx.x;
+    const PrepSide& P = side ? pb : pa;
+    const int cells = side ? cells_b : cells_a;
+    if (cells > 0 && cells <= kPrepScanCells) scan_wg_1024(P.cell_count, P.cell_start, cells, false, wsum);
+    const int64_t nw = ((int64_t)P.c.n + 31) >> 5;
+    if (!bits_ready) {
+        for (int64_t w = threadIdx.x; w < nw; w += 1024) P.bits[w] = flags_word(P.flag8, w);
+        __syncthreads();  // (the scan below reads words other threads of this workgroup wrote)
+    }
+    const uint32_t total = scan_wg_1024(P.bits, P.wpre, nw, true, wsum);
+    if (threadIdx.x == 0) st->n_unique[side] = total;
+}
+__global__ void k_prep_scatter(PrepSide pa, PrepSide pb, int cells_a, int cells_b) {
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x, g0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t na = pa.c.n, nb = pb.c.n;
+    for (int64_t t = g0; t < na + nb; t += gsz) {
+        const bool sb_ = t >= na;
+        const PrepSide& P = sb_ ? pb : pa;
+        const int64_t i = sb_ ? t - na : t;
+        const CloudView& c = P.c;
+        const bool general = (sb_ ? cells_b : cells_a) != 0;
+        const uint32_t w = P.bits[i >> 5];
+        const bool anchor = (w >> (i & 31)) & 1u;
+        if (!general && !anchor) continue;  // (struct path, not an anchor: nothing to do -- most atoms of a trajectory batch)
+        const double x = c.x[i], y = c.y[i], z = c.z[i];
+        const uint32_t tag = (uint32_t)c.tag[i];
+        uint32_t pos = P.pos_of[i];
+        if (general) {  // general cell list: rank inside the cell -> position, record into cell order
+            pos += P.cell_start[P.cell_of[i]];
+            CellRec r;
+            r.x = x; r.y = y; r.z = z;
+            r.tag = tag;
+            r.cat = c.cat[i];
+            P.rec[pos] = r;
+            P.pos_of[i] = pos;
+        }
+        if (anchor) {  // its environment slot and its record
+            const uint32_t sl = P.wpre[i >> 5] + (uint32_t)__popc(w & ((1u << (i & 31)) - 1u));
+            P.slot[i] = sl;
             AnchorRec r;
-            r.x = c.x[i]; r.y = c.y[i]; r.z = c.z[i];
-            r.tag = (uint32_t)c.tag[i];
-            r.apos = pos_of[i];
+            r.x = x; r.y = y; r.z = z;
+            r.tag = tag;
+            r.apos = pos;
             r.sid = c.sid ? c.sid[i] : 0;
             r.atom = (uint32_t)i;
-            uniq[slot[i]] = r;
-        }
-}
-// both sides of <= kStructAtomsMax atoms: global flags -> LDS bit set -> slots + anchor records, one launch
-__global__ __launch_bounds__(1024) void k_dedupe_finish_small(PrepSide pa, PrepSide pb, DeviceStatus* st) {
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t bits[kBitWordsMax + 1], wpre[kBitWordsMax + 2];
-    const int side = blockIdx.x, tid = threadIdx.x;
-    const PrepSide& P = side ? pb : pa;
-    const int n = P.c.n, nw = (n + 31) >> 5;
-    const uint32_t* __restrict__ flag = P.slot;
-    for (int i0 = (tid >> 6) * 64; i0 < n; i0 += 1024) {  // coalesced flag reads, 64 flags -> two words per wavefront ballot
-        const int i = i0 + (tid & 63);
-        const unsigned long long m = __ballot(i < n && flag[i] != 0u);
-        if ((tid & 63) == 0) {
-            bits[i0 >> 5] = (uint32_t)m;
-            if ((i0 >> 5) + 1 <= kBitWordsMax) bits[(i0 >> 5) + 1] = (uint32_t)(m >> 32);
+            P.uniq[sl] = r;
         }
     }
-    __syncthreads();
-    const uint32_t* __restrict__ pos_of = P.pos_of;
-    dedupe_finish_wg<1024>(bits, wpre, nw, P.c, P.slot, P.uniq, &st->n_unique[side], wsum, [&](int i) { return pos_of[i]; });
 }
 
 static bool fits_struct_path(const PrepSide& P, const Tuning& t, CloudView& cs) {
     cs = P.c;
     if (!P.c.sid) { cs.struct_size = P.c.n; cs.n_struct = 1; }
     const int cps = P.g.dim[0] * P.g.dim[1] * P.g.dim[2];
+    // (a single structure of more than 4096 atoms is faster through the three parallel launches than through one
+    // workgroup, whose memory pipe moves ~25 GB/s: ~50 us per 10^4 atoms)
     return !t.no_struct_cells && cs.struct_size > 0 && cs.struct_size <= kStructAtomsMax && cps <= kStructCellsMax &&
-           (int64_t)cs.n_struct * cs.struct_size == P.c.n;
-}
-static void launch_cells_generic(hipStream_t s, const PrepSide& P) {  // cell_count / cursor already zeroed
-    const CloudView& c = P.c;
-    const int nb = (c.n + 255) / 256 > 4096 ? 4096 : (c.n + 255) / 256;
-    if (c.n > 0) k_cell_count<<<nb, 256, 0, s>>>(c, P.g, P.cell_of, P.cell_count);
-    launch_exclusive_scan(s, P.cell_count, P.cell_start, P.g.n_cells, nullptr, P.scan_tmp);
-    if (c.n > 0) k_cell_scatter<<<nb, 256, 0, s>>>(c, P.cell_of, P.cell_start, P.cursor, P.rec, P.pos_of);
+           (int64_t)cs.n_struct * cs.struct_size == P.c.n && (cs.n_struct >= 8 || cs.struct_size <= 4096);
 }
 
 int launch_prologue(hipStream_t s, const Tuning& t, const int64_t* anchors, int64_t n_pairs, const PrepSide& a_in, const PrepSide& b_in,
@@ -500,7 +551,7 @@ int launch_prologue(hipStream_t s, const Tuning& t, const int64_t* anchors, int6
         k_prologue_fused<<<2, 1024, lds, s>>>(anchors, n_pairs, a, b, st);
         return 1;
     }
-    // the anchor flags (and, for the generic cell list, its counters) must be zero: folded into the struct launch when both
+    // the anchor flags (and, for the general cell list, its counters) must be zero: folded into the struct launch when both
     // sides take it, otherwise ONE memset over the contiguous region the caller laid out
     const bool fold_zero = fa && fb;
     if (!fold_zero) { (void)hipMemsetAsync(zero_base, 0, zero_bytes, s); ++ops; }
@@ -509,11 +560,9 @@ int launch_prologue(hipStream_t s, const Tuning& t, const int64_t* anchors, int6
         sa_.c = csa; sb_.c = csb;
         const int nsa = fa ? csa.n_struct : 0, nsb = fb ? csb.n_struct : 0;
         const size_t lds = std::max(fa ? (size_t)cps_a * 4 + (size_t)csa.struct_size * 4 : 0, fb ? (size_t)cps_b * 4 + (size_t)csb.struct_size * 4 : 0);
-        // the flag arrays sit at the END of the zero region: [.. counters ..][slot_a][slot_b]
-        const int64_t flag_words = (int64_t)a.c.n + 1 + (int64_t)b.c.n + 1;
-        uint32_t* zb = fold_zero ? a.slot : nullptr;
-        const int64_t zw = fold_zero ? (int64_t)((reinterpret_cast<char*>(b.slot) + ((size_t)b.c.n + 1) * 4 - reinterpret_cast<char*>(a.slot)) / 4) : 0;
-        (void)flag_words;
+        // the anchor flags sit at the END of the zero region: [.. counters ..][flags_a][flags_b]
+        uint32_t* zb = fold_zero ? reinterpret_cast<uint32_t*>(a.flag8) : nullptr;
+        const int64_t zw = fold_zero ? (int64_t)((reinterpret_cast<char*>(zero_base) + zero_bytes - reinterpret_cast<char*>(a.flag8)) / 4) : 0;
         if (nsa + nsb <= 16) {
             const int nz = fold_zero ? (int)std::min<int64_t>(64, (zw + 4095) / 4096) : 0;
             k_cells_struct2<1024><<<nsa + nsb + nz, 1024, lds, s>>>(sa_, sb_, nsa, nsb, zb, zw);
@@ -523,27 +572,26 @@ int launch_prologue(hipStream_t s, const Tuning& t, const int64_t* anchors, int6
         }
         ++ops;
     }
-    if (!fa) { launch_cells_generic(s, a); ops += 3; }
-    if (!fb) { launch_cells_generic(s, b); ops += 3; }
-    if (n_pairs > 0) {
-        const int64_t nbp = (n_pairs + 255) / 256;
-        k_mark_anchors2<<<(int)(nbp > 4096 ? 4096 : nbp), 256, 0, s>>>(anchors, n_pairs, a.c.n, b.c.n, a.slot, b.slot, st);
+    const int cells_a = fa ? 0 : a.g.n_cells, cells_b = fb ? 0 : b.g.n_cells;  // 0: the struct path has built that side's cell list
+    const int64_t work = std::max<int64_t>((cells_a ? a.c.n : 0) + (int64_t)(cells_b ? b.c.n : 0), n_pairs);
+    const int64_t nbk = (work + 255) / 256;
+    k_prep_count<<<(unsigned)std::max<int64_t>(1, std::min<int64_t>(nbk, 8192)), 256, 0, s>>>(anchors, n_pairs, a, b, cells_a, cells_b, st);
+    ++ops;
+    for (int side = 0; side < 2; ++side) {  // batches with more cells than one workgroup scans
+        const PrepSide& P = side ? b : a;
+        const int cells = side ? cells_b : cells_a;
+        if (cells > kPrepScanCells) { launch_exclusive_scan(s, P.cell_count, P.cell_start, cells, nullptr, P.scan_tmp); ops += 3; }
+    }
+    const bool big = a.c.n > kPrepScanAtoms || b.c.n > kPrepScanAtoms;
+    if (big) {
+        const int64_t nwk = (((int64_t)a.c.n + 31) / 32 + ((int64_t)b.c.n + 31) / 32 + 255) / 256;
+        k_flags_to_bits<<<(unsigned)std::min<int64_t>(nwk, 4096), 256, 0, s>>>(a, b);
         ++ops;
     }
-    if (a.c.n <= kStructAtomsMax && b.c.n <= kStructAtomsMax && !t.no_small_dedupe && a.c.n > 0 && b.c.n > 0) {
-        k_dedupe_finish_small<<<2, 1024, 0, s>>>(a, b, st);
-        return ops + 1;
-    }
-    for (int side = 0; side < 2; ++side) {
-        const PrepSide& P = side ? b : a;
-        launch_exclusive_scan(s, P.slot, P.slot, P.c.n, &st->n_unique[side], P.scan_tmp);
-        if (P.c.n > 0) {
-            const int nb = (P.c.n + 255) / 256;
-            k_compact_anchors<<<nb > 4096 ? 4096 : nb, 256, 0, s>>>(P.slot, P.c.n, P.uniq, P.c, P.pos_of);
-        }
-        ops += 2;
-    }
-    return ops;
+    k_prep_scan<<<2, 1024, 0, s>>>(a, b, cells_a, cells_b, big ? 1 : 0, st);
+    const int64_t nba = ((int64_t)a.c.n + b.c.n + 255) / 256;
+    k_prep_scatter<<<(unsigned)std::max<int64_t>(1, std::min<int64_t>(nba, 8192)), 256, 0, s>>>(a, b, cells_a, cells_b);
+    return ops + 2;
 }
 
 // ------------------------------------------------------------------------------------------------
