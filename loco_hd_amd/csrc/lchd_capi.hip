@@ -727,7 +727,7 @@ static GridPlan plan_grid(const lchd_cloud* cl, double thr) {
 }
 
 struct SideBufs {
-    uint32_t *cell_of, *cell_count, *cell_start, *pos_of, *slot, *scan_tmp, *bits, *wpre;
+    uint32_t *cell_of, *cell_count, *cell_start, *pos_of, *slot, *scan_tmp, *bits, *wpre, *chunk_base;
     uint8_t* flag8;
     AnchorRec* uniq;
     CellRec* rec;
@@ -763,6 +763,7 @@ static void carve_pass(Arena& ar, int64_t n_a, int cells_a, int64_t envs_a, int6
         b.slot = ar.take<uint32_t>(m + 1);
         b.bits = ar.take<uint32_t>((m + 31) / 32 + 1);
         b.wpre = ar.take<uint32_t>((m + 31) / 32 + 2);
+        b.chunk_base = ar.take<uint32_t>((m >> 18) + 2);
         b.cell_start = ar.take<uint32_t>((size_t)n_cells + 1);
         b.rec = ar.take<CellRec>(m);
         b.pos_of = ar.take<uint32_t>(m);
@@ -849,7 +850,7 @@ static int prims_enqueue(lchd_ctx* c) {
         ps.c = cv; ps.g = gv;
         ps.cell_start = sbuf.cell_start; ps.rec = sbuf.rec; ps.pos_of = sbuf.pos_of;
         ps.cell_of = sbuf.cell_of; ps.cell_count = sbuf.cell_count; ps.scan_tmp = sbuf.scan_tmp;
-        ps.flag8 = sbuf.flag8; ps.bits = sbuf.bits; ps.wpre = sbuf.wpre; ps.slot = sbuf.slot; ps.uniq = sbuf.uniq;
+        ps.flag8 = sbuf.flag8; ps.bits = sbuf.bits; ps.wpre = sbuf.wpre; ps.chunk_base = sbuf.chunk_base; ps.slot = sbuf.slot; ps.uniq = sbuf.uniq;
         return ps;
     };
     (void)launch_prologue(s, c->tune, P.anchors, n_pairs, prep_side(cva, gva, sa), prep_side(cvb, gvb, sb), pb.zero_base, pb.zero_bytes,

@@ -147,7 +147,8 @@ struct PrepSide {
     uint32_t* scan_tmp;      // (n_cells / 4096 + 4) u32 of scratch for the multi-block scan
     uint8_t* flag8;          // [n rounded up to 32, + 32] one byte per atom: "is an anchor" (inside the zero region, 16-byte aligned)
     uint32_t* bits;          // [(n + 31) / 32 + 1] the same as a bit set (k_prep_scan / k_flags_to_bits)
-    uint32_t* wpre;          // [(n + 31) / 32 + 2] anchors before each bit-set word
+    uint32_t* wpre;          // [(n + 31) / 32 + 2] anchors before each bit-set word (inside its chunk of 2^18 atoms)
+    uint32_t* chunk_base;    // [(n >> 18) + 2] anchors before each chunk
     uint32_t* slot;          // [n + 1] atom -> environment slot (anchors only)
     AnchorRec* uniq;         // [max_envs]
 };

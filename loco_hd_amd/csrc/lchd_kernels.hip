@@ -405,7 +405,7 @@ __global__ __launch_bounds__(NT) void k_cells_struct2(PrepSide pa, PrepSide pb, 
 //                   plain stores every XCD's L2 absorbs its share)
 //   k_prep_scan     one workgroup per side: exclusive scan of the cell counters (a few thousand cells; batches with more
 //                   than kPrepScanCells cells take the multi-block scan), byte flags -> bit set, scan of the words'
-//                   popcounts (sides of more than kPrepScanAtoms atoms convert in k_flags_to_bits first)
+//                   popcounts (sides of more than kPrepScanAtoms atoms: k_prep_bits first, one workgroup per chunk)
 //   k_prep_scatter  atoms: record into cell order, atom -> position; anchors: environment slot + anchor record
 // (the struct path builds the cell lists in k_cells_struct2 and skips the atom halves of k_prep_count / k_prep_scan)
 constexpr int kPrepScanCells = 1 << 16;  // cells one workgroup scans (64 per thread)
@@ -468,14 +468,37 @@ __device__ __forceinline__ uint32_t flags_word(const uint8_t* __restrict__ flag8
     return nib(lo.x) | (nib(lo.y) << 4) | (nib(lo.z) << 8) | (nib(lo.w) << 12) | (nib(hi.x) << 16) | (nib(hi.y) << 20) | (nib(hi.z) << 24) |
            (nib(hi.w) << 28);
 }
-__global__ void k_flags_to_bits(PrepSide pa, PrepSide pb) {
-    const int64_t wa = ((int64_t)pa.c.n + 31) >> 5, wb = ((int64_t)pb.c.n + 31) >> 5;
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < wa + wb; t += (int64_t)gridDim.x * blockDim.x) {
-        const bool sb_ = t >= wa;
-        const PrepSide& P = sb_ ? pb : pa;
-        const int64_t w = sb_ ? t - wa : t;
-        P.bits[w] = flags_word(P.flag8, w);
+// Sides of more than kPrepScanAtoms atoms (trajectory batches: millions of atoms): one workgroup per chunk of
+// kPrepScanAtoms atoms turns the chunk's byte flags into bit-set words, scans the words' popcounts inside the chunk (wpre =
+// anchors before the word WITHIN its chunk) and leaves the chunk's total in chunk_base[chunk]; k_prep_scan then only scans the
+// chunk totals.  (One workgroup walking 80 000 words took longer than the cell lists of the whole batch.)
+constexpr int kChunkWords = kPrepScanAtoms / 32;  // 8192 words, 8 consecutive ones per thread
+__global__ __launch_bounds__(1024) void k_prep_bits(PrepSide pa, PrepSide pb, int chunks_a) {
+    __shared__ uint32_t wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool sb_ = (int)blockIdx.x >= chunks_a;
+    const PrepSide& P = sb_ ? pb : pa;
+    const int chunk = sb_ ? blockIdx.x - chunks_a : blockIdx.x;
+    const int64_t nw = ((int64_t)P.c.n + 31) >> 5, w0 = (int64_t)chunk * kChunkWords + 8 * tid;
+    uint32_t bw[8], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        bw[k] = w0 + k < nw ? flags_word(P.flag8, w0 + k) : 0u;
+        sum += (uint32_t)__popc(bw[k]);
     }
+    const uint32_t incl = wave_incl_scan_u32(sum);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t pre = incl - sum, total = 0;
+    for (int w = 0; w < 16; ++w) { if (w < wave) pre += wsum[w]; total += wsum[w]; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (w0 + k < nw) {
+            P.bits[w0 + k] = bw[k];
+            P.wpre[w0 + k] = pre;
+            pre += (uint32_t)__popc(bw[k]);
+        }
+    if (tid == 0) P.chunk_base[chunk] = total;
 }
 __global__ __launch_bounds__(1024) void k_prep_scan(PrepSide pa, PrepSide pb, int cells_a, int cells_b, int bits_ready, DeviceStatus* st) {
     __shared__ uint32_t wsum[16];
@@ -484,10 +507,15 @@ __global__ __launch_bounds__(1024) void k_prep_scan(PrepSide pa, PrepSide pb, in
     const int cells = side ? cells_b : cells_a;
     if (cells > 0 && cells <= kPrepScanCells) scan_wg_1024(P.cell_count, P.cell_start, cells, false, wsum);
     const int64_t nw = ((int64_t)P.c.n + 31) >> 5;
-    if (!bits_ready) {
-        for (int64_t w = threadIdx.x; w < nw; w += 1024) P.bits[w] = flags_word(P.flag8, w);
-        __syncthreads();  // (the scan below reads words other threads of this workgroup wrote)
+    if (bits_ready) {  // k_prep_bits has done the words and the scans inside the chunks: only the chunk totals are left
+        const int64_t n_chunks = (nw + kChunkWords - 1) / kChunkWords;
+        const uint32_t total = scan_wg_1024(P.chunk_base, P.chunk_base, n_chunks, false, wsum);
+        if (threadIdx.x == 0) st->n_unique[side] = total;
+        return;
     }
+    for (int64_t w = threadIdx.x; w < nw; w += 1024) P.bits[w] = flags_word(P.flag8, w);
+    __syncthreads();  // (the scan below reads words other threads of this workgroup wrote)
+    if (threadIdx.x == 0) P.chunk_base[0] = 0u;
     const uint32_t total = scan_wg_1024(P.bits, P.wpre, nw, true, wsum);
     if (threadIdx.x == 0) st->n_unique[side] = total;
 }
@@ -516,7 +544,7 @@ __global__ void k_prep_scatter(PrepSide pa, PrepSide pb, int cells_a, int cells_
             P.pos_of[i] = pos;
         }
         if (anchor) {  // its environment slot and its record
-            const uint32_t sl = P.wpre[i >> 5] + (uint32_t)__popc(w & ((1u << (i & 31)) - 1u));
+            const uint32_t sl = P.chunk_base[i >> 18] + P.wpre[i >> 5] + (uint32_t)__popc(w & ((1u << (i & 31)) - 1u));
             P.slot[i] = sl;
             AnchorRec r;
             r.x = x; r.y = y; r.z = z;
@@ -584,8 +612,8 @@ int launch_prologue(hipStream_t s, const Tuning& t, const int64_t* anchors, int6
     }
     const bool big = a.c.n > kPrepScanAtoms || b.c.n > kPrepScanAtoms;
     if (big) {
-        const int64_t nwk = (((int64_t)a.c.n + 31) / 32 + ((int64_t)b.c.n + 31) / 32 + 255) / 256;
-        k_flags_to_bits<<<(unsigned)std::min<int64_t>(nwk, 4096), 256, 0, s>>>(a, b);
+        const int ca = (int)((((int64_t)a.c.n + 31) / 32 + kChunkWords - 1) / kChunkWords), cb = (int)((((int64_t)b.c.n + 31) / 32 + kChunkWords - 1) / kChunkWords);
+        k_prep_bits<<<ca + cb, 1024, 0, s>>>(a, b, ca);
         ++ops;
     }
     k_prep_scan<<<2, 1024, 0, s>>>(a, b, cells_a, cells_b, big ? 1 : 0, st);
@@ -1704,6 +1732,7 @@ __device__ __forceinline__ void sweep_report(HostStatus* h, uint32_t bit) { h->s
 // Called by ONE thread per workgroup; returns true in exactly one workgroup, which then collects the accumulators with
 // atomic exchanges (resetting them).  Everything is left at zero.
 constexpr int kDoneStride = 32;  // u32 per slot: 128 bytes apart
+static_assert(kPrepScanAtoms == 1 << 18, "k_prep_scatter: chunk of atom i = i >> 18");
 static_assert(sizeof(DoneState) == (65 + 64 + 64) * kDoneStride * 4, "DoneState layout (lchd_device.h)");
 __device__ __forceinline__ bool last_workgroup_done(DoneState* d, unsigned long long add_sum, uint32_t add_max) {
     const uint32_t n = gridDim.x, G = n < 64u ? n : 64u, g = blockIdx.x % G;
