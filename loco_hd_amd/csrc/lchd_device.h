@@ -221,6 +221,7 @@ struct SweepArgs {
     int32_t duo_enabled;      // set by launch_sweep: k_sweep_duo was launched too and sweeps the small pairs when they are the majority
     int32_t small_rule;       // set by launch_sweep: which pairs count as "small" (0: <= kDuoTile merged events, k_sweep_duo; 1: both
                               // environments <= 255 points, the 8-bit-count k_sweep); the indirect k_sweep takes the others
+    int32_t gen_tab;          // set by launch_sweep: MODE_GEN may use power tables (Hellinger with a general exponent, unit category weights)
     int32_t forced;           // set by launch_sweep: the host picked the sweep kernels (hint from the previous pass): no device-side decision
 };
 // sweep_hint: 0 = unknown (launch every candidate kernel, the device decides from the pair records), 1 = the previous pass of

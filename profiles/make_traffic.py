@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""traffic_<workload>.json for bench.py's roofline block, from a workload's PMC summary (profiles/summarize_pmc.py) and its
+kernel-trace statistics:  make_traffic.py <workload> <pmc_summary.txt> <kernel_stats.csv>
+
+HBM-side bytes follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE counts 64 B per 128-B fabric
+read request, so read bytes = 2 x FETCH_SIZE x 1024 (cross-check printed: TCC_MISS_sum x 128 B); WRITE_SIZE x 1024 as is.
+valu_issue_frac = SQ_ACTIVE_INST_VALU x 4 cycles / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs): the share of the launch's cycles in
+which a SIMD issued a vector instruction (SQ_ACTIVE_INST_* count quad-cycles summed over the chip)."""
+import ast
+import csv
+import json
+import sys
+
+DOMINANT = {"c2a": "k_sweep<12", "c5": "k_sweep<28", "c4": "k_env_cells<64", "c3": "k_sweep_duo<8>", "c2b": "k_env_rows2<1024, 10"}
+
+
+def main(workload, summary, stats):
+    want = DOMINANT[workload]
+    counters, name = {}, None
+    for line in open(summary):
+        if "| per-dispatch:" not in line:
+            continue
+        kname = line.split(" | ")[0]
+        if want not in kname or "true, true" in kname.split("(")[0].replace(want, ""):  # (not the INDIRECT companion)
+            continue
+        if name is None:
+            name = kname
+        if kname == name:
+            counters.update(ast.literal_eval(line.split("per-dispatch: ")[1]))
+    avg_ns = None
+    with open(stats, newline="") as fh:
+        for row in csv.DictReader(fh):
+            if name and row["Name"].split("(")[0] == name.strip():
+                avg_ns = float(row["AverageNs"])
+    if not name:
+        raise SystemExit(f"no kernel matching {want!r} in {summary}")
+    read_b = 2 * counters.get("FETCH_SIZE", 0) * 1024
+    write_b = counters.get("WRITE_SIZE", 0) * 1024
+    out = {"workload": workload, "kernel": name.strip().replace("void ", "").replace("lchd::", ""), "per_launch": counters,
+           "avg_launch_ns_kernel_trace": avg_ns,
+           "traffic_bytes_per_launch": read_b + write_b,
+           "read_bytes": read_b, "write_bytes": write_b, "tcc_miss_x128_crosscheck": counters.get("TCC_MISS_sum", 0) * 128,
+           "correction": "read bytes = 2 x FETCH_SIZE x 1024 (gfx950: 64 B counted per 128-B fabric request), write bytes = WRITE_SIZE x 1024"}
+    if counters.get("GRBM_GUI_ACTIVE") and counters.get("SQ_ACTIVE_INST_VALU"):
+        cyc = counters["GRBM_GUI_ACTIVE"] / 8.0
+        out["valu_issue_frac"] = counters["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / cyc
+        out["lds_issue_frac"] = counters.get("SQ_ACTIVE_INST_LDS", 0) * 4.0 / 1024.0 / cyc
+        if avg_ns:
+            out["clock_ghz_during_counter_pass"] = cyc / avg_ns
+        out["binding"] = "valu issue" if out["valu_issue_frac"] > 0.5 else "latency (neither the vector pipes nor HBM are busy half the time)"
+    if counters.get("SQ_INSTS_VALU") and counters.get("SQ_WAVES"):
+        out["valu_insts_per_wave"] = counters["SQ_INSTS_VALU"] / counters["SQ_WAVES"]
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
