@@ -174,6 +174,8 @@ struct lchd_ctx {
     int sweep_hint = 0;                // 0 unknown, 1 small pairs were the majority in the last pass, 2 they were not (launch_sweep)
     unsigned long long* d_points = nullptr;
     double* d_tabs = nullptr;  // sqrt(k) | 1/sqrt(k), 65536 entries each
+    double* d_powtab = nullptr;  // k^(1/e) | k^(-1/e) for the configured Hellinger exponent (allocated when one is first configured)
+    double powtab_e = 0.0;       // the exponent the table holds
     DoneState* d_done = nullptr;     // 'last workgroup' counters / accumulators of k_pair_meta (zero between kernels)
     // host-pointer calls: one grow-only device block + pinned staging block per context (no allocation in the steady state)
     char *d_io = nullptr, *h_io = nullptr;
@@ -341,6 +343,7 @@ extern "C" void lchd_ctx_destroy(lchd_ctx* c) {
     (void)hipFree(c->d_status);
     (void)hipFree(c->d_points);
     (void)hipFree(c->d_tabs);
+    (void)hipFree(c->d_powtab);
     (void)hipFree(c->d_done);
     (void)hipFree(c->d_io);
     (void)hipFree(c->d_shard);
@@ -471,6 +474,16 @@ extern "C" int lchd_ctx_set_config(lchd_ctx* c, const lchd_config* cfg) {
     h.wf_finf = reinterpret_cast<const double*>(c->d_blob + o_f);
     h.wf_inv = reinterpret_cast<const double*>(c->d_blob + o_i);
     h.tag_pairs = reinterpret_cast<const uint64_t*>(c->d_blob + o_t);
+    h.pow_tab = nullptr;
+    if (cfg->sd_kind == LCHD_SD_HELLINGER && cfg->sd_params[0] != 2.0) {  // power tables of the general-exponent Hellinger distance
+        if (!c->d_powtab) HIP_TRY(hipMalloc(&c->d_powtab, sizeof(double) * 2 * 65536));
+        if (c->powtab_e != cfg->sd_params[0]) {
+            launch_fill_pow_tables(c->stream, c->d_powtab, cfg->sd_params[0]);
+            HIP_TRY(hipGetLastError());
+            c->powtab_e = cfg->sd_params[0];
+        }
+        h.pow_tab = c->d_powtab;
+    }
     HIP_TRY(hipMemcpy(c->d_cfg, &h, sizeof h, hipMemcpyHostToDevice));
     c->h_cfg = h;
     c->hellinger2 = (cfg->sd_kind == LCHD_SD_HELLINGER && cfg->sd_params[0] == 2.0);

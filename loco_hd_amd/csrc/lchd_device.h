@@ -83,6 +83,7 @@ struct DevConfig {
     const double* wf_finf;      // [n_wf] F(+inf) per weight function (host-evaluated; 1.0 except for degenerate dagum)
     const double* wf_inv;       // [n_wf] 1 / (the CDF's constant divisor): 1 / sum a_i (hyper_exp), 1 / (x_max - x_min) (uniform, kumaraswamy)
     const uint64_t* tag_pairs;  // sorted, (anchor_tag << 32) | neighbour_tag
+    const double* pow_tab;      // Hellinger with exponent e != 2: [2][65536] k^(1/e), k^(-1/e) (context-owned, filled by set_config); else null
 };
 
 // SoA structure in HBM.
@@ -243,6 +244,7 @@ void launch_frames_centroids(hipStream_t s, const float* raw, int64_t n_src, con
 int centroid_tile_span();
 int bbox_parts_capacity();
 void launch_fill_sqrt_tables(hipStream_t s, double* sqrt_tab, double* rsqrt_tab);  // 65536 entries each
+void launch_fill_pow_tables(hipStream_t s, double* tab /* [2][65536] */, double exponent);  // k^(1/e), k^(-1/e)
 
 // Multi-GPU sharding of an anchor-pair list by side-A anchor (see lchd_kernels.hip).  ShardState lives in device memory,
 // zero-initialised once; hist / cursor / done are zero again after every plan.

@@ -767,8 +767,12 @@ __device__ const double kLogCTab[128] = {
     0x1.53aad05b99b7cp-1, 0x1.55b9354b40bcep-1, 0x1.57c57f336f191p-1, 0x1.59cfb25fae87fp-1,
     0x1.5bd7d30e71c73p-1, 0x1.5ddde57149923p-1, 0x1.5fe1edad18919p-1, 0x1.61e3efda46467p-1,
 };
+// (the library routines stay out of line: inlined at every call site of the unrolled per-category loops they made the generic
+// sweep kernels several hundred KB of code, beyond the reach of a conditional branch)
+__device__ __noinline__ double log_library(double x) { return log(x); }
+__device__ __noinline__ double pow_library(double x, double y) { return pow(x, y); }
 __device__ __forceinline__ double log_fast(double x) {
-    if (!(x >= 0x1p-1022) || !(x < INFINITY)) return log(x);  // zero, subnormal, negative, inf, NaN: the library's semantics
+    if (!(x >= 0x1p-1022) || !(x < INFINITY)) return log_library(x);  // zero, subnormal, negative, inf, NaN: the library's semantics
     const unsigned long long u = (unsigned long long)__double_as_longlong(x);
     const int k = (int)(u >> 52) - 1023;
     const int j = (int)((u >> 45) & 127ull);
@@ -790,7 +794,7 @@ __device__ __forceinline__ double log_fast(double x) {
 // inside the path's 1e-6 (and the tests' 1e-11).
 __device__ __forceinline__ double pow_fast(double x, double y) {
     if (x == 0.0) return y > 0.0 ? 0.0 : (y == 0.0 ? 1.0 : INFINITY);
-    if (!(x > 0.0) || !(x < INFINITY)) return pow(x, y);  // negative, inf, NaN: the library's semantics
+    if (!(x > 0.0) || !(x < INFINITY)) return pow_library(x, y);  // negative, inf, NaN: the library's semantics
     return exp_fast(y * log_fast(x));
 }
 
@@ -1916,6 +1920,55 @@ __device__ __forceinline__ uint64_t spread8(uint64_t x) {
     return ((uint64_t)half(v >> 16) << 32) | half(v & 0xFFFFu);
 }
 
+// StatisticalDistance::run for Hellinger with a general exponent (statistical_distances.rs:4-10) and Renyi (:31-78) on the
+// weighted category counts va / vb with sums sa / sb (pmf.rs:65-83 normalises by the sums).  Out of line, runtime loops.
+//   Hellinger: p^(1/e) = va^(1/e) * sa^(-1/e).  With unit category weights va and sa are integers (< 65536: the count fields
+//   are 16 bits), so both factors come from the configuration's tables pow_tab[k] = k^(1/e), pow_tab[65536 + k] = k^(-1/e)
+//   (library pow, filled when the configuration is set): one pow per category -- |x - y|^e -- instead of three, none when
+//   e is 1, 2, 3 or 4.  Weighted categories take pow_fast for all three.
+//   Renyi: ratio^(alpha - 1) = exp((alpha - 1) ln ratio) through the fast log / exp.
+__device__ __noinline__ double sd_generic_fast(int kind, double p0, double p1, const double* va, const double* vb, double sa, double sb, int C,
+                                               const double* __restrict__ pow_tab) {
+    const double ia = 1.0 / sa, ib = 1.0 / sb;  // (one reciprocal per side: <= 1 ulp from pmf.rs:78-81's per-category divisions)
+    if (kind == SD_HELLINGER) {
+        const double e = p0, einv = 1.0 / e;
+        const int ie = (e == 1.0 || e == 2.0 || e == 3.0 || e == 4.0) ? (int)e : 0;  // |d|^e by multiplication
+        double na1 = 0.0, nb1 = 0.0;
+        if (pow_tab) { na1 = pow_tab[65536 + (int)sa]; nb1 = pow_tab[65536 + (int)sb]; }
+        double dist = 0.0;
+#pragma unroll 2
+        for (int c = 0; c < C; ++c) {
+            double x, y;
+            if (pow_tab) { x = pow_tab[(int)va[c]] * na1; y = pow_tab[(int)vb[c]] * nb1; }
+            else { x = pow_fast(va[c] * ia, einv); y = pow_fast(vb[c] * ib, einv); }
+            const double d = fabs(x - y);
+            dist += ie == 1 ? d : (ie == 2 ? d * d : (ie == 3 ? d * d * d : (ie == 4 ? (d * d) * (d * d) : pow_fast(d, e))));
+        }
+        return pow_fast(dist / 2.0, einv);
+    }
+    const double alpha = p0, eps = p1;
+    if (alpha == (double)INFINITY) {
+        double best = 0.0;
+        for (int c = 0; c < C; ++c) {
+            const double r = (va[c] * ia + eps) / (vb[c] * ib + eps);
+            best = (c == 0 || r >= best) ? r : best;
+        }
+        return log_fast(best);
+    }
+    if (alpha == 0.0) {
+        double sm = 0.0;
+        for (int c = 0; c < C; ++c) sm += (va[c] > 0.0) ? vb[c] * ib : 0.0;
+        return -log_fast(sm);
+    }
+    double sm = 0.0;
+#pragma unroll 2
+    for (int c = 0; c < C; ++c) {
+        const double x = va[c] * ia;
+        sm += x * pow_fast((x + eps) / (vb[c] * ib + eps), alpha - 1.0);
+    }
+    return log_fast(sm) / (alpha - 1.0);
+}
+
 // One pair's weight function.  hyper_exp with <= 4 terms and uniform keep their parameters in (scalar)
 // registers; everything else goes through the out-of-line evaluator with the parameter pointer.
 struct WfRegs {
@@ -2038,19 +2091,10 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
     const int C = cfgp->n_categories;
     const double* __restrict__ g_sqrt = args.sqrt_tab;    // [65536] sqrt(k)
     const double* __restrict__ g_rsqrt = args.rsqrt_tab;  // [65536] 1/sqrt(k)
-    // MODE_GEN, Hellinger distance with a general exponent e and unit weights: p_c^(1/e) = a_c^(1/e) * N_a^(-1/e) with integer
-    // counts, so the LDS tables hold k^(1/e) and k^(-1/e) instead of the square roots (library pow, once per workgroup)
-    const bool gen_tab = (MODE == MODE_GEN) && LDSTAB && args.gen_tab != 0;
     if constexpr (LDSTAB)
         for (int k = tid; k < NT; k += 64 * WPB) {
-            if (gen_tab) {
-                const double einv = 1.0 / cfgp->sd_p0;
-                t_sqrt[k] = pow((double)k, einv);
-                t_rsqrt[k] = pow((double)k, -einv);
-            } else {
-                t_sqrt[k] = g_sqrt[k];
-                t_rsqrt[k] = g_rsqrt[k];
-            }
+            t_sqrt[k] = g_sqrt[k];
+            t_rsqrt[k] = g_rsqrt[k];
         }
     if (tid < 32) {
         const double wv_ = tid < C ? cfgp->cat_w[tid] : 0.0;
@@ -2343,51 +2387,12 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
                     }
                     return dist;
                 }
-                if (kind == SD_HELLINGER) {  // :4-10 with a general exponent (exponent 2 has its own kernels)
-                    const double e = prm0, einv = 1.0 / e;
-                    const int ie = (e == 1.0 || e == 2.0 || e == 3.0 || e == 4.0) ? (int)e : 0;  // |d|^e by multiplication
-                    double na1 = 0.0, nb1 = 0.0;
-                    if (gen_tab) { na1 = t_rsqrt[(int)sa_]; nb1 = t_rsqrt[(int)sb_]; }  // N^(-1/e): unit weights, the sums are the point counts
-                    double dist = 0.0;
+                // Hellinger with a general exponent, Renyi: one out-of-line call per event on a scratch copy of the weighted counts
+                // (inlined into the unrolled per-category loops these branches tripled the kernel's size)
+                double ca_[CMAX], cb_[CMAX];
 #pragma unroll
-                    for (int c = 0; c < CMAX; ++c) {
-                        if (c < C) {
-                            double x, y;
-                            if (gen_tab) { x = t_sqrt[(int)va[c]] * na1; y = t_sqrt[(int)vb[c]] * nb1; }
-                            else { x = pow_fast(va[c] * ia_, einv); y = pow_fast(vb[c] * ib_, einv); }
-                            const double d = fabs(x - y);
-                            dist += ie == 1 ? d : (ie == 2 ? d * d : (ie == 3 ? d * d * d : (ie == 4 ? (d * d) * (d * d) : pow_fast(d, e))));
-                        }
-                    }
-                    return pow_fast(dist / 2.0, einv);
-                }
-                // Renyi, :31-78
-                const double alpha = prm0, eps = prm1;
-                if (alpha == (double)INFINITY) {
-                    double best = 0.0;
-#pragma unroll
-                    for (int c = 0; c < CMAX; ++c)
-                        if (c < C) {
-                            const double r = (va[c] * ia_ + eps) / (vb[c] * ib_ + eps);
-                            best = (c == 0 || r >= best) ? r : best;
-                        }
-                    return log_fast(best);
-                }
-                if (alpha == 0.0) {
-                    double sm = 0.0;
-#pragma unroll
-                    for (int c = 0; c < CMAX; ++c)
-                        if (c < C) sm += (va[c] > 0.0) ? vb[c] * ib_ : 0.0;
-                    return -log_fast(sm);
-                }
-                double sm = 0.0;
-#pragma unroll
-                for (int c = 0; c < CMAX; ++c)
-                    if (c < C) {
-                        const double x = va[c] * ia_;
-                        sm += x * pow_fast((x + eps) / (vb[c] * ib_ + eps), alpha - 1.0);
-                    }
-                return log_fast(sm) / (alpha - 1.0);
+                for (int c = 0; c < CMAX; ++c) { ca_[c] = va[c]; cb_[c] = vb[c]; }
+                return sd_generic_fast(kind, prm0, prm1, ca_, cb_, sa_, sb_, C, args.gen_tab ? cfgp->pow_tab : nullptr);
             }
         };
 
@@ -3307,7 +3312,7 @@ void launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool helling
     SweepArgs a = a_in;
     a.duo_enabled = 0;
     a.forced = 0;
-    a.gen_tab = (unit_weights && !t.no_tables) ? 1 : 0;  // (only the Hellinger branch of MODE_GEN looks at it)
+    a.gen_tab = (unit_weights && !t.no_tables) ? 1 : 0;  // (MODE_GEN, Hellinger with a general exponent: the configuration's power tables apply)
     if (t.force_generic) hellinger2 = false;  // test hook
     if (a.n_pairs <= kInlineMetaPairs && !t.no_inline_meta && hellinger2 && unit_weights && n_categories <= 32 && !t.force_wide &&
         a.env_a.cdf_keys && a.env_b.cdf_keys && a.env_a.stride <= kSqrtTab && a.env_b.stride <= kSqrtTab && !t.force_bigenv) {
@@ -3597,6 +3602,14 @@ extern "C" int lchd_debug_sweep_stamps(unsigned long long* out8, int reset) {
 }
 namespace lchd {
 #endif
+__global__ void k_fill_pow_tables(double* tab, double einv) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < 65536) {
+        tab[k] = pow((double)k, einv);
+        tab[65536 + k] = pow((double)k, -einv);
+    }
+}
+void launch_fill_pow_tables(hipStream_t s, double* tab, double exponent) { k_fill_pow_tables<<<256, 256, 0, s>>>(tab, 1.0 / exponent); }
 void launch_fill_sqrt_tables(hipStream_t s, double* sqrt_tab, double* rsqrt_tab) {
     k_fill_sqrt_tables<<<256, 256, 0, s>>>(sqrt_tab, rsqrt_tab);
 }
