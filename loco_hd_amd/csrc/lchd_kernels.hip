@@ -1921,13 +1921,15 @@ __device__ __forceinline__ uint64_t spread8(uint64_t x) {
 }
 
 // StatisticalDistance::run for Hellinger with a general exponent (statistical_distances.rs:4-10) and Renyi (:31-78) on the
-// weighted category counts va / vb with sums sa / sb (pmf.rs:65-83 normalises by the sums).  Out of line, runtime loops.
+// weighted category counts va / vb with sums sa / sb (pmf.rs:65-83 normalises by the sums).  Inlined (a call from a kernel
+// with ~200 live registers costs more in saves and restores than the arithmetic), but with RUNTIME loops over the categories
+// on a scratch copy of the counts: one copy of the per-category code, not one per unrolled slot.
 //   Hellinger: p^(1/e) = va^(1/e) * sa^(-1/e).  With unit category weights va and sa are integers (< 65536: the count fields
 //   are 16 bits), so both factors come from the configuration's tables pow_tab[k] = k^(1/e), pow_tab[65536 + k] = k^(-1/e)
 //   (library pow, filled when the configuration is set): one pow per category -- |x - y|^e -- instead of three, none when
 //   e is 1, 2, 3 or 4.  Weighted categories take pow_fast for all three.
 //   Renyi: ratio^(alpha - 1) = exp((alpha - 1) ln ratio) through the fast log / exp.
-__device__ __noinline__ double sd_generic_fast(int kind, double p0, double p1, const double* va, const double* vb, double sa, double sb, int C,
+__device__ __forceinline__ double sd_generic_fast(int kind, double p0, double p1, const double* va, const double* vb, double sa, double sb, int C,
                                                const double* __restrict__ pow_tab) {
     const double ia = 1.0 / sa, ib = 1.0 / sb;  // (one reciprocal per side: <= 1 ulp from pmf.rs:78-81's per-category divisions)
     if (kind == SD_HELLINGER) {
@@ -1936,7 +1938,7 @@ __device__ __noinline__ double sd_generic_fast(int kind, double p0, double p1, c
         double na1 = 0.0, nb1 = 0.0;
         if (pow_tab) { na1 = pow_tab[65536 + (int)sa]; nb1 = pow_tab[65536 + (int)sb]; }
         double dist = 0.0;
-#pragma unroll 2
+#pragma unroll 1
         for (int c = 0; c < C; ++c) {
             double x, y;
             if (pow_tab) { x = pow_tab[(int)va[c]] * na1; y = pow_tab[(int)vb[c]] * nb1; }
@@ -1949,6 +1951,7 @@ __device__ __noinline__ double sd_generic_fast(int kind, double p0, double p1, c
     const double alpha = p0, eps = p1;
     if (alpha == (double)INFINITY) {
         double best = 0.0;
+#pragma unroll 1
         for (int c = 0; c < C; ++c) {
             const double r = (va[c] * ia + eps) / (vb[c] * ib + eps);
             best = (c == 0 || r >= best) ? r : best;
@@ -1957,11 +1960,12 @@ __device__ __noinline__ double sd_generic_fast(int kind, double p0, double p1, c
     }
     if (alpha == 0.0) {
         double sm = 0.0;
+#pragma unroll 1
         for (int c = 0; c < C; ++c) sm += (va[c] > 0.0) ? vb[c] * ib : 0.0;
         return -log_fast(sm);
     }
     double sm = 0.0;
-#pragma unroll 2
+#pragma unroll 1
     for (int c = 0; c < C; ++c) {
         const double x = va[c] * ia;
         sm += x * pow_fast((x + eps) / (vb[c] * ib + eps), alpha - 1.0);
@@ -2387,8 +2391,9 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
                     }
                     return dist;
                 }
-                // Hellinger with a general exponent, Renyi: one out-of-line call per event on a scratch copy of the weighted counts
-                // (inlined into the unrolled per-category loops these branches tripled the kernel's size)
+                // Hellinger with a general exponent, Renyi: runtime loops over a scratch copy of the weighted counts (unrolled per
+                // category slot these branches tripled the kernel's size; as an out-of-line call the register saves cost more
+                // than the arithmetic)
                 double ca_[CMAX], cb_[CMAX];
 #pragma unroll
                 for (int c = 0; c < CMAX; ++c) { ca_[c] = va[c]; cb_[c] = vb[c]; }
