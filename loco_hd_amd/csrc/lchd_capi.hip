@@ -745,6 +745,8 @@ struct SideBufs {
     AnchorRec* uniq;
     CellRec* rec;
     EnvStore env;
+    double* raw_key;   // environments of more than 16384 points: unsorted scratch rows (k_env_collect)
+    uint8_t* raw_cat;
 };
 
 // Workspace layout of one pass.  Everything that must be zero when the prologue starts -- the general cell list's counters
@@ -787,6 +789,8 @@ static void carve_pass(Arena& ar, int64_t n_a, int cells_a, int64_t envs_a, int6
         b.env.len = ar.take<int32_t>(ne);
         b.env.stride = cap;
         b.env.cdf_keys = 0;
+        b.raw_key = cap > 16384 ? ar.take<double>(ne * (size_t)cap) : nullptr;
+        b.raw_cat = cap > 16384 ? ar.take<uint8_t>(ne * (size_t)cap) : nullptr;
     }
     pb.pair_meta = ar.take<int4>((size_t)n_pairs);
 }
@@ -871,7 +875,7 @@ static int prims_enqueue(lchd_ctx* c) {
     mark(c, 1);
     mark(c, 2);  // (cell lists and anchor de-duplication are one phase now; "anchors" reads 0)
     const bool tag_list = c->h_cfg.tag_mode != 0;
-    const EnvSide esa{cva, gva, sa.uniq, sa.env, max_env_a}, esb{cvb, gvb, sb.uniq, sb.env, max_env_b};
+    const EnvSide esa{cva, gva, sa.uniq, sa.env, max_env_a, sa.raw_key, sa.raw_cat}, esb{cvb, gvb, sb.uniq, sb.env, max_env_b, sb.raw_key, sb.raw_cat};
     if (!launch_env_cells(s, cap, c->d_cfg, tag_list, esa, esb, thr, c->d_status))
         return fail(LCHD_EUNSUPPORTED, "no environment kernel variant with capacity %d", cap);
     mark(c, 3);
@@ -934,9 +938,9 @@ extern "C" int lchd_ctx_finish(lchd_ctx* c) {
         if (f & ST_BAD_ANCHOR) return status_to_rc(f, DRV_PRIMS);
         const int64_t biggest = c->h_status->max_env;  // largest environment of the pass (k_pair_meta), or what overflowed
         if (f & ST_ENV_OVERFLOW) {  // an environment did not fit the kernel variant's LDS capacity: run the pass again, larger
-            if (biggest > 16384)
-                return fail(LCHD_EUNSUPPORTED, "an environment holds %lld points; this build sorts at most 16384 per environment",
-                            (long long)biggest);
+            if (biggest > 65535)
+                return fail(LCHD_EUNSUPPORTED, "an environment holds %lld points; this build handles at most 65535 per environment "
+                                               "(the category counts of the sweep are 16-bit fields)", (long long)biggest);
             P.cap = next_pow2_host(biggest);
             c->cap_hint = P.cap;
             c->shrink_votes = 0;

@@ -169,6 +169,8 @@ struct EnvSide {
     const AnchorRec* uniq;
     EnvStore env;
     int64_t max_envs;   // upper bound of the side's unique anchors (the kernel stops at DeviceStatus::n_unique[side])
+    double* raw_key;    // environments of more than 16384 points only: [max_envs][cap] unsorted distances ...
+    uint8_t* raw_cat;   // ... and categories (k_env_collect -> k_env_rows)
 };
 struct EnvSides {
     EnvSide s[2];
@@ -177,9 +179,14 @@ bool launch_env_cells(hipStream_t s, int cap, const DevConfig* cfg, bool tag_lis
                       DeviceStatus* st);
 
 // dense rows: either distances from coordinates (dmx == nullptr) or given rows (dmx != nullptr, leading dim ld)
+struct RowExtras {            // all null for from_coords / from_dmxs
+    const uint8_t* row_cat;   // [n_rows][ld] categories of the row's own points (instead of the structure's)
+    const int32_t* row_lens;  // [n_rows] points of each row (<= 0: skip the row)
+    const uint32_t* n_unique; // rows at or beyond *n_unique do not exist
+};
 bool launch_env_rows(hipStream_t s, int cap, const DevConfig* cfg, const CloudView& c, const double* dmx, int64_t ld,
                      int64_t n_rows, int64_t row_len, double image_bound /* coords: >= largest squared distance, or 0 */, EnvStore env,
-                     DeviceStatus* st);
+                     DeviceStatus* st, const RowExtras& ex = RowExtras{nullptr, nullptr, nullptr});
 
 // "last workgroup" detection + hand-over through memory-side atomics (lchd_kernels.hip: last_workgroup_done)
 struct DoneState {

@@ -1221,9 +1221,91 @@ static void launch_env_cells_nt(hipStream_t s, dim3 grid, size_t lds, bool tag_l
     else k_env_cells<NT, false><<<grid, NT, lds, s>>>(cfg, sides, thr, cap, st);
 }
 
+// Thresholded environments of more than 16384 points (a threshold that swallows most of a large structure): too many keys for
+// LDS.  One 1024-thread workgroup per unique anchor walks the neighbour cells like k_env_cells and appends the survivors --
+// distance and category -- UNSORTED to the environment's scratch row in global memory; k_env_rows then sorts each scratch row
+// into the environment store in global memory (rows of up to 65535 points), exactly as it does for given distance rows.
+template <bool TAGLIST>
+__global__ __launch_bounds__(1024) void k_env_collect(const DevConfig* __restrict__ cfgp, EnvSides sides, double thr, int cap, DeviceStatus* st) {
+    const int side = (int64_t)blockIdx.x >= sides.s[0].max_envs ? 1 : 0;
+    const EnvSide& S = sides.s[side];
+    const GridView g = S.g;
+    const int64_t e = (int64_t)blockIdx.x - (side ? sides.s[0].max_envs : 0);
+    __shared__ int count_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (e >= (int64_t)st->n_unique[side]) return;
+    const DevConfig cfg = *cfgp;
+    const AnchorRec arec = S.uniq[e];
+    const double ax = arec.x, ay = arec.y, az = arec.z, thr2 = thr * thr;
+    const int32_t atag = (int32_t)arec.tag;
+    const bool accept_same = cfg.tag_accept_same != 0;
+    const int cx = cell_coord(ax, g.min[0], g.inv[0], g.dim[0]);
+    const int cy = cell_coord(ay, g.min[1], g.inv[1], g.dim[1]);
+    const int cz = cell_coord(az, g.min[2], g.inv[2], g.dim[2]);
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
+    double* __restrict__ rk = S.raw_key + e * (int64_t)cap;
+    uint8_t* __restrict__ rc = S.raw_cat + e * (int64_t)cap;
+    if (tid == 0) count_s = 0;
+    __syncthreads();
+    for (int zz = max(cz - 1, 0); zz <= min(cz + 1, g.dim[2] - 1); ++zz)
+        for (int yy = max(cy - 1, 0); yy <= min(cy + 1, g.dim[1] - 1); ++yy) {
+            const int row = (int)((((int64_t)arec.sid * g.dim[2] + zz) * g.dim[1] + yy) * g.dim[0]);
+            const int beg = (int)g.cell_start[row + x0], end = (int)g.cell_start[row + x1 + 1];
+            for (int base = beg + wave * 64; base < end; base += 1024) {
+                const int idx = base + lane;
+                bool ok = false;
+                double d2 = 0.0;
+                uint32_t ccat = 0;
+                if (idx < end) {
+                    const CellRec r = g.rec[idx];
+                    const double dx = r.x - ax, dy = r.y - ay, dz = r.z - az;
+                    d2 = dx * dx;  // utils.rs:1-8 order, uncontracted
+                    d2 = d2 + dy * dy;
+                    d2 = d2 + dz * dz;
+                    ccat = r.cat;
+                    if (d2 < thr2) {
+                        if constexpr (TAGLIST) ok = ((uint32_t)idx == arec.apos) || tag_pair_accepted(cfg, atag, (int32_t)r.tag);
+                        else ok = ((uint32_t)idx == arec.apos) || ((atag == (int32_t)r.tag) == accept_same);
+                    }
+                }
+                const unsigned long long m = __ballot(ok);
+                int wbase = 0;
+                if (lane == 0 && m) wbase = atomicAdd(&count_s, __popcll(m));
+                wbase = __shfl(wbase, 0);
+                if (ok) {
+                    const int pos = wbase + __popcll(m & ((1ull << lane) - 1ull));
+                    if (pos < cap) { rk[pos] = sqrt(d2); rc[pos] = (uint8_t)ccat; }
+                }
+            }
+        }
+    __syncthreads();
+    if (tid == 0) {
+        const int count = count_s;
+        if (count > cap) { atomicOr(&st->flags, ST_ENV_OVERFLOW); atomicMax(&st->max_env, (uint32_t)count); S.env.len[e] = 0; }
+        else if (count == 0) { atomicOr(&st->flags, ST_EMPTY_ENV); S.env.len[e] = 0; }
+        else S.env.len[e] = count;  // (k_env_rows sorts the row into the store and keeps this length)
+    }
+}
+
 bool launch_env_cells(hipStream_t s, int cap, const DevConfig* cfg, bool tag_list, const EnvSide& a, const EnvSide& b, double thr,
                       DeviceStatus* st) {
     if (a.max_envs + b.max_envs <= 0) return true;
+    if (cap > 16384 && cap <= 65536 && !(cap & (cap - 1))) {  // collect unsorted, then the global-memory row sort
+        if (!a.raw_key || !b.raw_key) return false;
+        EnvSides sides;
+        sides.s[0] = a;
+        sides.s[1] = b;
+        const dim3 grid((unsigned)(a.max_envs + b.max_envs));
+        if (tag_list) k_env_collect<true><<<grid, 1024, 0, s>>>(cfg, sides, thr, cap, st);
+        else k_env_collect<false><<<grid, 1024, 0, s>>>(cfg, sides, thr, cap, st);
+        for (int side = 0; side < 2; ++side) {
+            const EnvSide& S = side ? b : a;
+            if (S.max_envs <= 0) continue;
+            RowExtras ex{S.raw_cat, S.env.len, &st->n_unique[side]};
+            if (!launch_env_rows(s, cap, cfg, S.c, S.raw_key, cap, S.max_envs, cap, 0.0, S.env, st, ex)) return false;
+        }
+        return true;
+    }
     if (cap < 64 || cap > 16384 || (cap & (cap - 1))) return false;
     const dim3 grid((unsigned)(a.max_envs + b.max_envs));
     const size_t lds = (size_t)cap * 9;
@@ -1251,7 +1333,10 @@ constexpr int kRowBucketLimit = 64;   // a fuller bucket sends the row to the bi
 template <int NT, bool GLOBALKV>
 __global__ __launch_bounds__(NT) void k_env_rows(const DevConfig* __restrict__ cfgp, CloudView c, const double* __restrict__ dmx,
                                                  int64_t ld, int64_t row_len, int n2, int n_buckets, double image_bound, EnvStore env,
-                                                 DeviceStatus* st) {
+                                                 DeviceStatus* st, RowExtras ex) {
+    // ex (thresholded environments of more than 16384 points, collected unsorted by k_env_collect): the row's own categories
+    // and length instead of the structure's, rows beyond the side's unique anchors are not there
+    if (ex.n_unique && (uint32_t)blockIdx.x >= *ex.n_unique) return;
     // Sorting one row of n <= 16384 distances in O(n): an empirical CDF of the row on kRowCoarse uniform bins of
     // [0, max] of a monotone image of the distance (d^2 for coordinates) gives every point an interpolated rank; rank * kRowBuckets / n is its bucket, so buckets hold
     // ~n / kRowBuckets points whatever the shape of the cloud.  One LDS histogram + scan + scatter puts the points
@@ -1274,8 +1359,10 @@ __global__ __launch_bounds__(NT) void k_env_rows(const DevConfig* __restrict__ c
     __shared__ uint32_t coarse[kRowCoarse + 1], cum[kRowCoarse + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t r = blockIdx.x;
-    const int n = (int)row_len;
+    const int n = ex.row_lens ? ex.row_lens[r] : (int)row_len;
+    if (n <= 0) return;  // (an environment its collector flagged as empty or too large)
     const double* __restrict__ row = dmx ? dmx + r * ld : nullptr;
+    const uint8_t* __restrict__ cats = ex.row_cat ? ex.row_cat + r * ld : c.cat;
     double ax = 0.0, ay = 0.0, az = 0.0;
     if (!dmx) { ax = c.x[r]; ay = c.y[r]; az = c.z[r]; }
     // The bucketing phases work on a MONOTONE image of the distance -- the squared distance for coordinates (no square root
@@ -1351,7 +1438,7 @@ __global__ __launch_bounds__(NT) void k_env_rows(const DevConfig* __restrict__ c
     if (biggest > (uint32_t)kRowBucketLimit) {
         for (int i = tid; i < n2; i += NT) {
             key[i] = i < n ? d2u(dist_of(i, bad)) : kPadKey;
-            val[i] = i < n ? c.cat[i] : (uint8_t)0;
+            val[i] = i < n ? cats[i] : (uint8_t)0;
         }
         __syncthreads();
         bitonic_sort_lds<NT>(key, val, n2, tid);
@@ -1376,7 +1463,7 @@ __global__ __launch_bounds__(NT) void k_env_rows(const DevConfig* __restrict__ c
             const double m = image_of(i, bad);
             const uint32_t pos = atomicAdd(&hist[bucket_of(m)], 1u);
             key[pos] = d2u(dist_from_image(m));
-            val[pos] = c.cat[i];
+            val[pos] = cats[i];
         }
         __syncthreads();
         // 6. finish every bucket with an insertion sort on the exact keys
@@ -1734,23 +1821,23 @@ bool launch_env_rows2(hipStream_t s, const DevConfig* cfg, const RowSide& a, con
 }
 
 bool launch_env_rows(hipStream_t s, int cap, const DevConfig* cfg, const CloudView& c, const double* dmx, int64_t ld,
-                     int64_t n_rows, int64_t row_len, double image_bound, EnvStore env, DeviceStatus* st) {
+                     int64_t n_rows, int64_t row_len, double image_bound, EnvStore env, DeviceStatus* st, const RowExtras& ex) {
     if (dmx) image_bound = 0.0;  // given rows: the kernel finds the largest finite entry itself
     if (n_rows <= 0) return true;
     if (cap > 65536 || row_len > cap || row_len > 65535) return false;
     const dim3 grid((unsigned)n_rows);
     if (cap > 16384) {  // keys in global memory, 64 KB histogram in LDS
         const size_t lds = (size_t)(kRowBucketsBig + 1) * sizeof(uint32_t) + 16;
-        k_env_rows<1024, true><<<grid, 1024, lds, s>>>(cfg, c, dmx, ld, row_len, cap, kRowBucketsBig, image_bound, env, st);
+        k_env_rows<1024, true><<<grid, 1024, lds, s>>>(cfg, c, dmx, ld, row_len, cap, kRowBucketsBig, image_bound, env, st, ex);
         return true;
     }
     const size_t lds = (size_t)cap * 9 + 16 + (size_t)(kRowBucketsSmall + 1) * sizeof(uint32_t);
     if (cap <= 1024) {
-        k_env_rows<64, false><<<grid, 64, lds, s>>>(cfg, c, dmx, ld, row_len, cap, kRowBucketsSmall, image_bound, env, st);
+        k_env_rows<64, false><<<grid, 64, lds, s>>>(cfg, c, dmx, ld, row_len, cap, kRowBucketsSmall, image_bound, env, st, ex);
     } else if (cap <= 4096) {
-        k_env_rows<256, false><<<grid, 256, lds, s>>>(cfg, c, dmx, ld, row_len, cap, kRowBucketsSmall, image_bound, env, st);
+        k_env_rows<256, false><<<grid, 256, lds, s>>>(cfg, c, dmx, ld, row_len, cap, kRowBucketsSmall, image_bound, env, st, ex);
     } else {
-        k_env_rows<1024, false><<<grid, 1024, lds, s>>>(cfg, c, dmx, ld, row_len, cap, kRowBucketsSmall, image_bound, env, st);
+        k_env_rows<1024, false><<<grid, 1024, lds, s>>>(cfg, c, dmx, ld, row_len, cap, kRowBucketsSmall, image_bound, env, st, ex);
     }
     return true;
 }

@@ -277,6 +277,29 @@ def test_big_environments_block_kernel(lh, oracle):
     assert np.max(np.abs(got - want)) < TIGHT
 
 
+def test_environments_beyond_16384_points(lh, oracle):
+    """A threshold that swallows most of a 20 000-atom structure: environments of ~8 000 .. 20 000 points.  Up to 16 384 they
+    are sorted in LDS by the 1024-thread environment kernel; beyond, k_env_collect appends them unsorted to scratch rows and
+    the global-memory row sort finishes them (capacity 32 768).  With a tag rule and a dictionary of weight functions."""
+    rng = np.random.default_rng(61)
+    n = 20_000
+    sa, xa = cloud(rng, n, box=20.0)
+    sb, xb = cloud(rng, n, box=20.0)
+    tags = [f"r{i // 5}" for i in range(n)]
+    anchors = [(int(i), int(j)) for i, j in zip(rng.integers(0, n, 5), rng.integers(0, n, 5))]
+    for thr, rule, multi in ((float("inf"), None, False), (30.0, {"accept_same": False}, True), (18.0, None, False)):
+
+        def run(mod):
+            wf = {"a": mod.WeightFunction("hyper_exp", [1.0, 0.2]), "b": mod.WeightFunction("uniform", [1.0, 25.0])} if multi \
+                else mod.WeightFunction("hyper_exp", [1.0, 0.2])
+            lchd = mod.LoCoHD(CATS, wf, None if rule is None else mod.TagPairingRule(rule))
+            ap = [(i, j, "a" if k % 2 else "b") for k, (i, j) in enumerate(anchors)] if multi else anchors
+            return np.asarray(lchd.from_primitives(prims(mod, sa, xa, tags), prims(mod, sb, xb, tags), ap, thr))
+
+        got, want = both(lh, oracle, run)
+        assert np.max(np.abs(got - want)) < TIGHT, thr
+
+
 def test_two_contexts_and_capacity_decay(lh, oracle):
     """Two contexts alive at once: the dynamic-LDS attributes and the hooks belong to a context / its device, not to the
     process, so a > 4096-point environment (the 1024-thread environment kernel with > 64 KB of LDS) must work on the SECOND
