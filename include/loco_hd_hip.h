@@ -102,6 +102,14 @@ int lchd_from_dmxs(lchd_ctx *ctx, const lchd_config *cfg, const int32_t *seq_a, 
                    int64_t len_seq_b, const double *dmx_a, int64_t rows_a, int64_t cols_a, const double *dmx_b,
                    int64_t rows_b, int64_t cols_b, const int32_t *wf_index, double *out);
 
+/* The same with ragged rows (the reference's Vec<Vec<f64>> may hold rows of different lengths; utils.rs:25-39 sorts each row
+ * with a prefix of seq): dmx_x is padded to [rows][cols_x], row r of side x has row_len_x[r] in 1..cols_x real entries; what lies
+ * beyond a row's length -- matrix entries and seq categories alike -- is never looked at. */
+int lchd_from_dmxs_ragged(lchd_ctx *ctx, const lchd_config *cfg, const int32_t *seq_a, int64_t len_seq_a, const int32_t *seq_b,
+                          int64_t len_seq_b, const double *dmx_a, int64_t rows_a, int64_t cols_a, const int32_t *row_len_a,
+                          const double *dmx_b, int64_t rows_b, int64_t cols_b, const int32_t *row_len_b, const int32_t *wf_index,
+                          double *out);
+
 /* LoCoHD::from_coords, src/locohd.rs:463-476.  xyz_x is [n_x][3]; out is [n_a]. */
 int lchd_from_coords(lchd_ctx *ctx, const lchd_config *cfg, const int32_t *seq_a, int64_t len_seq_a, const int32_t *seq_b,
                      int64_t len_seq_b, const double *xyz_a, int64_t n_a, const double *xyz_b, int64_t n_b,

@@ -66,6 +66,7 @@ _PROTOS = {
     "lchd_ctx_set_config": (C.c_int, [_VP, C.POINTER(ConfigC)]),
     "lchd_from_anchors": (C.c_int, [_VP, C.POINTER(ConfigC), _IP, _i64, _DP, _i64, _IP, _i64, _DP, _i64, _i32, _DP]),
     "lchd_from_dmxs": (C.c_int, [_VP, C.POINTER(ConfigC), _IP, _i64, _IP, _i64, _DP, _i64, _i64, _DP, _i64, _i64, _IP, _DP]),
+    "lchd_from_dmxs_ragged": (C.c_int, [_VP, C.POINTER(ConfigC), _IP, _i64, _IP, _i64, _DP, _i64, _i64, _IP, _DP, _i64, _i64, _IP, _IP, _DP]),
     "lchd_from_coords": (C.c_int, [_VP, C.POINTER(ConfigC), _IP, _i64, _IP, _i64, _DP, _i64, _DP, _i64, _IP, _DP]),
     "lchd_from_primitives": (C.c_int, [_VP, C.POINTER(ConfigC), _DP, _IP, _IP, _i64, _DP, _IP, _IP, _i64, _LP, _IP, _i64, _f64, _DP]),
     "lchd_cloud_create": (C.c_int, [_VP, _DP, _IP, _IP, _i64, C.POINTER(_VP)]),

@@ -330,7 +330,7 @@ class LoCoHD:
 
     def from_dmxs(self, seq_a, seq_b, dmx_a, dmx_b, w_func_keys: Optional[Sequence[str]] = None) -> List[float]:
         """src/locohd.rs:410-458."""
-        ma, mb = self._matrix(dmx_a), self._matrix(dmx_b)
+        (ma, la), (mb, lb) = self._matrix(dmx_a), self._matrix(dmx_b)
         if ma.shape[0] != mb.shape[0]:  # :420-428
             raise ValueError(f"Expected matrices with the same length, got lengths {ma.shape[0]} and {mb.shape[0]}!")
         idx = self._wf_indices(None if w_func_keys is None else [str(k) for k in w_func_keys], ma.shape[0])
@@ -339,8 +339,15 @@ class LoCoHD:
         out = np.empty(ma.shape[0])
         if ma.shape[0] == 0:
             return []
-        N.check(N.lib().lchd_from_dmxs(self._context(), C.byref(cfg), N.ip(ca), ca.size, N.ip(cb), cb.size, N.dp(ma),
-                                       ma.shape[0], ma.shape[1], N.dp(mb), mb.shape[0], mb.shape[1], N.ip(idx), N.dp(out)))
+        if la is None and lb is None:
+            N.check(N.lib().lchd_from_dmxs(self._context(), C.byref(cfg), N.ip(ca), ca.size, N.ip(cb), cb.size, N.dp(ma),
+                                           ma.shape[0], ma.shape[1], N.dp(mb), mb.shape[0], mb.shape[1], N.ip(idx), N.dp(out)))
+        else:  # ragged rows: every row with its own length (what lies beyond a row is never looked at, as in the reference)
+            la = np.full(ma.shape[0], ma.shape[1], dtype=np.int32) if la is None else la
+            lb = np.full(mb.shape[0], mb.shape[1], dtype=np.int32) if lb is None else lb
+            N.check(N.lib().lchd_from_dmxs_ragged(self._context(), C.byref(cfg), N.ip(ca), ca.size, N.ip(cb), cb.size, N.dp(ma),
+                                                  ma.shape[0], ma.shape[1], N.ip(la), N.dp(mb), mb.shape[0], mb.shape[1], N.ip(lb),
+                                                  N.ip(idx), N.dp(out)))
         return out.tolist()
 
     def from_coords(self, seq_a, seq_b, coords_a, coords_b, w_func_keys: Optional[Sequence[str]] = None) -> List[float]:
@@ -444,10 +451,10 @@ class LoCoHD:
 
     # ---- argument conversion helpers ------------------------------------------------------------------------
     @staticmethod
-    def _matrix(m) -> np.ndarray:
-        """Vec<Vec<f64>> -> rectangular f64 matrix.  Ragged rows (the reference sorts each row with a prefix of seq,
-        utils.rs:25-39) are padded with +inf: points at infinite distance only ever add zero-width intervals
-        (F(inf) - F(inf) = 0), so the scores are unchanged."""
+    def _matrix(m):
+        """Vec<Vec<f64>> -> (rectangular f64 matrix, row lengths or None).  Ragged rows (the reference sorts each row with a
+        prefix of seq, utils.rs:25-39) are padded and travel with their lengths (lchd_from_dmxs_ragged)."""
+        lens = None
         try:
             arr = _f64(m)
         except ValueError:
@@ -455,14 +462,15 @@ class LoCoHD:
             width = max((len(r) for r in rows), default=0)
             if any(len(r) == 0 for r in rows):
                 raise N.PanicException("index out of bounds: empty distance row (src/locohd.rs:74)")
-            arr = np.full((len(rows), width), np.inf)
+            arr = np.zeros((len(rows), width))
             for k, r in enumerate(rows):
                 arr[k, : len(r)] = r
+            lens = np.asarray([len(r) for r in rows], dtype=np.int32)
         if arr.ndim == 1 and arr.size == 0:
             arr = arr.reshape(0, 0)
         if arr.ndim != 2:
             raise TypeError("a distance matrix must be a 2-D sequence of floats")
-        return arr
+        return arr, lens
 
     @staticmethod
     def _coords(x) -> np.ndarray:

@@ -1541,7 +1541,8 @@ static int sweep_rows(lchd_ctx* c, const EnvStore& ea, const EnvStore& eb, const
 // host-mapped scores.  `retry` reports that a long row defeated the segmented in-LDS sort (repeat with old_rows).
 static int dense_pass(lchd_ctx* c, const lchd_cloud& a, const lchd_cloud& b, const double* d_ma, const double* d_mb, int64_t rows,
                       int64_t cols_a, int64_t cols_b, const int32_t* d_wf, double* d_out, bool old_rows, bool& retry,
-                      const double* h_ma = nullptr, const double* h_mb = nullptr) {
+                      const double* h_ma = nullptr, const double* h_mb = nullptr, const int32_t* d_len_a = nullptr,
+                      const int32_t* d_len_b = nullptr) {
     retry = false;
     const int cap_a = next_pow2_host(cols_a), cap_b = next_pow2_host(cols_b);
     EnvStore ea{}, eb{};
@@ -1578,11 +1579,13 @@ static int dense_pass(lchd_ctx* c, const lchd_cloud& a, const lchd_cloud& b, con
         for (int k = 0; k < 3; ++k) { const double e = cl.bbmax[k] - cl.bbmin[k]; s2 += e * e; }
         return s2 * (1.0 + 1e-9) + 1e-300;
     };
-    const RowSide rsa{a.view(), d_ma, cols_a, cols_a, diag2(a), ea}, rsb{b.view(), d_mb, cols_b, cols_b, diag2(b), eb};
-    if (old_rows || !launch_env_rows2(s, c->d_cfg, rsa, rsb, rows, c->d_status))  // (rows beyond 20480 points: keys sorted in global memory)
-        if (!launch_env_rows(s, cap_a, c->d_cfg, a.view(), d_ma, cols_a, rows, cols_a, diag2(a), ea, c->d_status) ||
-            !launch_env_rows(s, cap_b, c->d_cfg, b.view(), d_mb, cols_b, rows, cols_b, diag2(b), eb, c->d_status))
+    const RowSide rsa{a.view(), d_ma, cols_a, cols_a, diag2(a), ea, d_len_a}, rsb{b.view(), d_mb, cols_b, cols_b, diag2(b), eb, d_len_b};
+    if (old_rows || !launch_env_rows2(s, c->d_cfg, rsa, rsb, rows, c->d_status)) {  // (rows beyond 20480 points: keys sorted in global memory)
+        const RowExtras exa{nullptr, d_len_a, nullptr}, exb{nullptr, d_len_b, nullptr};
+        if (!launch_env_rows(s, cap_a, c->d_cfg, a.view(), d_ma, cols_a, rows, cols_a, diag2(a), ea, c->d_status, exa) ||
+            !launch_env_rows(s, cap_b, c->d_cfg, b.view(), d_mb, cols_b, rows, cols_b, diag2(b), eb, c->d_status, exb))
             return fail(LCHD_EUNSUPPORTED, "no dense environment kernel for this row length");
+    }
     mark(c, 3);
     uint32_t f = 0;
     if (int rc2 = sweep_rows(c, ea, eb, d_wf, rows, d_out, d_meta, DRV_DMXS, &f)) return rc2;
@@ -1592,7 +1595,8 @@ static int dense_pass(lchd_ctx* c, const lchd_cloud& a, const lchd_cloud& b, con
 
 static int dense_driver(lchd_ctx* c, const lchd_config* cfg, const int32_t* seq_a, int64_t len_seq_a, const int32_t* seq_b,
                         int64_t len_seq_b, const double* xyz_a, const double* xyz_b, const double* dmx_a, const double* dmx_b,
-                        int64_t rows, int64_t cols_a, int64_t cols_b, const int32_t* wf_index, double* out) {
+                        int64_t rows, int64_t cols_a, int64_t cols_b, const int32_t* wf_index, double* out,
+                        const int32_t* row_len_a = nullptr, const int32_t* row_len_b = nullptr) {
     if (c->pend.active) return fail(LCHD_EVALUE, "an asynchronous call has not been finished (lchd_ctx_finish)");
     CTX_GUARD(c);
     if (int rc = lchd_ctx_set_config(c, cfg)) return rc;
@@ -1608,8 +1612,17 @@ static int dense_driver(lchd_ctx* c, const lchd_config* cfg, const int32_t* seq_
     // The two structures (SoA coordinates + categories), the weight-function indices and -- for calls of up to kDirectOutPairs
     // rows -- the scores travel through the context's pinned staging block (one asynchronous copy in, none out); nothing is
     // allocated per call.
+    for (int side = 0; side < 2 && (row_len_a || row_len_b); ++side) {  // ragged rows (utils.rs:25-39: a row is sorted with a prefix of seq)
+        const int32_t* rl = side ? row_len_b : row_len_a;
+        const int64_t cols = side ? cols_b : cols_a;
+        if (!rl) return fail(LCHD_EVALUE, "row lengths must be given for both matrices or for neither");
+        for (int64_t r = 0; r < rows; ++r) {
+            if (rl[r] < 1) return fail(LCHD_EPANIC, "index out of bounds: empty distance row (src/locohd.rs:74)");
+            if (rl[r] > cols) return fail(LCHD_EVALUE, "row %lld is longer (%d) than the padded matrix (%lld columns)", (long long)r, rl[r], (long long)cols);
+        }
+    }
     lchd_cloud a, b;
-    size_t o_wf = 0, o_out = 0, in_bytes = 0;
+    size_t o_wf = 0, o_out = 0, in_bytes = 0, o_la = 0, o_lb = 0;
     for (int pass = 0; pass < 2; ++pass) {
         size_t off = 0;
         char* hb = pass ? c->h_io : nullptr;
@@ -1617,12 +1630,18 @@ static int dense_driver(lchd_ctx* c, const lchd_config* cfg, const int32_t* seq_
         if (int rc = stage_cloud(xyz_b, seq_b, nullptr, cols_b, hb, c->d_io, off, b)) return rc;
         auto take = [&](size_t bytes) { off = (off + 255) & ~size_t(255); const size_t o = off; off += bytes; return o; };
         o_wf = take(wf_index ? sizeof(int32_t) * (size_t)rows : 0);
+        o_la = take(row_len_a ? sizeof(int32_t) * (size_t)rows : 0);
+        o_lb = take(row_len_b ? sizeof(int32_t) * (size_t)rows : 0);
         in_bytes = off;
         o_out = take(sizeof(double) * (size_t)rows);
         if (pass == 0)
             if (int rc = grow_io(c, off)) return rc;
     }
     if (wf_index) memcpy(c->h_io + o_wf, wf_index, sizeof(int32_t) * (size_t)rows);
+    if (row_len_a) memcpy(c->h_io + o_la, row_len_a, sizeof(int32_t) * (size_t)rows);
+    if (row_len_b) memcpy(c->h_io + o_lb, row_len_b, sizeof(int32_t) * (size_t)rows);
+    const int32_t* d_la = row_len_a ? reinterpret_cast<const int32_t*>(c->d_io + o_la) : nullptr;
+    const int32_t* d_lb = row_len_b ? reinterpret_cast<const int32_t*>(c->d_io + o_lb) : nullptr;
     const bool direct = rows <= kDirectOutPairs;
     const int32_t* d_wf = wf_index ? reinterpret_cast<const int32_t*>(c->d_io + o_wf) : nullptr;
     double* d_out = reinterpret_cast<double*>((direct ? c->h_io : c->d_io) + o_out);
@@ -1632,7 +1651,7 @@ static int dense_driver(lchd_ctx* c, const lchd_config* cfg, const int32_t* seq_
         if (int rc2 = begin_pass(c)) return rc2;
         c->status_dirty = true;  // until the record pass has been enqueued (sweep_rows)
         HIP_TRY(hipMemcpyAsync(c->d_io, c->h_io, in_bytes, hipMemcpyHostToDevice, c->stream));
-        rc = dense_pass(c, a, b, nullptr, nullptr, rows, cols_a, cols_b, d_wf, d_out, c->tune.old_rows || attempt > 0, retry, dmx_a, dmx_b);
+        rc = dense_pass(c, a, b, nullptr, nullptr, rows, cols_a, cols_b, d_wf, d_out, c->tune.old_rows || attempt > 0, retry, dmx_a, dmx_b, d_la, d_lb);
         if (rc || !retry) break;
     }
     if (rc) return rc;
@@ -1685,6 +1704,21 @@ extern "C" int lchd_from_dmxs(lchd_ctx* c, const lchd_config* cfg, const int32_t
     if (rows_a != rows_b)  // src/locohd.rs:420-428
         return fail(LCHD_EVALUE, "Expected matrices with the same length, got lengths %lld and %lld!", (long long)rows_a, (long long)rows_b);
     return dense_driver(c, cfg, seq_a, len_seq_a, seq_b, len_seq_b, nullptr, nullptr, dmx_a, dmx_b, rows_a, cols_a, cols_b, wf_index, out);
+}
+
+/* from_dmxs with ragged rows: the reference takes Vec<Vec<f64>> and sorts each row with a PREFIX of seq (utils.rs:25-39), so rows
+ * may be shorter than seq and differ in length.  dmx_x is the row-major [rows][cols_x] matrix padded with anything; row r of
+ * side x has row_len_x[r] (1 .. cols_x) real entries.  Entries and categories beyond a row's length are never looked at. */
+extern "C" int lchd_from_dmxs_ragged(lchd_ctx* c, const lchd_config* cfg, const int32_t* seq_a, int64_t len_seq_a, const int32_t* seq_b,
+                                     int64_t len_seq_b, const double* dmx_a, int64_t rows_a, int64_t cols_a, const int32_t* row_len_a,
+                                     const double* dmx_b, int64_t rows_b, int64_t cols_b, const int32_t* row_len_b, const int32_t* wf_index,
+                                     double* out) {
+    if (!c) return fail(LCHD_EVALUE, "null context");
+    if (rows_a != rows_b)  // src/locohd.rs:420-428
+        return fail(LCHD_EVALUE, "Expected matrices with the same length, got lengths %lld and %lld!", (long long)rows_a, (long long)rows_b);
+    if (!row_len_a || !row_len_b) return fail(LCHD_EVALUE, "null row-length array");
+    return dense_driver(c, cfg, seq_a, len_seq_a, seq_b, len_seq_b, nullptr, nullptr, dmx_a, dmx_b, rows_a, cols_a, cols_b, wf_index, out, row_len_a,
+                        row_len_b);
 }
 
 extern "C" int lchd_from_anchors(lchd_ctx* c, const lchd_config* cfg, const int32_t* seq_a, int64_t len_seq_a, const double* dists_a,

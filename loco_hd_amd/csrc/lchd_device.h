@@ -201,6 +201,7 @@ struct RowSide {
     int64_t ld, row_len;
     double image_bound;    // coordinates: >= largest squared distance (bounding-box diagonal^2); ignored for given rows
     EnvStore env;
+    const int32_t* row_lens;  // ragged given rows: [n_rows] points of each row (1 .. row_len); nullptr: every row has row_len
 };
 struct RowSides {
     RowSide s[2];

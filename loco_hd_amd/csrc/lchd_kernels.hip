@@ -1536,7 +1536,7 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 2 : 4)) void k_env_rows2(const Dev
     const int64_t r = (int64_t)blockIdx.x - (side ? sides.n_rows : 0);
     const CloudView c = S.c;
     const EnvStore env = S.env;
-    const int n = (int)S.row_len;
+    const int n = S.row_lens ? S.row_lens[r] : (int)S.row_len;  // (ragged distance matrices: every row its own length)
     // Buckets: as many as fit (up to kRowBucketsMax, ~1 point per bucket: the ranking step reads a bucket's members once
     // per member).  The histogram lives in the part of the key array the row (or distance segment) does not need -- the
     // array is sized for the bitonic fallback, a power of two --, or behind the categories when the row fills it.
@@ -1801,6 +1801,7 @@ bool launch_env_rows2(hipStream_t s, const DevConfig* cfg, const RowSide& a, con
     // rows of 16385 .. 20480 points: sorted in distance segments of ~10^4 points each (the segment's keys in LDS)
     const int n_seg = longest > 16384 ? 2 : 1;
     if (n_seg > 1 && (std::min(a.row_len, b.row_len) <= 16384)) return false;  // (one launch, one segment count: both sides must be long)
+    if (n_seg > 1 && (a.row_lens || b.row_lens)) return false;  // (ragged rows may be short: same reason)
     RowSides sides;
     sides.s[0] = a; sides.s[1] = b;
     if (a.dmx) sides.s[0].image_bound = 0.0;  // given rows: the kernel finds the largest finite entry itself

@@ -201,22 +201,27 @@ class DeviceSession:
         if topology is not None:
             for b in bufs:
                 self.set_frame_sources(b, topology)
-        copy_stream = torch.cuda.Stream(device=dev)
-        starts = list(range(0, n_frames, chunk))
-        load(bufs[0], frames_xyz[starts[0]:starts[0] + chunk], copy_stream)
-        for k, f0 in enumerate(starts):
-            nf = min(chunk, n_frames - f0)
-            self.from_primitives_async(ref_cloud, bufs[k % 2], anchors[: nf * len(lp)], threshold_distance,
-                                       out[f0 * len(lp):(f0 + nf) * len(lp)])
-            if k + 1 < len(starts):
-                f1 = starts[k + 1]
-                load(bufs[(k + 1) % 2], frames_xyz[f1:f1 + chunk], copy_stream)
-            self.finish()
-        res = out.cpu().numpy().reshape(n_frames, len(lp))
-        for b in bufs:
-            N.lib().lchd_cloud_destroy(self._ctx, b)
-            self._clouds.remove(b)
-        return res
+        try:
+            copy_stream = torch.cuda.Stream(device=dev)
+            starts = list(range(0, n_frames, chunk))
+            load(bufs[0], frames_xyz[starts[0]:starts[0] + chunk], copy_stream)
+            for k, f0 in enumerate(starts):
+                nf = min(chunk, n_frames - f0)
+                self.from_primitives_async(ref_cloud, bufs[k % 2], anchors[: nf * len(lp)], threshold_distance,
+                                           out[f0 * len(lp):(f0 + nf) * len(lp)])
+                if k + 1 < len(starts):
+                    f1 = starts[k + 1]
+                    load(bufs[(k + 1) % 2], frames_xyz[f1:f1 + chunk], copy_stream)
+                self.finish()
+            return out.cpu().numpy().reshape(n_frames, len(lp))
+        finally:  # the two frames buffers go away on every path out (a failed load or finish included)
+            try:
+                self.finish()
+            except Exception:
+                pass
+            for b in bufs:
+                N.lib().lchd_cloud_destroy(self._ctx, b)
+                self._clouds.remove(b)
 
     def close(self):
         if self._ctx:

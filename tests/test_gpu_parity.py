@@ -256,6 +256,37 @@ def test_ragged_distance_matrix(lh, oracle):
     assert np.max(np.abs(got - np.asarray(want))) < TIGHT
 
 
+def test_ragged_rows_never_look_beyond_their_length(lh, oracle):
+    """What lies beyond a row's length is not part of the environment (utils.rs:25-39 zips the row with seq): categories
+    outside the map there do not raise, and statistical distances with logarithms see no padding."""
+    rng = np.random.default_rng(32)
+    n = 300
+    s, x = cloud(rng, n, box=12.0)
+    s = list(s)
+    for k in range(200, n):
+        s[k] = "not-a-category"
+    full = np.sqrt(((x[:, None, :] - x[None, :, :]) ** 2).sum(-1))
+    lens = rng.integers(120, 201, 100)
+    ragged_a = [full[i, : int(lens[i])].tolist() for i in range(100)]
+    ragged_b = [full[(i + 7) % 100, : int(lens[(i * 3) % 100])].tolist() for i in range(100)]
+    for r in ragged_b:
+        r[0], r[int(np.argmin(r))] = 0.0, r[0]  # the anchor (distance 0) first, as stat_dist_integral demands
+    for sd in (("Hellinger", [2.0]), ("Kullback-Leibler", [1e-3]), ("Renyi", [2.0, 1e-3])):
+        lchd = lh.LoCoHD(CATS, lh.WeightFunction("hyper_exp", [1.0, 0.3]), statistical_distance=lh.StatisticalDistance(*sd))
+        lo = oracle.LoCoHD(CATS, oracle.WeightFunction("hyper_exp", [1.0, 0.3]), statistical_distance=oracle.StatisticalDistance(*sd))
+        got = np.asarray(lchd.from_dmxs(s, s, ragged_a, ragged_b))
+        want = []
+        for i in range(100):
+            (sa, da), (sb, db) = _sorted_env(s, ragged_a[i]), _sorted_env(s, ragged_b[i])
+            want.append(lo.from_anchors(sa, sb, da, db))
+        assert np.all(np.isfinite(got)), sd
+        assert np.max(np.abs(got - np.asarray(want))) < TIGHT, sd
+    # a row that DOES reach an unknown category raises like the reference (pmf.rs:38-42)
+    ragged_a[5] = full[5, :201].tolist()
+    with pytest.raises(ValueError):
+        lchd.from_dmxs(s, s, ragged_a, ragged_b)
+
+
 def _sorted_env(seq, row):
     row = np.asarray(row, dtype=float)
     order = np.argsort(row, kind="stable")
