@@ -1,0 +1,151 @@
+"""BASELINE.json configs C3 / C4 / C5 at their FULL sizes under `pytest -m gpu` (the synthetic inputs are bench.py's own
+generators).  The CPU oracle cannot score 10^6 pairs in a test's time, so every case checks
+
+  * a seeded sample of the pairs against the oracle (TIGHT), and
+  * size-independent properties over ALL pairs: output i belongs to anchor pair i (a permuted pair list gives the permuted
+    scores bit for bit, src/locohd.rs:556 is an indexed collect), symmetry under exchanging the two structures, range [0, 1],
+    self-comparison exactly 0, and equality of one big call with the per-structure-pair calls where the workload has those.
+"""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+TIGHT = 1e-11
+
+
+@pytest.fixture(scope="module")
+def lh():
+    import loco_hd_amd
+
+    return loco_hd_amd
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as orc  # the checker
+
+    return orc
+
+
+def test_c5_full_size(lh, oracle):
+    """2 x 200 000 points, 25 categories, 10^6 random anchor pairs, 10 A (BASELINE configs[4])."""
+    import torch
+    import bench
+    from loco_hd_amd.device import DeviceSession
+
+    w = bench.make_workload("c5", 0, 1_000_000)
+    n, c = w["n"], w["C"]
+    cats = [f"c{i}" for i in range(c)]
+    lchd = lh.LoCoHD(cats, lh.WeightFunction(*w["wf"]))
+    sess = DeviceSession(lchd)
+    a, b = sess.upload(w["xyz_a"], w["cat_a"]), sess.upload(w["xyz_b"], w["cat_b"])
+    pairs = torch.from_numpy(w["pairs"]).cuda()
+    s1 = sess.from_primitives(a, b, pairs, w["thr"]).clone()
+    assert s1.shape[0] == 1_000_000
+    assert float(s1.min()) >= 0.0 and float(s1.max()) <= 1.0
+    perm = torch.randperm(pairs.shape[0], device="cuda")
+    s2 = sess.from_primitives(a, b, pairs[perm].contiguous(), w["thr"])
+    assert torch.equal(s1[perm], s2)
+    s3 = sess.from_primitives(b, a, pairs.flip(1).contiguous(), w["thr"])
+    assert float((s1 - s3).abs().max()) < 1e-13
+    self_pairs = pairs[:, :1].expand(-1, 2).contiguous()
+    assert float(sess.from_primitives(a, a, self_pairs, w["thr"]).abs().max()) == 0.0
+    # sample vs the oracle
+    lo = oracle.LoCoHD(cats, oracle.WeightFunction(*w["wf"]), n_of_threads=8)
+    tag = np.zeros(n, dtype=np.int32)
+    pick = np.random.default_rng(0).choice(1_000_000, 20_000, replace=False)
+    want = np.asarray(lo.from_arrays(w["xyz_a"], w["cat_a"], tag, w["xyz_b"], w["cat_b"], tag, w["pairs"][pick], w["thr"]))
+    got = s1.cpu().numpy()[pick]
+    assert np.max(np.abs(got - want)) < TIGHT
+    sess.close()
+
+
+def test_c3_full_size(lh, oracle):
+    """50 decoys x 3000 points, all 1225 unordered decoy pairs x 1000 'Cent' anchors in ONE batched call (BASELINE
+    configs[2]); equal (1e-14: summation order) to the per-decoy-pair calls of the reference's caller
+    (python_codes/casp14/casp14_extend_with_locohd.py:72-79) on a sample of decoy pairs, and to the oracle on a smaller one."""
+    import torch
+    import bench
+    from loco_hd_amd.device import DeviceSession
+
+    w = bench.make_c3(0, True)
+    lchd = lh.LoCoHD(w["types"], lh.WeightFunction("uniform", [3.0, 10.0]), lh.TagPairingRule({"accept_same": False}))
+    sess = DeviceSession(lchd)
+    batch, offs = sess.upload_batch(w["decoys"])
+    la = np.arange(0, w["n"], 3)
+    pairs = np.concatenate([np.stack([offs[x] + la, offs[y] + la], 1) for x, y in w["spairs"]])
+    assert pairs.shape[0] == 1225 * 1000
+    anchors = torch.from_numpy(np.ascontiguousarray(pairs)).cuda()
+    s1 = sess.from_primitives(batch, batch, anchors, w["thr"]).clone()
+    assert float(s1.min()) >= 0.0 and float(s1.max()) <= 1.0
+    perm = torch.randperm(anchors.shape[0], device="cuda")
+    assert torch.equal(s1[perm], sess.from_primitives(batch, batch, anchors[perm].contiguous(), w["thr"]))
+    s3 = sess.from_primitives(batch, batch, anchors.flip(1).contiguous(), w["thr"])
+    assert float((s1 - s3).abs().max()) < 1e-13
+    s1 = s1.cpu().numpy().reshape(1225, 1000)
+    rng = np.random.default_rng(1)
+    local = torch.from_numpy(np.stack([la, la], 1)).cuda()
+    singles = {}
+    for k in rng.choice(1225, 40, replace=False):
+        x, y = w["spairs"][int(k)]
+        for d in (x, y):
+            if d not in singles:
+                singles[d] = sess.upload(*w["decoys"][d])
+        got = sess.from_primitives(singles[x], singles[y], local, w["thr"]).cpu().numpy()
+        # (not bit for bit: a 1000-pair call and the 1.2e6-pair call may run sweep variants with a different number of events
+        #  per lane, i.e. another summation order of the same terms)
+        assert np.max(np.abs(got - s1[int(k)])) < 1e-14, (x, y)
+    lo = oracle.LoCoHD(w["types"], oracle.WeightFunction("uniform", [3.0, 10.0]), oracle.TagPairingRule({"accept_same": False}),
+                       n_of_threads=8)
+    lp = np.stack([la, la], 1)
+    for k in rng.choice(1225, 6, replace=False):
+        x, y = w["spairs"][int(k)]
+        (xa, ca, ta), (xb, cb, tb) = w["decoys"][x], w["decoys"][y]
+        want = np.asarray(lo.from_arrays(xa, ca, ta, xb, cb, tb, lp, w["thr"]))
+        assert np.max(np.abs(s1[int(k)] - want)) < TIGHT, (x, y)
+    sess.close()
+
+
+def test_c4_full_size(lh, oracle):
+    """One reference structure against 5000 trajectory frames of a 2001-point system, 667 per-residue anchors per frame
+    (BASELINE configs[3]): the streamed frames-buffer path (lchd_frames_*) at full size; a sample of frames against
+    single-structure calls (1e-14) and against the oracle."""
+    import torch
+    from loco_hd_amd.device import DeviceSession
+
+    rng = np.random.default_rng(4)
+    types = ["Cent", "AmideC", "OH", "Pos", "Neg", "Aro", "Ali", "Sulf"]
+    n, n_frames = 2001, 5000
+    side = (n / 0.023) ** (1 / 3)
+    ref = rng.uniform(0, side, (n, 3))
+    cat = np.where(np.arange(n) % 3 == 0, 0, rng.integers(1, 8, n)).astype(np.int32)
+    tag = (np.arange(n) // 3).astype(np.int32)
+    drift = rng.normal(0, 0.02, (n_frames, 1, 3)).cumsum(0)
+    frames = ref[None] + drift + rng.normal(0, 0.8, (n_frames, n, 3))
+    lchd = lh.LoCoHD(types, lh.WeightFunction("uniform", [3.0, 10.0]), lh.TagPairingRule({"accept_same": False}))
+    sess = DeviceSession(lchd)
+    ref_cloud = sess.upload(ref, cat, tag)
+    la = np.arange(0, n, 3)
+    lp = np.stack([la, la], 1)
+    scores = sess.score_trajectory(ref_cloud, frames, lp, 10.0)
+    assert scores.shape == (n_frames, len(la))
+    assert scores.min() >= 0.0 and scores.max() <= 1.0
+    again = sess.score_trajectory(ref_cloud, frames[::-1].copy(), lp, 10.0, chunk=700)  # other chunking, frames reversed
+    assert np.array_equal(again[::-1], scores)
+    local = torch.from_numpy(lp).cuda()
+    lo = oracle.LoCoHD(types, oracle.WeightFunction("uniform", [3.0, 10.0]), oracle.TagPairingRule({"accept_same": False}), n_of_threads=8)
+    for k, f in enumerate(rng.choice(n_frames, 25, replace=False)):
+        one = sess.upload(frames[int(f)], cat, tag)
+        got = sess.from_primitives(ref_cloud, one, local, 10.0).cpu().numpy()
+        assert np.max(np.abs(got - scores[int(f)])) < 1e-14, f
+        if k < 8:
+            want = np.asarray(lo.from_arrays(ref, cat, tag, frames[int(f)], cat, tag, lp, 10.0))
+            assert np.max(np.abs(got - want)) < TIGHT, f
+    sess.close()
