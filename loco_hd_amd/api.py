@@ -271,6 +271,10 @@ class LoCoHD:
             pass
 
     def _cats(self, seq) -> np.ndarray:
+        if _fastpack is not None and hasattr(_fastpack, "cats_into"):  # the same loop in native code (Vec<String> extraction)
+            out = np.empty(len(seq), dtype=np.int32)
+            _fastpack.cats_into(seq, self._categories, out)
+            return out
         get = self._categories.get
         return np.fromiter((get(str(s), -1) for s in seq), dtype=np.int32, count=len(seq))
 

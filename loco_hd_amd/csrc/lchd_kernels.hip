@@ -1517,19 +1517,33 @@ __global__ __launch_bounds__(NT) void k_env_rows(const DevConfig* __restrict__ c
 // of two 10^4-atom structures; this kernel builds both structures' rows in one launch.)
 // Dynamic LDS: n2 * 9 bytes (keys, categories) + the bucket histogram.
 // ------------------------------------------------------------------------------------------------
-constexpr int kRowSegCap = 14272;  // rows of more than 16384 points: most points of one distance segment (keys in LDS)
-template <int NT, int EPT, int NSEG>  // NSEG: distance segments the row is sorted in (2 for rows of more than 16384 points)
+constexpr int kRowSegCap = 11776;  // rows of more than 16384 points: most points of one distance segment (keys in LDS)
+constexpr int kRowLongEpt = 20;    // ... and the points per thread of such a row (<= 20480 points, 1024 threads)
+constexpr size_t kRowSegLds = (size_t)kRowSegCap * 9 + (size_t)(kRowBucketsMax + 1) * 4;  // keys, categories, histogram
+static_assert(((size_t)kRowSegCap * 9) % 16 == 0, "histogram alignment");
+// EPT: points per thread of ONE sort -- the whole row, or one distance segment of a long row (NSEG = 2).
+// Long rows (16385 .. 20480 points: more keys than the LDS holds) are sorted segment by segment: the coarse empirical CDF
+// says which half of the buckets -- the nearer or the farther half of the row, ~n/2 points each -- a point falls into;
+// for each segment the block compacts its points into the key array (ballot prefix inside a wave, wave totals through LDS:
+// a deterministic order), every thread takes EPT of them back into registers, and from there the sort is the one of a
+// 10^4-point row.  (A first version kept all 20 points of a thread in registers through both segments and tested
+// "is it in this segment?" per point and phase: half the lanes idle in every instruction, 136 bytes of spill: 22.8 ms
+// for the 4 x 10^4 rows of two 2 x 10^4-atom structures.)
+template <int NT, int EPT, int NSEG>
 __global__ __launch_bounds__(NT, (NT == 512 ? 2 : 4)) void k_env_rows2(const DevConfig* __restrict__ cfgp, RowSides sides, int n2, DeviceStatus* st) {
+    static_assert(NSEG == 1 || NSEG == 2, "a point's segment is one bit");
     constexpr int n_seg = NSEG;
+    constexpr int PEPT = NSEG > 1 ? kRowLongEpt : EPT;  // points per thread of the whole row
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* key = reinterpret_cast<uint64_t*>(smem);
-    uint8_t* val = smem + (size_t)n2 * 8;
+    uint8_t* val = smem + (NSEG > 1 ? (size_t)kRowSegCap : (size_t)n2) * 8;
     __shared__ double red_max[NT / 64];
-    __shared__ uint32_t red_cnt[NT / 64];
+    __shared__ uint32_t red_cnt[NT / 64], far_cnt[NT / 64];
     __shared__ uint32_t seg_tot[kRowBucketsMax / 64 + 1];
     __shared__ uint32_t coarse[kRowCoarse + 1], cum[kRowCoarse + 1];
     __shared__ uint32_t seg_n_s;
     __shared__ uint64_t carry_key_s;
+    __shared__ double split_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int side = (int64_t)blockIdx.x >= sides.n_rows ? 1 : 0;
     const RowSide& S = sides.s[side];
@@ -1538,13 +1552,13 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 2 : 4)) void k_env_rows2(const Dev
     const EnvStore env = S.env;
     const int n = S.row_lens ? S.row_lens[r] : (int)S.row_len;  // (ragged distance matrices: every row its own length)
     // Buckets: as many as fit (up to kRowBucketsMax, ~1 point per bucket: the ranking step reads a bucket's members once
-    // per member).  The histogram lives in the part of the key array the row (or distance segment) does not need -- the
-    // array is sized for the bitonic fallback, a power of two --, or behind the categories when the row fills it.
+    // per member).  The histogram lives in the part of the key array the row does not need -- the array is sized for the
+    // bitonic fallback, a power of two --, or behind the categories when the row fills it.
     int NB = kRowBucketsSmall;
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem + (size_t)n2 * 9 + ((16 - (((size_t)n2 * 9) & 15)) & 15));  // [NB + 1]
     if (n_seg > 1) {
-        NB = 4096;
-        hist = reinterpret_cast<uint32_t*>(key + kRowSegCap);
+        NB = kRowBucketsMax;
+        hist = reinterpret_cast<uint32_t*>(smem + (size_t)kRowSegCap * 9);
     } else {
         const int nk = (n + 63) & ~63;
         while (NB > 64 && NB >= 4 * nk) NB >>= 1;  // short rows: no more than ~2 buckets per point
@@ -1564,28 +1578,70 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 2 : 4)) void k_env_rows2(const Dev
 
     // 1. the distance image of this thread's points (d^2 for coordinates, utils.rs:1-8 order, uncontracted; the distance
     //    itself for a given row) and their categories (four to a register).  Point i = tid + q * NT: coalesced.
-    double m[EPT];
-    uint32_t ct4[(EPT + 3) / 4];
-#pragma unroll
-    for (int q = 0; q < (EPT + 3) / 4; ++q) ct4[q] = 0u;
+    //    (The "given row or coordinates?" test stays OUTSIDE the loops over a thread's points: inside, it was a branch per
+    //    point -- wave-uniform, but the loads behind it were issued one point after the other.)
     bool bad = false;
-#pragma unroll
-    for (int q = 0; q < EPT; ++q) {
+    auto image_row = [&](int tid, int q) -> double {
+        const int i = tid + q * NT;
+        double v = row[i < n ? i : 0];
+        if (i < n && !(v >= 0.0)) { bad = true; v = 0.0; }  // negative or NaN
+        return v + 0.0;                                      // -0.0 -> +0.0
+    };
+    auto image_xyz = [&](int tid, int q) -> double {
         const int i = tid + q * NT;
         const int ii = i < n ? i : 0;
-        ct4[q >> 2] |= (uint32_t)c.cat[ii] << ((q & 3) * 8);
+        const double dx = ax - c.x[ii], dy = ay - c.y[ii], dz = az - c.z[ii];
+        double d2 = dx * dx;
+        d2 = d2 + dy * dy;
+        d2 = d2 + dz * dz;
+        return d2;
+    };
+    constexpr int IB = PEPT <= 10 ? PEPT : (PEPT % 10 == 0 ? 10 : 8);
+    double m[EPT];                   // the images of the points being sorted (the row, or the current segment)
+    double mp[NSEG > 1 ? PEPT : 1];  // long rows: the images of all the thread's points while they are dealt to the segments
+    uint32_t ct4[(EPT + 3) / 4];
+    uint32_t cp4[NSEG > 1 ? (PEPT + 3) / 4 : 1];  // ... and their categories
+#pragma unroll
+    for (int q = 0; q < (EPT + 3) / 4; ++q) ct4[q] = 0u;
+#pragma unroll
+    for (int q = 0; q < (NSEG > 1 ? (PEPT + 3) / 4 : 1); ++q) cp4[q] = 0u;
+    if constexpr (NSEG == 1) {
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int i = tid + q * NT;
+            ct4[q >> 2] |= (uint32_t)c.cat[i < n ? i : 0] << ((q & 3) * 8);
+        }
         if (row) {
-            double v = row[ii];
-            if (i < n && !(v >= 0.0)) { bad = true; v = 0.0; }  // negative or NaN
-            m[q] = v + 0.0;                                      // -0.0 -> +0.0
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) m[q] = image_row(tid, q);
         } else {
-            const double dx = ax - c.x[ii], dy = ay - c.y[ii], dz = az - c.z[ii];
-            double d2 = dx * dx;
-            d2 = d2 + dy * dy;
-            d2 = d2 + dz * dz;
-            m[q] = d2;
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) {
+                m[q] = image_xyz(tid, q);
+                if ((q + 1) % IB == 0) __builtin_amdgcn_sched_barrier(0);  // (at most 3 * IB coordinate loads in flight)
+            }
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < PEPT; ++q) {
+            const int i = tid + q * NT;
+            cp4[q >> 2] |= (uint32_t)c.cat[i < n ? i : 0] << ((q & 3) * 8);
+        }
+        if (row) {
+#pragma unroll
+            for (int q = 0; q < PEPT; ++q) mp[q] = image_row(tid, q);
+        } else {
+#pragma unroll
+            for (int q = 0; q < PEPT; ++q) {
+                mp[q] = image_xyz(tid, q);
+                if ((q + 1) % IB == 0) __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
+    auto row_img = [&](int q) -> double {  // q static
+        if constexpr (NSEG > 1) return mp[q];
+        else return m[q];
+    };
     auto cat_of = [&](int q) -> uint8_t { return (uint8_t)(ct4[q >> 2] >> ((q & 3) * 8)); };  // q static
     if (__ballot(bad) && lane == 0) atomicOr(&st->flags, ST_BAD_DISTANCE);
     ESTAMP(0);
@@ -1594,8 +1650,8 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 2 : 4)) void k_env_rows2(const Dev
     double dmax = S.image_bound > 0.0 ? S.image_bound : 0.0;
     if (!(S.image_bound > 0.0)) {
 #pragma unroll
-        for (int q = 0; q < EPT; ++q)
-            if (tid + q * NT < n && m[q] < 1.0e300 && m[q] > dmax) dmax = m[q];
+        for (int q = 0; q < PEPT; ++q)
+            if (tid + q * NT < n && row_img(q) < 1.0e300 && row_img(q) > dmax) dmax = row_img(q);
         for (int k = 32; k > 0; k >>= 1) dmax = fmax(dmax, shfl_xor_f64(dmax, k));
         if (lane == 0) red_max[wave] = dmax;
     }
@@ -1607,8 +1663,8 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 2 : 4)) void k_env_rows2(const Dev
     // 2. empirical CDF of the row on kRowCoarse uniform bins of [0, dmax]
     const double inv_w = dmax > 0.0 ? (double)kRowCoarse / dmax : 0.0;
 #pragma unroll
-    for (int q = 0; q < EPT; ++q)
-        if (tid + q * NT < n && m[q] <= dmax) atomicAdd(&coarse[min((int)(m[q] * inv_w), kRowCoarse - 1)], 1u);
+    for (int q = 0; q < PEPT; ++q)
+        if (tid + q * NT < n && row_img(q) <= dmax) atomicAdd(&coarse[min((int)(row_img(q) * inv_w), kRowCoarse - 1)], 1u);
     __syncthreads();
     if (wave == 0) {  // cum[b] = points below bin b
         uint32_t carry = 0;
@@ -1628,35 +1684,140 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 2 : 4)) void k_env_rows2(const Dev
     const double winv = cfg.wf_inv[0];
     const int NBT = NB * n_seg;  // buckets of the whole row; distance segment sg owns buckets [sg * NB, (sg + 1) * NB)
     const double rank_scale = n > 0 ? (double)NBT / (double)n : 0.0;
+    // interpolated rank of an image in the row -> one of NBT balanced buckets
+    auto bucket_of = [&](double v) -> int {
+        int gb = NBT - 1;  // +inf entries of a distance matrix
+        if (v <= dmax) {
+            const double t = v * inv_w;
+            const int bin = min((int)t, kRowCoarse - 1);
+            const double frac = fmin(t - (double)bin, 1.0);
+            const double qq = ((double)cum[bin] + frac * (double)coarse[bin]) * rank_scale;
+            gb = qq < (double)NBT ? (int)qq : NBT - 1;
+        }
+        return gb;
+    };
     uint64_t* ok_ = env.key + r * env.stride;
     uint8_t* oc_ = env.cat + r * env.stride;
+    uint32_t seg_total[2] = {0u, 0u};
+    if constexpr (NSEG > 1) {
+        // Long rows: deal the points to the two segments, ONCE and from the registers (every further pass over the row's
+        // coordinates costs ~8 000 cycles of this CU's 64-byte-per-clock L1 path: 480 KB).  The nearer segment's points go
+        // into the key array, the farther segment's into the row's own slot of the environment store (which its sorted
+        // keys overwrite at the end); position = points of the lower waves + of this wave's earlier q + of the lower lanes:
+        // a deterministic order.
+        // Which segment?  One comparison with the image at which the empirical CDF reaches n / 2 (any threshold keeps the
+        // two segments ordered; this one balances them).
+        if (wave == 0) {
+            const uint32_t half = (uint32_t)n / 2u;
+            int bin = 0;  // the last bin that starts at or below the median rank
+            for (int b = lane; b < kRowCoarse; b += 64) bin = cum[b] <= half ? b : bin;
+            for (int k = 32; k > 0; k >>= 1) bin = max(bin, __shfl_xor(bin, k));
+            if (lane == 0) {
+                const double inside = coarse[bin] ? (double)(half - cum[bin]) / (double)coarse[bin] : 0.0;
+                split_s = inv_w > 0.0 ? ((double)bin + fmin(inside, 1.0)) / inv_w : 0.0;
+            }
+        }
+        __syncthreads();
+        const double split = split_s;
+        uint32_t seg_bits = 0u;  // bit q = the segment of point q
+#pragma unroll
+        for (int q = 0; q < PEPT; ++q)
+            if (tid + q * NT < n && mp[q] >= split) seg_bits |= 1u << q;
+        ESTAMP(0);  // (diagnostic builds: the segment bits are booked on the image phase, the dealing on the coarse-CDF phase)
+        uint32_t wn0 = 0, wn1 = 0;
+#pragma unroll
+        for (int q = 0; q < PEPT; ++q) {
+            const bool in = tid + q * NT < n, far = (seg_bits >> q) & 1u;
+            wn0 += (uint32_t)__popcll(__ballot(in && !far));
+            wn1 += (uint32_t)__popcll(__ballot(in && far));
+        }
+        if (lane == 0) { red_cnt[wave] = wn0; far_cnt[wave] = wn1; }
+        __syncthreads();
+        uint32_t at0 = 0, at1 = 0;
+        for (int w = 0; w < NT / 64; ++w) {
+            const uint32_t v0 = red_cnt[w], v1 = far_cnt[w];
+            at0 += w < wave ? v0 : 0u;
+            at1 += w < wave ? v1 : 0u;
+            seg_total[0] += v0;
+            seg_total[1] += v1;
+        }
+        const uint32_t seg_max = max(seg_total[0], seg_total[1]);
+        if (seg_max > (uint32_t)kRowSegCap || seg_max > (uint32_t)(EPT * NT)) {
+            // the empirical CDF balanced the segments badly (no in-LDS fallback for these rows: the host repeats the call
+            // with k_env_rows)
+            if (tid == 0) { atomicOr(&st->flags, ST_ROW_RETRY); env.len[r] = 0; }
+            return;
+        }
+#pragma unroll
+        for (int q = 0; q < PEPT; ++q) {
+            const int i = tid + q * NT;
+            const bool in = i < n, far = (seg_bits >> q) & 1u;
+            const unsigned long long m0 = __ballot(in && !far), m1 = __ballot(in && far);
+            const uint8_t cv = (uint8_t)(cp4[q >> 2] >> ((q & 3) * 8));
+            if (in && !far) {
+                const uint32_t pos = at0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
+                key[pos] = d2u(mp[q]);
+                val[pos] = cv;
+            }
+            if (in && far) {
+                const uint32_t pos = seg_total[0] + at1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+                ok_[pos] = d2u(mp[q]);
+                oc_[pos] = cv;
+            }
+            at0 += (uint32_t)__popcll(m0);
+            at1 += (uint32_t)__popcll(m1);
+        }
+        __syncthreads();
+        ESTAMP(1);
+    }
     bool bad_c = false;
     int seg_base = 0;
-#pragma unroll
+#pragma unroll 1
     for (int sg = 0; sg < NSEG; ++sg) {
-        for (int b = tid; b <= NB; b += NT) hist[b] = 0u;
+        // (an opaque copy of the thread index: addresses derived from it -- 60 coordinate pointers -- are otherwise hoisted out of
+        //  the segment loop and kept alive through it: 280 spilled registers)
+        int tl = tid;
+        if constexpr (NSEG > 1) asm volatile("" : "+v"(tl));
+        int n_pts = n;  // points of this sort
+        if constexpr (NSEG > 1) {
+            // every thread takes EPT of the segment's points back into registers: from the key array, or from the row's slot
+            // of the environment store
+            const uint32_t total = seg_total[sg];
+            n_pts = (int)total;
+#pragma unroll
+            for (int q = 0; q < (EPT + 3) / 4; ++q) ct4[q] = 0u;
+            if (sg == 0) {
+#pragma unroll
+                for (int q = 0; q < EPT; ++q) {
+                    const int i = tl + q * NT, ii = i < n_pts ? i : 0;
+                    m[q] = u2d(key[ii]);
+                    ct4[q >> 2] |= (uint32_t)val[ii] << ((q & 3) * 8);
+                }
+            } else {  // (clamped, unconditional loads: all in flight together; .glc -- written by other waves of this block)
+                const uint64_t* src_k = ok_ + seg_total[0];
+                const uint8_t* src_c = oc_ + seg_total[0];
+#pragma unroll
+                for (int q = 0; q < EPT; ++q) {
+                    const int i = tl + q * NT, ii = i < n_pts ? i : 0;
+                    m[q] = u2d(__hip_atomic_load(&src_k[ii], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    ct4[q >> 2] |= (uint32_t)__hip_atomic_load(&src_c[ii], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << ((q & 3) * 8);
+                }
+            }
+            __syncthreads();  // (the sort below reuses the key array)
+        }
+        for (int b = tl; b <= NB; b += NT) hist[b] = 0u;
         __syncthreads();
-        // 3. interpolated rank -> one of NBT balanced buckets; the histogram atomic returns the point's slot inside its bucket
-        uint32_t bs[EPT];  // bucket | slot << 13; ~0 = not in this segment
+        // 3. the point's bucket; the histogram atomic returns its slot inside the bucket
+        uint32_t bs[EPT];  // bucket | slot << 13
         uint32_t biggest = 0;
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
             bs[q] = ~0u;
-            if (tid + q * NT < n && m[q] >= 0.0) {  // (a point an earlier segment has placed carries -1)
-                int gb = NBT - 1;  // +inf entries of a distance matrix
-                if (m[q] <= dmax) {
-                    const double t = m[q] * inv_w;
-                    const int bin = min((int)t, kRowCoarse - 1);
-                    const double frac = fmin(t - (double)bin, 1.0);
-                    const double qq = ((double)cum[bin] + frac * (double)coarse[bin]) * rank_scale;
-                    gb = qq < (double)NBT ? (int)qq : NBT - 1;
-                }
-                const int b = gb - sg * NB;
-                if (b >= 0 && b < NB) {
-                    const uint32_t slot = atomicAdd(&hist[b], 1u);
-                    bs[q] = (uint32_t)b | (slot << 13);
-                    biggest = max(biggest, slot + 1u);
-                }
+            if (tl + q * NT < n_pts) {
+                const int b = min(max(bucket_of(m[q]) - sg * NB, 0), NB - 1);  // (in range by the choice of the segment)
+                const uint32_t slot = atomicAdd(&hist[b], 1u);
+                bs[q] = (uint32_t)b | (slot << 13);
+                biggest = max(biggest, slot + 1u);
             }
         }
         for (int k = 32; k > 0; k >>= 1) biggest = max(biggest, (uint32_t)__shfl_xor((int)biggest, k));
@@ -1667,22 +1828,22 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 2 : 4)) void k_env_rows2(const Dev
         ESTAMP(2);
         if (biggest > (uint32_t)kRowBucketLimit) {
             if (n_seg > 1) {  // (rows of more than 16384 points have no in-LDS fallback: the host repeats the call with k_env_rows)
-                if (tid == 0) { atomicOr(&st->flags, ST_ROW_RETRY); env.len[r] = 0; }
+                if (tl == 0) { atomicOr(&st->flags, ST_ROW_RETRY); env.len[r] = 0; }
                 return;
             }
             // a pathological row (thousands of identical distances): the bitonic network on the exact keys
 #pragma unroll
             for (int q = 0; q < EPT; ++q) {
-                const int i = tid + q * NT;
+                const int i = tl + q * NT;
                 if (i < n) { key[i] = d2u(row ? m[q] : sqrt(m[q])); val[i] = cat_of(q); }
             }
-            for (int i = n + tid; i < n2; i += NT) { key[i] = kPadKey; val[i] = 0; }
+            for (int i = n + tl; i < n2; i += NT) { key[i] = kPadKey; val[i] = 0; }
             __syncthreads();
-            bitonic_sort_lds<NT>(key, val, n2, tid);
-            if (tid == 0 && n > 0 && key[0] != 0ull) atomicOr(&st->flags, ST_FIRST_NOT_ZERO);  // src/locohd.rs:74-77
+            bitonic_sort_lds<NT>(key, val, n2, tl);
+            if (tl == 0 && n > 0 && key[0] != 0ull) atomicOr(&st->flags, ST_FIRST_NOT_ZERO);  // src/locohd.rs:74-77
             __syncthreads();
-            if (env.cdf_keys) keys_to_cdf_lds<NT>(key, n, tid, cfgp);
-            if (tid == 0) seg_n_s = (uint32_t)n;
+            if (env.cdf_keys) keys_to_cdf_lds<NT>(key, n, tl, cfgp);
+            if (tl == 0) seg_n_s = (uint32_t)n;
             __syncthreads();
         } else {
             // 4. exclusive scan in groups of 64 buckets (one wavefront scan each), then of the group totals, then one
@@ -1706,14 +1867,10 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 2 : 4)) void k_env_rows2(const Dev
                 if (lane == 0) seg_n_s = carry;
             }
             __syncthreads();
-            for (int b = tid; b < NB; b += NT) hist[b] += seg_tot[b >> 6];
-            if (tid == 0) hist[NB] = seg_n_s;
+            for (int b = tl; b < NB; b += NT) hist[b] += seg_tot[b >> 6];
+            if (tl == 0) hist[NB] = seg_n_s;
             __syncthreads();
             const int seg_n = (int)seg_n_s;
-            if (n_seg > 1 && seg_n > kRowSegCap) {  // the empirical CDF balanced the segments badly: see above
-                if (tid == 0) { atomicOr(&st->flags, ST_ROW_RETRY); env.len[r] = 0; }
-                return;
-            }
             ESTAMP(3);
             // 5. scatter (no atomics): position = bucket start + slot; the exact distance replaces the image in the register
 #pragma unroll
@@ -1756,15 +1913,14 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 2 : 4)) void k_env_rows2(const Dev
                     nz |= (sg == 0 && rank == 0u && m[q] != 0.0);  // src/locohd.rs:74-77, on the distance
                     key[rank] = env.cdf_keys ? d2u(cdf_lean(wf.kind, prm, wf.n_params, winv, m[q]) + 0.0) : d2u(m[q]);
                     val[rank] = cat_of(q);
-                    m[q] = -1.0;  // placed: the later segments skip it
                 }
             if (__ballot(nz) && lane == 0) atomicOr(&st->flags, ST_FIRST_NOT_ZERO);
             __syncthreads();
             if (env.cdf_keys) {  // F is monotone; a last-bit inversion of its floating-point evaluation is repaired by a running maximum
                 bool inv = false;
-                for (int i = tid; i < seg_n; i += NT) inv |= key[i] < (i ? key[i - 1] : carry_key_s);
+                for (int i = tl; i < seg_n; i += NT) inv |= key[i] < (i ? key[i - 1] : carry_key_s);
                 if (__syncthreads_or(inv ? 1 : 0)) {
-                    if (tid == 0) {
+                    if (tl == 0) {
                         uint64_t mx = carry_key_s;
                         for (int i = 0; i < seg_n; ++i) { mx = key[i] > mx ? key[i] : mx; key[i] = mx; }
                     }
@@ -1775,14 +1931,14 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 2 : 4)) void k_env_rows2(const Dev
         ESTAMP(6);
         {   // 8. write-out; categories outside the map: reported here, stored as 0 (see k_env_cells)
             const int seg_n = (int)seg_n_s, C = cfg.n_categories;
-            for (int i = tid; i < seg_n; i += NT) {
+            for (int i = tl; i < seg_n; i += NT) {
                 const uint8_t v = val[i];
                 bad_c |= (int)v >= C;
                 ok_[seg_base + i] = key[i];
                 oc_[seg_base + i] = (int)v < C ? v : (uint8_t)0;
             }
             __syncthreads();
-            if (tid == 0 && seg_n > 0) carry_key_s = key[seg_n - 1];
+            if (tl == 0 && seg_n > 0) carry_key_s = key[seg_n - 1];
             seg_base += seg_n;
             __syncthreads();
         }
@@ -1809,7 +1965,7 @@ bool launch_env_rows2(hipStream_t s, const DevConfig* cfg, const RowSide& a, con
     sides.n_rows = n_rows;
     const dim3 grid((unsigned)(2 * n_rows));
     const size_t lds = (size_t)n2 * 9 + 16 + (size_t)(kRowBucketsSmall + 1) * sizeof(uint32_t);
-    if (n_seg > 1) k_env_rows2<1024, 20, 2><<<grid, 1024, lds, s>>>(cfg, sides, n2, st);
+    if (n_seg > 1) k_env_rows2<1024, 12, 2><<<grid, 1024, kRowSegLds, s>>>(cfg, sides, n2, st);
     else if (n2 <= 1024) k_env_rows2<64, 16, 1><<<grid, 64, lds, s>>>(cfg, sides, n2, st);
     else if (n2 <= 4096) k_env_rows2<256, 16, 1><<<grid, 256, lds, s>>>(cfg, sides, n2, st);
     else if (n2 <= 8192) k_env_rows2<1024, 8, 1><<<grid, 1024, lds, s>>>(cfg, sides, n2, st);
@@ -3506,7 +3662,7 @@ void init_device_kernels() {
 #ifdef LCHD_ROWS_NT512
     raise(reinterpret_cast<const void*>(&k_env_rows2<512, 20, 1>), 16384 * 9 + 16 + (kRowBucketsSmall + 1) * 4);
 #endif
-    raise(reinterpret_cast<const void*>(&k_env_rows2<1024, 20, 2>), 16384 * 9 + 16 + (kRowBucketsSmall + 1) * 4);
+    raise(reinterpret_cast<const void*>(&k_env_rows2<1024, 12, 2>), (int)kRowSegLds);
     raise(reinterpret_cast<const void*>(&k_env_rows2<1024, 8, 1>), 8192 * 9 + 16 + (kRowBucketsSmall + 1) * 4);
     raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_GEN, F_KEY, 1>), 256 * 256);
     raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_GEN, F_ANY, 1>), 256 * 256);

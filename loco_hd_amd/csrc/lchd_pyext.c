@@ -111,7 +111,45 @@ static PyObject *pack_into(PyObject *self, PyObject *args) {
     Py_RETURN_NONE;
 }
 
+/* cats_into(seq, categories: dict, cat) -> None: category index of every label of a sequence (LoCoHD._cats: the seq_a /
+ * seq_b arguments of from_anchors / from_dmxs / from_coords, Vec<String> in the reference), -1 for labels outside the map. */
+static PyObject *cats_into(PyObject *self, PyObject *args) {
+    PyObject *labels, *categories, *o_cat;
+    if (!PyArg_ParseTuple(args, "OO!O", &labels, &PyDict_Type, &categories, &o_cat)) return NULL;
+    PyObject *seq = PySequence_Fast(labels, "expected a sequence of category labels");
+    if (!seq) return NULL;
+    const Py_ssize_t n = PySequence_Fast_GET_SIZE(seq);
+    Py_buffer b_cat;
+    if (get_buffer(o_cat, &b_cat, 4, n, "cat") != 0) { Py_DECREF(seq); return NULL; }
+    int32_t *cat = (int32_t *)b_cat.buf;
+    int ok = 1;
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject *t = PySequence_Fast_GET_ITEM(seq, i); /* borrowed */
+        PyObject *idx = PyDict_GetItemWithError(categories, t); /* borrowed */
+        if (!idx && PyErr_Occurred()) { ok = 0; break; }
+        if (!idx && !PyUnicode_CheckExact(t)) { /* str(label), as the Python loop does */
+            PyObject *ts = PyObject_Str(t);
+            if (!ts) { ok = 0; break; }
+            idx = PyDict_GetItemWithError(categories, ts);
+            Py_DECREF(ts);
+            if (!idx && PyErr_Occurred()) { ok = 0; break; }
+        }
+        if (idx) {
+            const long v = PyLong_AsLong(idx);
+            if (v == -1 && PyErr_Occurred()) { ok = 0; break; }
+            cat[i] = (int32_t)v;
+        } else {
+            cat[i] = -1;
+        }
+    }
+    PyBuffer_Release(&b_cat);
+    Py_DECREF(seq);
+    if (!ok) return NULL;
+    Py_RETURN_NONE;
+}
+
 static PyMethodDef methods[] = {
+    {"cats_into", cats_into, METH_VARARGS, "cats_into(labels, categories, cat): category indices of a sequence of labels (-1: not in the map)"},
     {"pack_into", pack_into, METH_VARARGS, "pack_into(prims, categories, interner, xyz, cat, tag): fill SoA buffers from a sequence of PrimitiveAtom"},
     {NULL, NULL, 0, NULL}};
 
