@@ -254,6 +254,7 @@ static Tuning tuning_from_env() {  // the ONLY place that reads LCHD_* hooks (te
     Tuning t;
     t.no_struct_cells = getenv("LCHD_NO_STRUCT_CELLS") != nullptr;
     t.no_small_dedupe = getenv("LCHD_NO_SMALL_DEDUPE") != nullptr;
+    t.no_share = getenv("LCHD_NO_SHARED_ENVS") != nullptr;
     t.no_cdf_keys = getenv("LCHD_NO_CDF_KEYS") != nullptr;
     t.no_duo = getenv("LCHD_NO_DUO") != nullptr;
     t.force_wide = env_int("LCHD_FORCE_WIDE", 0) != 0;
@@ -832,7 +833,12 @@ static int prims_enqueue(lchd_ctx* c) {
     const double thr = P.thr;
     const int cap = P.cap;
     const GridPlan ga = plan_grid(a, thr), gb = plan_grid(b, thr);
-    const int64_t max_env_a = std::min<int64_t>(a->n, n_pairs), max_env_b = std::min<int64_t>(b->n, n_pairs);
+    // Both sides the SAME device object (all-vs-all over one batch of structures, a structure against itself): an anchor's
+    // environment does not depend on the side it is used on (src/locohd.rs:514-542 is one closure for both), so the cell
+    // list and every environment are built once -- the anchors of both columns share side A's flags, slots and store.
+    const bool same = (a == b) && !c->tune.no_share;
+    const int64_t max_env_a = same ? std::min<int64_t>(a->n, 2 * n_pairs) : std::min<int64_t>(a->n, n_pairs);
+    const int64_t max_env_b = same ? 0 : std::min<int64_t>(b->n, n_pairs);
     PassBufs pb{};
     {
         Arena dry(nullptr, 0, true);
@@ -871,7 +877,7 @@ static int prims_enqueue(lchd_ctx* c) {
         return ps;
     };
     (void)launch_prologue(s, c->tune, P.anchors, n_pairs, prep_side(cva, gva, sa), prep_side(cvb, gvb, sb), pb.zero_base, pb.zero_bytes,
-                          c->d_status);
+                          c->d_status, same);
     mark(c, 1);
     mark(c, 2);  // (cell lists and anchor de-duplication are one phase now; "anchors" reads 0)
     const bool tag_list = c->h_cfg.tag_mode != 0;
@@ -882,10 +888,10 @@ static int prims_enqueue(lchd_ctx* c) {
     SweepArgs sw{};
     fill_sweep_args(c, sw);
     sw.env_a = sa.env;
-    sw.env_b = sb.env;
+    sw.env_b = same ? sa.env : sb.env;
     sw.anchors = P.anchors;
     sw.slot_a = sa.slot;
-    sw.slot_b = sb.slot;
+    sw.slot_b = same ? sa.slot : sb.slot;
     sw.n_slot_a = a->n;
     sw.n_slot_b = b->n;
     sw.wf_index = P.wf;

@@ -51,6 +51,7 @@ struct HostStatus {
 struct Tuning {
     bool no_struct_cells = false;   // LCHD_NO_STRUCT_CELLS: always the generic (multi-pass, global atomics) cell list
     bool no_small_dedupe = false;   // LCHD_NO_SMALL_DEDUPE: never the fused one-workgroup-per-side prologue
+    bool no_share = false;          // LCHD_NO_SHARED_ENVS: build both sides even when they are the same device object
     bool no_cdf_keys = false;       // LCHD_NO_CDF_KEYS: environments keep distance keys even with a single weight function
     bool no_duo = false;            // LCHD_NO_DUO: never two pairs per wavefront
     bool force_wide = false;        // LCHD_FORCE_WIDE: k_sweep_wide for any category count
@@ -156,8 +157,10 @@ struct PrepSide {
 // Cell lists of both sides + anchor de-duplication (see lchd_kernels.hip).  [zero_base, zero_base + zero_bytes) is the
 // contiguous region holding cell_count of both sides followed by flag8_a, flag8_b (in this order, flag8_b last): the prologue
 // zeroes what its launch tier needs with at most one operation.  Returns the number of stream operations enqueued.
+// `same`: both sides are one device object -- side B's cell list and slots are not built, the anchors of both columns are
+// de-duplicated together into side A's flags / slots / records and n_unique[1] = 0.
 int launch_prologue(hipStream_t s, const Tuning& t, const int64_t* anchors, int64_t n_pairs, const PrepSide& a, const PrepSide& b,
-                    void* zero_base, size_t zero_bytes, DeviceStatus* st);
+                    void* zero_base, size_t zero_bytes, DeviceStatus* st, bool same = false);
 // Per-device function attributes (dynamic LDS above 64 KB): called by lchd_ctx_create with the context's device current.
 void init_device_kernels();
 

@@ -568,26 +568,33 @@ static bool fits_struct_path(const PrepSide& P, const Tuning& t, CloudView& cs) 
 }
 
 int launch_prologue(hipStream_t s, const Tuning& t, const int64_t* anchors, int64_t n_pairs, const PrepSide& a_in, const PrepSide& b_in,
-                    void* zero_base, size_t zero_bytes, DeviceStatus* st) {
+                    void* zero_base, size_t zero_bytes, DeviceStatus* st, bool same) {
     PrepSide a = a_in, b = b_in;
     CloudView csa, csb;
-    const bool fa = fits_struct_path(a, t, csa), fb = fits_struct_path(b, t, csb);
+    bool fa = fits_struct_path(a, t, csa), fb = fits_struct_path(b, t, csb);
+    if (same) {
+        // one object on both sides: column 1's anchors are flagged in side A's byte flags (k_prep_count validates them against
+        // the same atom count), side B gets no cell list (fb: "already built") and, seen as a structure of 0 atoms by the
+        // scan and scatter kernels, no slots and no records
+        b.flag8 = a.flag8;
+        fb = true;
+    }
     const int cps_a = a.g.dim[0] * a.g.dim[1] * a.g.dim[2], cps_b = b.g.dim[0] * b.g.dim[1] * b.g.dim[2];
     int ops = 0;
-    if (fa && fb && csa.n_struct == 1 && csb.n_struct == 1 && n_pairs <= kFusedPairsMax && !t.no_small_dedupe && a.c.n > 0 && b.c.n > 0) {
+    if (!same && fa && fb && csa.n_struct == 1 && csb.n_struct == 1 && n_pairs <= kFusedPairsMax && !t.no_small_dedupe && a.c.n > 0 && b.c.n > 0) {
         const size_t lds = std::max((size_t)cps_a * 4 + (size_t)a.c.n * 4, (size_t)cps_b * 4 + (size_t)b.c.n * 4);
         k_prologue_fused<<<2, 1024, lds, s>>>(anchors, n_pairs, a, b, st);
         return 1;
     }
     // the anchor flags (and, for the general cell list, its counters) must be zero: folded into the struct launch when both
     // sides take it, otherwise ONE memset over the contiguous region the caller laid out
-    const bool fold_zero = fa && fb;
+    const bool fold_zero = fa && fb;  // (same: fb is true by definition, so side A decides)
     if (!fold_zero) { (void)hipMemsetAsync(zero_base, 0, zero_bytes, s); ++ops; }
-    if (fa || fb) {
+    if (fa || (fb && !same)) {
         PrepSide sa_ = a, sb_ = b;
         sa_.c = csa; sb_.c = csb;
-        const int nsa = fa ? csa.n_struct : 0, nsb = fb ? csb.n_struct : 0;
-        const size_t lds = std::max(fa ? (size_t)cps_a * 4 + (size_t)csa.struct_size * 4 : 0, fb ? (size_t)cps_b * 4 + (size_t)csb.struct_size * 4 : 0);
+        const int nsa = fa ? csa.n_struct : 0, nsb = (fb && !same) ? csb.n_struct : 0;
+        const size_t lds = std::max(fa ? (size_t)cps_a * 4 + (size_t)csa.struct_size * 4 : 0, (fb && !same) ? (size_t)cps_b * 4 + (size_t)csb.struct_size * 4 : 0);
         // the anchor flags sit at the END of the zero region: [.. counters ..][flags_a][flags_b]
         uint32_t* zb = fold_zero ? reinterpret_cast<uint32_t*>(a.flag8) : nullptr;
         const int64_t zw = fold_zero ? (int64_t)((reinterpret_cast<char*>(zero_base) + zero_bytes - reinterpret_cast<char*>(a.flag8)) / 4) : 0;
@@ -605,6 +612,7 @@ int launch_prologue(hipStream_t s, const Tuning& t, const int64_t* anchors, int6
     const int64_t nbk = (work + 255) / 256;
     k_prep_count<<<(unsigned)std::max<int64_t>(1, std::min<int64_t>(nbk, 8192)), 256, 0, s>>>(anchors, n_pairs, a, b, cells_a, cells_b, st);
     ++ops;
+    if (same) b.c.n = 0;  // (for the scan / scatter kernels below: nothing to do on side B, n_unique[1] = 0)
     for (int side = 0; side < 2; ++side) {  // batches with more cells than one workgroup scans
         const PrepSide& P = side ? b : a;
         const int cells = side ? cells_b : cells_a;

@@ -499,3 +499,72 @@ def test_pair_sizes_around_the_small_pair_threshold(lh, oracle, density):
     assert np.max(np.abs(got - np.asarray(want))) < TIGHT
     small = np.mean(np.asarray(sizes).sum(axis=1) - 2 <= 224)
     assert 0.0 < small < 1.0 or density > 0.04  # the sweep really had both kinds of pairs to deal with
+
+
+def test_same_object_on_both_sides_shares_environments(lh, oracle, monkeypatch):
+    """Both sides ONE device object (all-vs-all inside a batch, a structure against itself): cell list and environments are
+    built once for the anchors of both columns.  Bitwise equal to the two-sided build (LCHD_NO_SHARED_ENVS) on every prologue
+    tier, and equal to the oracle."""
+    import torch
+    from loco_hd_amd.device import DeviceSession
+
+    rng = np.random.default_rng(77)
+    cats = [f"c{i}" for i in range(10)]
+
+    def run(build, pairs_of, thr):
+        out = []
+        for share in (True, False):
+            if share:
+                monkeypatch.delenv("LCHD_NO_SHARED_ENVS", raising=False)
+            else:
+                monkeypatch.setenv("LCHD_NO_SHARED_ENVS", "1")
+            lchd = lh.LoCoHD(cats, lh.WeightFunction("hyper_exp", [1.0, 0.1]), lh.TagPairingRule({"accept_same": False}))
+            sess = DeviceSession(lchd)
+            obj = build(sess)
+            pairs = torch.from_numpy(pairs_of()).cuda()
+            for _ in range(2):  # (the second pass runs with the sweep hint of the first)
+                sc = sess.from_primitives(obj, obj, pairs, thr).cpu().numpy()
+            out.append(sc)
+            sess.close()
+        monkeypatch.delenv("LCHD_NO_SHARED_ENVS", raising=False)
+        assert np.array_equal(out[0], out[1])
+        return out[0]
+
+    # general three-launch prologue: one structure of 6000 atoms against itself, random pairs (many atoms anchor in both columns)
+    n = 6000
+    side = (n / 0.05) ** (1 / 3)
+    xyz, cat, tag = rng.uniform(0, side, (n, 3)), rng.integers(0, 10, n).astype(np.int32), rng.integers(0, 40, n).astype(np.int32)
+    pairs = np.stack([rng.integers(0, n, 20_000), rng.integers(0, n, 20_000)], 1).astype(np.int64)
+    got = run(lambda s: s.upload(xyz, cat, tag), lambda: pairs, 9.0)
+    lo = oracle.LoCoHD(cats, oracle.WeightFunction("hyper_exp", [1.0, 0.1]), oracle.TagPairingRule({"accept_same": False}), n_of_threads=8)
+    want = np.asarray(lo.from_arrays(xyz, cat, tag, xyz, cat, tag, pairs[:3000], 9.0))
+    assert np.max(np.abs(got[:3000] - want)) < TIGHT
+    assert np.all(got[pairs[:, 0] == pairs[:, 1]] == 0.0)
+    # one-workgroup-per-structure cell lists: a batch of 12 structures of 900 atoms, all-vs-all
+    m = 900
+    structs = [(rng.uniform(0, 26.0, (m, 3)), rng.integers(0, 10, m).astype(np.int32), rng.integers(0, 300, m).astype(np.int32)) for _ in range(12)]
+    la = np.arange(0, m, 3)
+    offs_holder = {}
+
+    def build_batch(s):
+        b, offs = s.upload_batch(structs)
+        offs_holder["o"] = offs
+        return b
+
+    def batch_pairs():
+        o = offs_holder["o"]
+        return np.concatenate([np.stack([o[i] + la, o[j] + la], 1) for i in range(12) for j in range(i, 12)]).astype(np.int64)
+
+    got = run(build_batch, batch_pairs, 10.0)
+    k = 0
+    for i in range(12):
+        for j in range(i, 12):
+            if (i, j) in ((0, 0), (0, 1), (3, 9), (11, 11)):
+                want = np.asarray(lo.from_arrays(*structs[i], *structs[j], np.stack([la, la], 1), 10.0))
+                assert np.max(np.abs(got[k * len(la):(k + 1) * len(la)] - want)) < TIGHT, (i, j)
+            k += 1
+    # a small single structure against itself (the fused one-launch prologue is for two different objects)
+    xs, cs, ts = structs[0]
+    got = run(lambda s: s.upload(xs, cs, ts), lambda: np.stack([np.arange(m), np.arange(m)[::-1]], 1).astype(np.int64), 10.0)
+    want = np.asarray(lo.from_arrays(xs, cs, ts, xs, cs, ts, np.stack([np.arange(m), np.arange(m)[::-1]], 1), 10.0))
+    assert np.max(np.abs(got - want)) < TIGHT
