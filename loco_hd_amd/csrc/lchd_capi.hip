@@ -171,7 +171,7 @@ struct lchd_ctx {
     HostStatus* h_status = nullptr;    // pinned, device-visible: the kernels publish into it with plain stores (no D2H copy)
     bool status_dirty = false;         // a pass was abandoned half-way: memset d_status before the next one
     uint32_t seq = 0;                  // pass counter (HostStatus::snapshot_seq)
-    int sweep_hint = 0;                // 0 unknown, 1 small pairs were the majority in the last pass, 2 they were not (launch_sweep)
+    int sweep_hint = 0;                // 0 unknown, else 4 | 1 (pairs of <= 224 events were the majority of the last pass) | 2 (pairs with both environments <= 255 points were): launch_sweep
     unsigned long long* d_points = nullptr;
     double* d_tabs = nullptr;  // sqrt(k) | 1/sqrt(k), 65536 entries each
     double* d_powtab = nullptr;  // k^(1/e) | k^(-1/e) for the configured Hellinger exponent (allocated when one is first configured)
@@ -916,6 +916,7 @@ extern "C" int lchd_from_primitives_dev_async(lchd_ctx* c, lchd_cloud* a, lchd_c
     c->last_valid = false;
     if (n_pairs <= 0) return LCHD_OK;
     if (!d_anchors || !d_out) return fail(LCHD_EVALUE, "null anchor / score pointer");
+    if (n_pairs > (int64_t)0x7FFFFFFF) return fail(LCHD_EUNSUPPORTED, "more than 2^31 - 1 anchor pairs in one call (%lld): split the list", (long long)n_pairs);
     if (!(thr > 0.0))  // within_radius returns nothing => dists[0] panics (src/locohd.rs:74)
         return fail(LCHD_EPANIC, "index out of bounds: threshold_distance = %g leaves every environment empty", thr);
     if (a->n == 0 || b->n == 0) return fail(LCHD_EPANIC, "index out of bounds: anchor pairs given for an empty structure");
@@ -960,8 +961,9 @@ extern "C" int lchd_ctx_finish(lchd_ctx* c) {
         } else {
             c->shrink_votes = 0;
         }
-        if (c->h_status->n_small != ~0ull)  // who swept the pairs this time is the hint for the next
-            c->sweep_hint = (2 * c->h_status->n_small >= (unsigned long long)P.n_pairs) ? 1 : 2;  // pass of this configuration
+        if (c->h_status->n_small != ~0ull)  // what the pairs looked like this time picks the sweep kernels of the next pass of this configuration
+            c->sweep_hint = 4 | (2 * c->h_status->n_duo >= (unsigned long long)P.n_pairs ? 1 : 0) |
+                            (2 * c->h_status->n_c8 >= (unsigned long long)P.n_pairs ? 2 : 0);
         c->last = P.sw;
         c->last_valid = true;
         return status_to_rc(f, DRV_PRIMS);

@@ -44,6 +44,7 @@ struct HostStatus {
     uint32_t sweep_flags[8]; // word k != 0 <=> a sweep kernel reported status bit k (ST_* below)
     uint32_t snapshot_seq;   // pass counter written with the snapshot (the host checks that the pass it waited for got this far)
     uint32_t pad;
+    unsigned long long n_duo, n_c8;  // pairs of at most kDuoTile merged events / with both environments <= 255 points (both always counted)
 };
 
 // Test / tuning hooks.  Read from the environment ONCE, when a context is created (lchd_ctx_create), and handed to the
@@ -236,9 +237,10 @@ struct SweepArgs {
     int32_t gen_tab;          // set by launch_sweep: MODE_GEN may use power tables (Hellinger with a general exponent, unit category weights)
     int32_t forced;           // set by launch_sweep: the host picked the sweep kernels (hint from the previous pass): no device-side decision
 };
-// sweep_hint: 0 = unknown (launch every candidate kernel, the device decides from the pair records), 1 = the previous pass of
-// this configuration had a majority of small pairs (k_sweep_duo + the indirect k_sweep), 2 = it had not (plain k_sweep only).
-// Any choice is correct for any input; the hint only avoids launching kernels that return at once.
+// sweep_hint: 0 = unknown (launch every candidate kernel, the device decides from the pair records); otherwise what
+// k_pair_meta counted in the previous pass of this configuration: 4 | 1 (pairs of at most 224 merged events were the
+// majority: k_sweep_duo + the indirect k_sweep) | 2 (pairs with both environments <= 255 points were: the 8-bit-count k_sweep
+// + the indirect one); neither: the plain k_sweep only.  Any choice is correct for any input; the hint only picks the launch set.
 void launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinger2, bool unit_weights, bool wf_pow, int sweep_hint,
                   const SweepArgs& a);
 // trajectory frames: replicate the template's labels / unpack [frames][atoms][3] into SoA + bounding box keys

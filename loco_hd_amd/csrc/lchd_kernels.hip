@@ -3517,7 +3517,7 @@ static void launch_sweep_wide(hipStream_t s, int n_cat, int64_t n_pairs, int fmo
 // n_B | category of anchor B << 24}; n = 0 marks a pair the sweep must answer with NaN (anchor index out of range -- already
 // flagged by k_mark_anchors -- or an environment that overflowed / is empty -- flagged by K1).
 __global__ void k_pair_meta(SweepArgs args) {
-    int n_small = 0, biggest = 0;
+    int n_duo = 0, n_c8 = 0, biggest = 0;
     for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < args.n_pairs; p += (int64_t)gridDim.x * blockDim.x) {
         int64_t ea = p, eb = p;
         bool ok = true;
@@ -3539,20 +3539,25 @@ __global__ void k_pair_meta(SweepArgs args) {
         }
         args.meta[p] = make_int4((int)ea, (int)eb, nA | (c0a << 24), nB | (c0b << 24));
         biggest = max(biggest, max(nA, nB));
-        // pairs k_sweep_duo takes: everything that fits its tile, and the unusable ones (it writes their NaN)
-        n_small += (args.small_rule ? (max(nA, nB) <= kCount8MaxEnv) : (nA + nB - 2 <= kDuoTileFwd)) ? 1 : 0;
+        // pairs k_sweep_duo takes: everything that fits its tile, and the unusable ones (it writes their NaN); pairs the
+        // 8-bit-count sweep takes: both environments of at most 255 points.  Both are counted whichever rule this pass uses:
+        // the host picks the next pass's kernels from them.
+        n_duo += (nA + nB - 2 <= kDuoTileFwd) ? 1 : 0;
+        n_c8 += (max(nA, nB) <= kCount8MaxEnv) ? 1 : 0;
     }
     // pairs that fit one 32-lane tile: if they are the majority, k_sweep_duo sweeps them and k_sweep only the rest.  One
     // partial count per workgroup; the workgroup that finishes LAST folds them, publishes what the host wants to know into
     // the host-mapped mirror and resets the device status for the next pass -- no separate summing kernel, no memset before
     // a pass, no copy after it.
-    __shared__ int part_s[4], big_s[4];
+    __shared__ int big_s[4];
     __shared__ bool last_s;
-    for (int m = 32; m > 0; m >>= 1) { n_small += __shfl_xor(n_small, m); biggest = max(biggest, __shfl_xor(biggest, m)); }
-    if ((threadIdx.x & 63) == 0) { part_s[threadIdx.x >> 6] = n_small; big_s[threadIdx.x >> 6] = biggest; }
+    unsigned long long n_both = (unsigned long long)n_duo | ((unsigned long long)n_c8 << 32);  // (a launch has < 2^32 pairs)
+    for (int m = 32; m > 0; m >>= 1) { n_both += shfl_u64(n_both, (threadIdx.x & 63) ^ m); biggest = max(biggest, __shfl_xor(biggest, m)); }
+    __shared__ unsigned long long both_s[4];
+    if ((threadIdx.x & 63) == 0) { both_s[threadIdx.x >> 6] = n_both; big_s[threadIdx.x >> 6] = biggest; }
     __syncthreads();
     if (threadIdx.x == 0)  // (largest environment of the pass: the host lets its capacity hint decay with it)
-        last_s = last_workgroup_done(args.done, (unsigned long long)(part_s[0] + part_s[1] + part_s[2] + part_s[3]),
+        last_s = last_workgroup_done(args.done, both_s[0] + both_s[1] + both_s[2] + both_s[3],
                                      (uint32_t)max(max(big_s[0], big_s[1]), max(big_s[2], big_s[3])));
     __syncthreads();
     if (!last_s || threadIdx.x >= 64) return;
@@ -3560,7 +3565,12 @@ __global__ void k_pair_meta(SweepArgs args) {
     uint32_t mx;
     collect_done(args.done, threadIdx.x, v, mx);
     for (int m = 32; m > 0; m >>= 1) { v += shfl_u64(v, threadIdx.x ^ m); mx = max(mx, (uint32_t)__shfl_xor((int)mx, m)); }
-    if (threadIdx.x == 0) publish_status(args, v, mx);
+    if (threadIdx.x == 0) {
+        const unsigned long long duo = v & 0xFFFFFFFFull, c8 = v >> 32;
+        args.hst->n_duo = duo;
+        args.hst->n_c8 = c8;
+        publish_status(args, args.small_rule ? c8 : duo, mx);
+    }
 }
 
 void launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinger2, bool unit_weights, bool wf_pow, int sweep_hint,
@@ -3598,12 +3608,18 @@ void launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool helling
     // k_sweep_duo (two pairs of <= 224 merged events per wavefront, <= 16 category slots) and the 8-bit-count k_sweep (both
     // environments <= 255 points, more than 16 slots); the INDIRECT 16-bit k_sweep takes what they leave over.
     const bool fast_cfg = !wide && hellinger2 && unit_weights && small && fmode == F_KEY && !a.wf_index;
-#ifdef LCHD_C8_ALL  // experiment: the 8-bit-count sweep for every slot count (instead of k_sweep_duo up to 16 slots)
-    const bool use_c8 = fast_cfg && !t.no_count8, use_duo = fast_cfg && cmax <= 16 && !t.no_duo && !use_c8;
-#else
-    const bool use_duo = fast_cfg && cmax <= 16 && !t.no_duo, use_c8 = fast_cfg && cmax > 16 && !t.no_count8;
-#endif
+    // sweep_hint (what k_pair_meta counted in the previous pass of this configuration): 0 = nothing known, else
+    // 4 | (pairs of <= 224 events were the majority ? 1 : 0) | (pairs with both environments <= 255 points were ? 2 : 0).
+    // Up to 16 slots k_sweep_duo is the first choice and the 8-bit-count sweep the second (C2a: environments of ~170 points,
+    // pairs of ~340 events -- too long for a 32-lane tile, but their counts fit 8 bits: 2 count words per side instead of 3);
+    // above 16 slots only the 8-bit-count sweep exists.
+    const int hint_bits = t.no_sweep_hint ? 0 : sweep_hint;
+    const bool known = (hint_bits & 4) != 0, duo_major = (hint_bits & 1) != 0, c8_major = (hint_bits & 2) != 0;
+    const bool c8_small_slots = fast_cfg && cmax <= 16 && !t.no_count8 && known && !(duo_major && !t.no_duo) && c8_major;
+    const bool use_duo = fast_cfg && cmax <= 16 && !t.no_duo && !c8_small_slots;
+    const bool use_c8 = fast_cfg && !t.no_count8 && (cmax > 16 || c8_small_slots);
     a.small_rule = use_c8 ? 1 : 0;
+    const int hint = !known ? 0 : ((use_c8 ? c8_major : duo_major) ? 1 : 2);
     {
         const int64_t nb = (a.n_pairs + 255) / 256;
         const int mgrid = (int)(nb < kMetaPartials ? nb : kMetaPartials);
@@ -3620,7 +3636,6 @@ void launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool helling
         // Without a hint the small-pair kernel, its companion and the plain sweep are all launched and the number of small
         // pairs (k_pair_meta) decides on the device which of them do the work; with the hint of the previous pass only the
         // kernels that will work are launched.
-        const int hint = t.no_sweep_hint ? 0 : sweep_hint;
         a.forced = hint != 0;
         if (hint != 2) {
             a.duo_enabled = 1;
@@ -3633,13 +3648,10 @@ void launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool helling
                 else if (cmax <= 12) { k_sweep_duo<12><<<dgrid, NTH, 0, s>>>(a); k_sweep<12, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
                 else { k_sweep_duo<16><<<dgrid, NTH, 0, s>>>(a); k_sweep<16, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
             } else {
-#ifdef LCHD_C8_ALL
                 if (cmax <= 8) { k_sweep<8, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); k_sweep<8, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
                 else if (cmax <= 12) { k_sweep<12, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); k_sweep<12, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
                 else if (cmax <= 16) { k_sweep<16, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); k_sweep<16, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
-                else
-#endif
-                if (cmax <= 20) { k_sweep<20, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); k_sweep<20, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+                else if (cmax <= 20) { k_sweep<20, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); k_sweep<20, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
                 else if (cmax <= 24) { k_sweep<24, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); k_sweep<24, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
                 else if (cmax <= 28) { k_sweep<28, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); k_sweep<28, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
                 else { k_sweep<32, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); k_sweep<32, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }

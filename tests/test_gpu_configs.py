@@ -413,31 +413,34 @@ def test_eight_bit_count_sweep_with_a_minority_of_large_environments(lh, oracle,
             assert np.max(np.abs(got - plain)) < 1e-13
 
 
-def test_sweep_hint_follows_the_workload(lh, oracle, monkeypatch):
-    """One context scores workloads whose pair sizes flip between 'mostly small' and 'mostly large': the first pass launches
-    every candidate sweep kernel and lets the device decide, later passes launch what the PREVIOUS pass's outcome suggests
-    (k_sweep_duo + indirect k_sweep, or the plain k_sweep).  Any choice must give the oracle's scores for any input."""
+@pytest.mark.parametrize("ncat", [7, 11, 15])
+def test_sweep_hint_follows_the_workload(lh, oracle, monkeypatch, ncat):
+    """One context scores workloads whose pair sizes flip between 'mostly <= 224 events' (k_sweep_duo + indirect k_sweep),
+    'environments <= 255 points' (the 8-bit-count k_sweep<8 / 12 / 16> + indirect) and 'larger' (plain k_sweep): the first
+    pass launches every candidate and lets the device decide, later passes launch what the PREVIOUS pass's counts suggest.
+    Any choice must give the oracle's scores for any input."""
     import torch
     from loco_hd_amd.device import DeviceSession
 
     monkeypatch.setenv("LCHD_NO_INLINE_META", "1")
-    rng = np.random.default_rng(77)
-    cats = [f"c{i}" for i in range(7)]
+    rng = np.random.default_rng(77 + ncat)
+    cats = [f"c{i}" for i in range(ncat)]
     wf = ("hyper_exp", [1.0, 0.2])
     lchd = lh.LoCoHD(cats, lh.WeightFunction(*wf))
-    lo = oracle.LoCoHD(cats, oracle.WeightFunction(*wf))
+    lo = oracle.LoCoHD(cats, oracle.WeightFunction(*wf), n_of_threads=8)
     sess = DeviceSession(lchd)
     clouds = {}
-    for name, density in (("sparse", 0.02), ("dense", 0.05)):  # ~84 / ~209 points per environment at threshold 10
+    for name, density in (("sparse", 0.02), ("dense", 0.05), ("packed", 0.08)):  # ~84 / ~209 / ~335 points per environment at threshold 10
         n = 2500
         side = (n / density) ** (1 / 3)
         xa, xb = rng.uniform(0, side, (n, 3)), rng.uniform(0, side, (n, 3))
-        ca, cb = rng.integers(0, 7, n).astype(np.int32), rng.integers(0, 7, n).astype(np.int32)
+        ca, cb = rng.integers(0, ncat, n).astype(np.int32), rng.integers(0, ncat, n).astype(np.int32)
         pairs = np.stack([rng.integers(0, n, 3000), rng.integers(0, n, 3000)], 1).astype(np.int64)
         tag = np.zeros(n, dtype=np.int32)
         want = np.asarray(lo.from_arrays(xa, ca, tag, xb, cb, tag, pairs, 10.0))
         clouds[name] = (sess.upload(xa, ca), sess.upload(xb, cb), torch.from_numpy(pairs).cuda(), want)
-    for name in ("sparse", "sparse", "dense", "dense", "sparse", "dense", "sparse"):  # every hint transition
+    order = ("sparse", "sparse", "dense", "dense", "sparse", "dense", "packed", "packed", "dense", "packed", "sparse", "packed", "dense", "dense")
+    for name in order:  # every hint transition
         a, b, anchors, want = clouds[name]
         got = sess.from_primitives(a, b, anchors, 10.0).cpu().numpy()
         assert np.max(np.abs(got - want)) < TIGHT, name
