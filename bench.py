@@ -62,10 +62,10 @@ PROFILE_ROUND = "r02"
 # ---------------------------------------------------------------------------------------------------------------------------
 # workloads
 # ---------------------------------------------------------------------------------------------------------------------------
-def make_workload(name: str, rank: int, n_pairs: int, same_on_all_ranks: bool = False):
+def make_workload(name: str, rank: int, n_pairs: int, same_on_all_ranks: bool = False, n_atoms: int = 10_000):
     """Synthetic pair-list inputs of SURVEY.md 8(d).  Returns dict(xyz_a, xyz_b, cat_a, cat_b, pairs, thr, C, wf, label)."""
     if name in ("c2a", "c2b"):
-        n, c, seed, thr = 10_000, 10, 2, 10.0
+        n, c, seed, thr = (n_atoms if name == "c2b" else 10_000), 10, 2, 10.0
         rounds = max(1, n_pairs // n)
     elif name == "c5":  # stress: two 200k-point clouds, 25 categories, random anchor pairs
         n, c, seed, thr = 200_000, 25, 5, 10.0
@@ -519,7 +519,7 @@ def run_c2b(args, torch, dist, dev, rank, world, use_dist):
     import loco_hd_amd as lh
     from loco_hd_amd.device import DeviceSession
 
-    w = make_workload("c2b", rank, 0)
+    w = make_workload("c2b", rank, 0, n_atoms=args.dense_atoms)
     lchd = lh.LoCoHD([f"c{i}" for i in range(w["C"])], lh.WeightFunction(*w["wf"]))
     sess = DeviceSession(lchd, device=dev.index)
     sess.enable_timing(True)
@@ -547,7 +547,7 @@ def run_c2b(args, torch, dist, dev, rank, world, use_dist):
         result = base_result(args, world, n * world, elapsed, w["label"], {"pairs_per_gpu": n, "mean_env_points_per_pair": 2 * n,
                                                                            "sharding": "replicas only (one from_coords call per rank)"})
         result["scaling"] = "weak"
-        result["roofline"] = roofline_block("c2b", {"env": "k_env_rows2 (both structures' rows in one launch)", "sweep": "k_sweep"}[dom], algo, phase_ms[dom])
+        result["roofline"] = roofline_block("c2b" if n == 10_000 else f"c2b_{n}", {"env": "k_env_rows2 (both structures' rows in one launch)", "sweep": "k_sweep"}[dom], algo, phase_ms[dom])
         result["kernel_ms"] = phase_ms
         if not args.no_cpu_baseline and world == 1:
             from oracle import oracle as orc  # checker / baseline only
@@ -795,6 +795,7 @@ def main():
     ap.add_argument("--gather", default=None, choices=["end", "step"],
                     help="multi-GPU: RCCL gather of the scores to rank 0 inside every timed step (default for N > 1) or once behind the timed region")
     ap.add_argument("--emulate-world", type=int, default=0, help="one GPU, --scaling strong: time every rank's share of a W-GPU job in turn")
+    ap.add_argument("--dense-atoms", type=int, default=10_000, help="c2b: atoms per structure (= anchor pairs; the environment is the whole structure)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg, the parity gate and the extras (profiling runs)")
     args = ap.parse_args()
     if args.gather is None:

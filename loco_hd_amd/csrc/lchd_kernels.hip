@@ -2331,7 +2331,10 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 
     // per-lane category counts of the event loop: [side][word][lane] u64 of four 16-bit fields (a lane only ever touches its own)
     // (13 and more category slots only: up to 12 the register form runs at 4 waves/SIMD, which the extra 3 KB of LDS per wave
     // would cut to 3 -- measured 2-6 % slower -- while from 13 on the LDS form is 4-13 % faster at unchanged occupancy)
-    constexpr bool LDSCNT = H2 && LDSTAB && NW > 3 && (LCHD_LDS_COUNTS != 0);  // (16-bit fields: from 13 category slots on)
+#ifndef LCHD_C8_REGCNT
+#define LCHD_C8_REGCNT 0
+#endif
+    constexpr bool LDSCNT = H2 && LDSTAB && NW > 3 && (LCHD_LDS_COUNTS != 0) && !(CNT8 && LCHD_C8_REGCNT);  // (16-bit fields: from 13 category slots on)
     __shared__ uint64_t lc_[LDSCNT ? WPB : 1][LDSCNT ? 2 * NW * 64 : 1];
     // When pairs with at most kDuoTile merged events are the majority of a launch, k_sweep_duo sweeps them two per wavefront
     // and the INDIRECT instantiation of this kernel picks the remaining ones out of the pair records; otherwise the plain

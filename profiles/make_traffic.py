@@ -16,22 +16,23 @@ DOMINANT = {"c2a": "k_sweep<12", "c5": "k_sweep<28", "c4": "k_env_cells<64", "c3
 
 def main(workload, summary, stats):
     want = DOMINANT[workload]
-    counters, name = {}, None
+    # candidates: the kernels of that family, without the INDIRECT companion; the one with the largest total time in the kernel
+    # trace is the dominant one (the first pass of a configuration runs a different instantiation than the steady state)
+    total_ns, avg_by_name = {}, {}
+    with open(stats, newline="") as fh:
+        for row in csv.DictReader(fh):
+            kname = row["Name"].split("(")[0].strip()
+            if want in kname and "true, true" not in kname.replace(want, ""):
+                total_ns[kname] = float(row["TotalDurationNs"])
+                avg_by_name[kname] = float(row["AverageNs"])
+    name = max(total_ns, key=total_ns.get) if total_ns else None
+    counters = {}
     for line in open(summary):
         if "| per-dispatch:" not in line:
             continue
-        kname = line.split(" | ")[0]
-        if want not in kname or "true, true" in kname.split("(")[0].replace(want, ""):  # (not the INDIRECT companion)
-            continue
-        if name is None:
-            name = kname
-        if kname == name:
+        if name and line.split(" | ")[0].split("(")[0].strip() == name:
             counters.update(ast.literal_eval(line.split("per-dispatch: ")[1]))
-    avg_ns = None
-    with open(stats, newline="") as fh:
-        for row in csv.DictReader(fh):
-            if name and row["Name"].split("(")[0] == name.strip():
-                avg_ns = float(row["AverageNs"])
+    avg_ns = avg_by_name.get(name)
     if not name:
         raise SystemExit(f"no kernel matching {want!r} in {summary}")
     read_b = 2 * counters.get("FETCH_SIZE", 0) * 1024
