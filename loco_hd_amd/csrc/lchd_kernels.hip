@@ -1692,15 +1692,19 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 2 : 4)) void k_env_rows2(const Dev
     const double winv = cfg.wf_inv[0];
     const int NBT = NB * n_seg;  // buckets of the whole row; distance segment sg owns buckets [sg * NB, (sg + 1) * NB)
     const double rank_scale = n > 0 ? (double)NBT / (double)n : 0.0;
-    // interpolated rank of an image in the row -> one of NBT balanced buckets
+    // interpolated rank of an image in the row -> one of NBT balanced buckets.  Single precision: any map that never
+    // decreases with the image sorts correctly (rounding to float, the product with a positive constant, the truncation and
+    // the interpolation inside a bin -- which never exceeds the next bin's start -- all are), it only has to balance the
+    // buckets, and the double-precision conversions were a third of this phase's instructions.
+    const float inv_wf = (float)inv_w, rank_scale_f = (float)rank_scale;
     auto bucket_of = [&](double v) -> int {
         int gb = NBT - 1;  // +inf entries of a distance matrix
         if (v <= dmax) {
-            const double t = v * inv_w;
+            const float t = (float)v * inv_wf;
             const int bin = min((int)t, kRowCoarse - 1);
-            const double frac = fmin(t - (double)bin, 1.0);
-            const double qq = ((double)cum[bin] + frac * (double)coarse[bin]) * rank_scale;
-            gb = qq < (double)NBT ? (int)qq : NBT - 1;
+            const float frac = fminf(t - (float)bin, 1.0f);
+            const float qq = ((float)cum[bin] + frac * (float)coarse[bin]) * rank_scale_f;
+            gb = qq < (float)NBT ? (int)qq : NBT - 1;
         }
         return gb;
     };
@@ -1924,28 +1928,30 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 2 : 4)) void k_env_rows2(const Dev
                 }
             if (__ballot(nz) && lane == 0) atomicOr(&st->flags, ST_FIRST_NOT_ZERO);
             __syncthreads();
-            if (env.cdf_keys) {  // F is monotone; a last-bit inversion of its floating-point evaluation is repaired by a running maximum
-                bool inv = false;
-                for (int i = tl; i < seg_n; i += NT) inv |= key[i] < (i ? key[i - 1] : carry_key_s);
-                if (__syncthreads_or(inv ? 1 : 0)) {
-                    if (tl == 0) {
-                        uint64_t mx = carry_key_s;
-                        for (int i = 0; i < seg_n; ++i) { mx = key[i] > mx ? key[i] : mx; key[i] = mx; }
-                    }
-                    __syncthreads();
-                }
-            }
         }
         ESTAMP(6);
-        {   // 8. write-out; categories outside the map: reported here, stored as 0 (see k_env_cells)
+        {   // 8. write-out; categories outside the map: reported here, stored as 0 (see k_env_cells).  F is monotone, but its
+            //    floating-point evaluation may produce a last-bit inversion between neighbours: looked for on the way out
+            //    (the keys are being read anyway) and, in the rare case, repaired by a running maximum and written again.
             const int seg_n = (int)seg_n_s, C = cfg.n_categories;
+            bool inv = false;
             for (int i = tl; i < seg_n; i += NT) {
                 const uint8_t v = val[i];
+                const uint64_t k = key[i];
                 bad_c |= (int)v >= C;
-                ok_[seg_base + i] = key[i];
+                if (env.cdf_keys) inv |= k < (i ? key[i - 1] : carry_key_s);
+                ok_[seg_base + i] = k;
                 oc_[seg_base + i] = (int)v < C ? v : (uint8_t)0;
             }
-            __syncthreads();
+            if (__syncthreads_or(inv ? 1 : 0)) {
+                if (tl == 0) {
+                    uint64_t mx = carry_key_s;
+                    for (int i = 0; i < seg_n; ++i) { mx = key[i] > mx ? key[i] : mx; key[i] = mx; }
+                }
+                __syncthreads();
+                for (int i = tl; i < seg_n; i += NT) ok_[seg_base + i] = key[i];
+                __syncthreads();
+            }
             if (tl == 0 && seg_n > 0) carry_key_s = key[seg_n - 1];
             seg_base += seg_n;
             __syncthreads();
