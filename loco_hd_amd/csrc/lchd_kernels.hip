@@ -2076,7 +2076,10 @@ enum { F_KEY = 0, F_FAST = 1, F_ANY = 2 };
 #endif
 constexpr int kDuoTileFwd = 224;  // = kDuoTile (k_sweep_duo, below)
 constexpr int kCount8MaxEnv = 255;        // the 8-bit-count sweep takes pairs whose environments both have at most this many points
-constexpr int64_t kInlineMetaPairs = 4096;   // calls of at most this many pairs: the sweep works out the pair records itself (one launch)
+#ifndef LCHD_INLINE_META_PAIRS
+#define LCHD_INLINE_META_PAIRS 4096
+#endif
+constexpr int64_t kInlineMetaPairs = LCHD_INLINE_META_PAIRS;   // calls of at most this many pairs: the sweep works out the pair records itself (one launch)
 // H^2 = 1 - D / sqrt(N_a N_b) carries an absolute rounding error of a few 1e-16 (D is rebuilt from the exact integer counts at
 // every lane chunk, so nothing drifts); sqrt() turns that into an error of ~3e-16 / (2 sqrt(H^2)) in H.  Below this bound the
 // literal difference-of-roots form is evaluated instead (exactly 0 for identical environments); at the bound the cancellation

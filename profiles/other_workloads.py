@@ -61,7 +61,7 @@ for nn in (1000, 3000):
     ha, hb = s1.upload(xa, ct, tg), s1.upload(xb, ct, tg)
     an = torch.from_numpy(np.stack([np.arange(0, nn, 3), np.arange(0, nn, 3)], 1)).cuda()
     o1 = torch.empty(len(an), dtype=torch.float64, device="cuda")
-    t = timed(lambda: s1.from_primitives(ha, hb, an, 10.0, out=o1), reps=50, warm=5)
+    t = timed(lambda: s1.from_primitives(ha, hb, an, 10.0, out=o1), reps=200, warm=20)  # (steady state: the first calls after start-up run at idle clocks)
     res[f"single_structure_pair_{nn}_atoms"] = {"pairs": len(an), "ms_per_call": t}
     s1.close()
 
