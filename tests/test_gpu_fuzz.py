@@ -40,8 +40,13 @@ def draw_sd(rng):
 
 
 @pytest.mark.parametrize("seed", range(N_SEEDS))
-def test_random_configuration(oracle, seed):
+def test_random_configuration(oracle, seed, monkeypatch):
     import loco_hd_amd as lh
+
+    # odd seeds: the regular pipeline (pair records by k_pair_meta, sweep kernels picked by the device on the first pass and from
+    # the previous pass's pair statistics afterwards) instead of the one-launch sweep of small calls; read when the context is created
+    if seed % 2:
+        monkeypatch.setenv("LCHD_NO_INLINE_META", "1")
 
     rng = np.random.default_rng(1000 + seed)
     ncat = int(rng.choice([2, 3, 5, 7, 10, 13, 20, 25, 31, 40]))
@@ -78,7 +83,14 @@ def test_random_configuration(oracle, seed):
             pa = [mod.PrimitiveAtom(s, t, c) for s, t, c in zip(sa, tags_a, xa)]
             pb = [mod.PrimitiveAtom(s, t, c) for s, t, c in zip(sb, tags_b, xb)]
             ap = [(i, j, k) for (i, j), k in zip(pairs, keys)] if multi else pairs
-            return np.asarray(lchd.from_primitives(pa, pb, ap, thr))
+            out = np.asarray(lchd.from_primitives(pa, pb, ap, thr))
+            if mod is lh:  # the same object again: later passes launch the sweep kernels the first pass's statistics suggest
+                for _ in range(2):
+                    again = np.asarray(lchd.from_primitives(pa, pb, ap, thr))
+                    same = np.isfinite(out)
+                    assert np.array_equal(same, np.isfinite(again))
+                    assert np.max(np.abs(again[same] - out[same]), initial=0.0) < 1e-13
+            return out
         n = min(na, nb)
         if mode == "coords":
             return np.asarray(lchd.from_coords(sa[:n], sb[:n], xa[:n], xb[:n], keys[:n] if multi else None))
