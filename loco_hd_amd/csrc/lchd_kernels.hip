@@ -2062,6 +2062,9 @@ enum { F_KEY = 0, F_FAST = 1, F_ANY = 2 };
 #ifndef LCHD_SWEEP_MINW
 #define LCHD_SWEEP_MINW 2
 #endif
+#ifndef LCHD_GEN_W3MAX
+#define LCHD_GEN_W3MAX 0   // generic-distance sweeps (MODE_GEN) with at most this many category slots are compiled for 3 waves/SIMD
+#endif
 #ifndef LCHD_EPL_C8
 #define LCHD_EPL_C8 7    // ... of the 8-bit-count sweep: tiles of 448 (two environments of <= 255 points rarely merge to more)
 #endif
@@ -2314,7 +2317,7 @@ __device__ unsigned long long g_sweep_stamps[8];
 // tile and to keep per lane, and 3 KB less LDS per wavefront, which lets the many-slot variants run at 3 waves per SIMD
 // instead of 2.  Pairs with a larger environment are left to the INDIRECT instantiation of the 16-bit kernel.
 template <int CMAX, int MODE, int FMODE, bool LDSTAB, bool INDIRECT = false, bool INLINE_META = false, bool CNT8 = false>
-__global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? 2 : (CMAX <= 12 ? 4 : (CMAX <= LCHD_SWEEP_W3MAX ? 3 : (CNT8 ? LCHD_C8_WAVES : 2))))) void k_sweep(SweepArgs args) {
+__global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? (CMAX <= LCHD_GEN_W3MAX ? 3 : 2) : (CMAX <= 12 ? 4 : (CMAX <= LCHD_SWEEP_W3MAX ? 3 : (CNT8 ? LCHD_C8_WAVES : 2))))) void k_sweep(SweepArgs args) {
     static_assert(!(INDIRECT && INLINE_META), "the indirect instantiation reads the records of k_pair_meta");
     static_assert(!CNT8 || (MODE == MODE_H2U && FMODE == F_KEY && LDSTAB && !INDIRECT && !INLINE_META), "8-bit counts: default configuration only");
     // Merged events per lane per tile.  The per-tile prologue (staging, merge path, scan of the packed counts, state reload)
