@@ -3006,7 +3006,11 @@ __device__ __forceinline__ double half_sum_f64(double v) {  // lanes 31 and 63 e
 template <int CMAX>
 __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs args) {
     constexpr int EPL = kDuoTile / 32, TILE = kDuoTile, WPB = kSweepWaves;
-    constexpr int NW = CMAX / 4;  // u64 words of 16-bit count fields per side (CMAX <= 16: one word of 4-bit fields)
+    // category counts as 8-bit fields: a pair of this kernel has at most kDuoTile = 224 merged events, so no count exceeds 225
+    // (one word per side up to 8 category slots, two up to 16: half the scans and no word select for the common 8-slot case)
+    constexpr int FPW = 8, FB = 8;
+    constexpr int NW = (CMAX + FPW - 1) / FPW;  // u64 words of count fields per side (CMAX <= 16: one word of 4-bit chunk fields)
+    static_assert(kDuoTile + 1 < 256, "8-bit count fields");
     static_assert(kDuoTile == kDuoTileFwd && EPL <= 15, "4-bit chunk-local counters");
     constexpr int NT = kSqrtTab + 8;
     __shared__ double t_sqrt[NT], t_rsqrt[NT];
@@ -3026,7 +3030,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs arg
     uint64_t* sB = sB_[wv][team];
     uint8_t* cA = cA_[wv][team];
     uint8_t* cB = cB_[wv][team];
-    auto field = [&](const uint64_t (&ex)[NW], int c) -> int { return (int)((ex[c >> 2] >> ((c & 3) * 16)) & 0xFFFFull); };
+    auto field = [&](const uint64_t (&ex)[NW], int c) -> int { return (int)((ex[c / FPW] >> ((c % FPW) * FB)) & 0xFFull); };
 
     const int64_t pstride = (int64_t)gridDim.x * WPB * 2;
     for (int64_t pb = ((int64_t)blockIdx.x * WPB + wv) * 2; pb < args.n_pairs; pb += pstride) {
@@ -3116,21 +3120,21 @@ __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs arg
         uint64_t exA[NW], exB[NW];
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
-            const uint64_t va_ = spread4(hA >> (16 * k)), vb_ = spread4(hB >> (16 * k));
+            const uint64_t va_ = spread8(hA >> (32 * k)), vb_ = spread8(hB >> (32 * k));
             const uint64_t sa_ = half_incl_scan_fields(va_), sb_ = half_incl_scan_fields(vb_);
-            exA[k] = (((c0a >> 2) == k) ? (1ull << ((c0a & 3) * 16)) : 0ull) + sa_ - va_;
-            exB[k] = (((c0b >> 2) == k) ? (1ull << ((c0b & 3) * 16)) : 0ull) + sb_ - vb_;
+            exA[k] = (((c0a / FPW) == k) ? (1ull << ((c0a % FPW) * FB)) : 0ull) + sa_ - va_;
+            exB[k] = (((c0b / FPW) == k) ? (1ull << ((c0b % FPW) * FB)) : 0ull) + sb_ - vb_;
         }
         int totA = 1 + i0, totB = 1 + j0;
         double D = 0.0;
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                const int c = 4 * k + f;
-                D += t_sqrt[field(exA, c)] * t_sqrt[field(exB, c)];
+            for (int f = 0; f < FPW; ++f) {
+                const int c = FPW * k + f;
+                if (c < CMAX) D += t_sqrt[field(exA, c)] * t_sqrt[field(exB, c)];
+                if ((f & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
         double ra = t_rsqrt[totA], rb = t_rsqrt[totB];
 
@@ -3158,16 +3162,16 @@ __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs arg
                 if (e == 0) firstF = F; else local += (F - Fp) * Hp;
                 totA += takeA ? 1 : 0;
                 totB += takeA ? 0 : 1;
-                const int sh = (ct & 3) * 16, sh4 = (ct & 15) * 4;
+                const int sh = (ct % FPW) * FB, sh4 = (ct & 15) * 4;
                 uint64_t wA = exA[0], wB = exB[0];
 #pragma unroll
                 for (int k = 1; k < NW; ++k) {
-                    const bool hit = ((ct >> 2) == k);
+                    const bool hit = ((ct / FPW) == k);
                     wA = hit ? exA[k] : wA;
                     wB = hit ? exB[k] : wB;
                 }
-                const int cntA_ = (int)((wA >> sh) & 0xFFFFull) + (int)((dA >> sh4) & 15ull);  // before the update
-                const int cntB_ = (int)((wB >> sh) & 0xFFFFull) + (int)((dB >> sh4) & 15ull);
+                const int cntA_ = (int)((wA >> sh) & 0xFFull) + (int)((dA >> sh4) & 15ull);  // before the update
+                const int cntB_ = (int)((wB >> sh) & 0xFFull) + (int)((dB >> sh4) & 15ull);
                 const uint64_t inc4 = 1ull << sh4;
                 dA += takeA ? inc4 : 0ull;
                 dB += takeA ? 0ull : inc4;
@@ -3181,14 +3185,16 @@ __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs arg
 #pragma unroll
                     for (int k = 0; k < NW; ++k) {
 #pragma unroll
-                        for (int f = 0; f < 4; ++f) {
-                            const int c = 4 * k + f;
-                            const int ca = field(exA, c) + (int)((dA >> (c * 4)) & 15ull);
-                            const int cb = field(exB, c) + (int)((dB >> (c * 4)) & 15ull);
-                            const double dd = t_sqrt[ca] * ra - t_sqrt[cb] * rb;
-                            acc2 = fma(dd, dd, acc2);
+                        for (int f = 0; f < FPW; ++f) {
+                            const int c = FPW * k + f;
+                            if (c < CMAX) {
+                                const int ca = field(exA, c) + (int)((dA >> (c * 4)) & 15ull);
+                                const int cb = field(exB, c) + (int)((dB >> (c * 4)) & 15ull);
+                                const double dd = t_sqrt[ca] * ra - t_sqrt[cb] * rb;
+                                acc2 = fma(dd, dd, acc2);
+                            }
+                            if ((f & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                         }
-                        __builtin_amdgcn_sched_barrier(0);
                     }
                     h2 = 0.5 * acc2;
                 }
