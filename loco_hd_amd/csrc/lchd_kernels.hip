@@ -3012,7 +3012,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs arg
     constexpr int NW = (CMAX + FPW - 1) / FPW;  // u64 words of count fields per side (CMAX <= 16: one word of 4-bit chunk fields)
     static_assert(kDuoTile + 1 < 256, "8-bit count fields");
     static_assert(kDuoTile == kDuoTileFwd && EPL <= 15, "4-bit chunk-local counters");
-    constexpr int NT = kSqrtTab + 8;
+    constexpr int NT = 256 + 8;  // (no count and no total of this kernel's pairs exceeds 226)
     __shared__ double t_sqrt[NT], t_rsqrt[NT];
     __shared__ uint64_t sA_[WPB][2][TILE], sB_[WPB][2][TILE];
     __shared__ uint8_t cA_[WPB][2][TILE], cB_[WPB][2][TILE];
