@@ -7,7 +7,10 @@
 namespace lchd {
 
 constexpr int kMaxCategories = 255;   // categories travel as u8 on the device
-constexpr int kSweepEPL = 6;          // merged events per lane per tile in the sweep kernel
+#ifndef LCHD_SWEEP_EPL
+#define LCHD_SWEEP_EPL 6
+#endif
+constexpr int kSweepEPL = LCHD_SWEEP_EPL;  // merged events per lane per tile in the sweep kernel (16-bit counts, LDS tables, <= 16 category slots; the generic distances)
 constexpr int kSweepTile = 64 * kSweepEPL;
 constexpr int kMetaPartials = 4096;   // most workgroups of k_pair_meta
 constexpr uint64_t kPadKey = ~0ull;   // sorts after every valid (non-negative, non-NaN) f64 bit pattern

@@ -2065,6 +2065,12 @@ enum { F_KEY = 0, F_FAST = 1, F_ANY = 2 };
 #ifndef LCHD_GEN_W3MAX
 #define LCHD_GEN_W3MAX 0   // generic-distance sweeps (MODE_GEN) with at most this many category slots are compiled for 3 waves/SIMD
 #endif
+#ifndef LCHD_EPL_WGEN
+#define LCHD_EPL_WGEN 7  // ... of the sweeps with category weights and of the generic distances, CDF-keyed environments (measured on C2a: weights 2.86 -> 2.54 ms, KS 4.62 -> 4.29 ms; the plain 16-bit Hellinger sweep and the sweeps that evaluate the CDF themselves are faster with 6: their LDS tables + tiles of 448 leave 3 workgroups per CU)
+#endif
+#ifndef LCHD_EPL_C8S
+#define LCHD_EPL_C8S 7   // ... of the 8-bit-count sweep with at most 16 category slots: tiles of 448 as well (C2a: 343 events per pair on average, 6 % of the pairs beyond 384 -- and a second, nearly empty tile costs half a pair; 1.77 -> 1.61 ms; 8 per lane drops to 3 waves/SIMD: 1.84 ms)
+#endif
 #ifndef LCHD_EPL_C8
 #define LCHD_EPL_C8 7    // ... of the 8-bit-count sweep: tiles of 448 (two environments of <= 255 points rarely merge to more)
 #endif
@@ -2325,7 +2331,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? (CMAX <= LCHD
     // the variants with many slots (25 categories at 0.05 atoms/A^3: ~416 events per pair) take tiles of 64 x LCHD_EPL_BIG so
     // that such a pair is ONE tile instead of a full one plus a nearly empty one.
     constexpr bool H2_ = (MODE != MODE_GEN);
-    constexpr int EPL = (CNT8 && CMAX > 16) ? LCHD_EPL_C8 : ((H2_ && LDSTAB && CMAX > 16) ? LCHD_EPL_BIG : ((H2_ && !LDSTAB) ? LCHD_EPL_DENSE : kSweepEPL)),
+    constexpr int EPL = (CNT8 && CMAX > 16) ? LCHD_EPL_C8 : (CNT8 && CMAX <= 16) ? LCHD_EPL_C8S : ((H2_ && LDSTAB && CMAX > 16) ? LCHD_EPL_BIG : ((H2_ && !LDSTAB) ? LCHD_EPL_DENSE : ((MODE != MODE_H2U && FMODE == F_KEY) ? LCHD_EPL_WGEN : kSweepEPL))),
                   TILE = 64 * EPL, WPB = kSweepWaves;
     static_assert(EPL <= 15, "4-bit chunk-local counters");
     constexpr int FB = CNT8 ? 8 : 16;     // bits per count field
