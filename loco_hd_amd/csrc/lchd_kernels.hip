@@ -2069,10 +2069,10 @@ enum { F_KEY = 0, F_FAST = 1, F_ANY = 2 };
 #define LCHD_EPL_WGEN 7  // ... of the sweeps with category weights and of the generic distances, CDF-keyed environments (measured on C2a: weights 2.86 -> 2.54 ms, KS 4.62 -> 4.29 ms; the plain 16-bit Hellinger sweep and the sweeps that evaluate the CDF themselves are faster with 6: their LDS tables + tiles of 448 leave 3 workgroups per CU)
 #endif
 #ifndef LCHD_EPL_C8S
-#define LCHD_EPL_C8S 7   // ... of the 8-bit-count sweep with at most 16 category slots: tiles of 448 as well (C2a: 343 events per pair on average, 6 % of the pairs beyond 384 -- and a second, nearly empty tile costs half a pair; 1.77 -> 1.61 ms; 8 per lane drops to 3 waves/SIMD: 1.84 ms)
+#define LCHD_EPL_C8S 8   // ... of the 8-bit-count sweep with at most 16 category slots: see LCHD_EPL_C8 (C2a: 343 events per pair on average; tiles of 384: 1.77 ms, 448: 1.61 ms, 512 with whole-list staging: 1.585 ms)
 #endif
 #ifndef LCHD_EPL_C8
-#define LCHD_EPL_C8 7    // ... of the 8-bit-count sweep: tiles of 448 (two environments of <= 255 points rarely merge to more)
+#define LCHD_EPL_C8 8    // ... of the 8-bit-count sweep: tiles of 512 -- two environments of <= 255 points never merge to more, so every pair is ONE tile (a list is staged whole: 256 entries; C5: 448-event tiles + tile-sized staging 3.08 ms, whole-list staging 2.88 ms, 512-event tiles 2.80 ms)
 #endif
 #ifndef LCHD_C8_WAVES
 #define LCHD_C8_WAVES 3  // waves per SIMD the 8-bit-count sweep with more than 16 category slots is compiled for
@@ -2333,6 +2333,10 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? (CMAX <= LCHD
     constexpr bool H2_ = (MODE != MODE_GEN);
     constexpr int EPL = (CNT8 && CMAX > 16) ? LCHD_EPL_C8 : (CNT8 && CMAX <= 16) ? LCHD_EPL_C8S : ((H2_ && LDSTAB && CMAX > 16) ? LCHD_EPL_BIG : ((H2_ && !LDSTAB) ? LCHD_EPL_DENSE : ((MODE != MODE_H2U && FMODE == F_KEY) ? LCHD_EPL_WGEN : kSweepEPL))),
                   TILE = 64 * EPL, WPB = kSweepWaves;
+    // entries staged per list and tile: a tile's worth -- but the pairs of the 8-bit-count sweep have at most 254 non-anchor
+    // points per environment, so 256 entries hold a whole list (4 KB of keys per wave instead of 7) and a tile of 512 events
+    // holds a whole pair
+    constexpr int LT = CNT8 ? 256 : TILE, LU = LT / 64;
     static_assert(EPL <= 15, "4-bit chunk-local counters");
     constexpr int FB = CNT8 ? 8 : 16;     // bits per count field
     constexpr int FPW = 64 / FB;          // count fields per u64 word
@@ -2344,8 +2348,8 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? (CMAX <= LCHD
     constexpr int NT = LDSTAB ? (CNT8 ? 256 + 8 : kSqrtTab + 8) : 1;  // sqrt(k), 1/sqrt(k) for k <= 512 (255) in LDS; otherwise read from the global tables
     __shared__ double t_sqrt[NT], t_rsqrt[NT];
     __shared__ double w_s[32], sw_s[32];
-    __shared__ uint64_t sA_[WPB][TILE], sB_[WPB][TILE];
-    __shared__ uint8_t cA_[WPB][TILE], cB_[WPB][TILE];
+    __shared__ uint64_t sA_[WPB][LT], sB_[WPB][LT];
+    __shared__ uint8_t cA_[WPB][LT], cB_[WPB][LT];
     // per-lane category counts of the event loop: [side][word][lane] u64 of four 16-bit fields (a lane only ever touches its own)
     // (13 and more category slots only: up to 12 the register form runs at 4 waves/SIMD, which the extra 3 KB of LDS per wave
     // would cut to 3 -- measured 2-6 % slower -- while from 13 on the LDS form is 4-13 % faster at unchanged occupancy)
@@ -2691,38 +2695,38 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? (CMAX <= LCHD
         int ia = 0, ib = 0;
         for (int k0 = 0; k0 < M; k0 += TILE) {
             const int T = min(TILE, M - k0);
-            const int nAt = min(TILE, mA - ia), nBt = min(TILE, mB - ib);
+            const int nAt = min(LT, mA - ia), nBt = min(LT, mB - ib);
             STAMP(0);
             wave_sync_lds();  // previous tile fully consumed
             // stage the tile: the global loads of BOTH lists are issued before the first LDS write (one memory latency per tile)
             {
                 // (wave-uniform base + 32-bit lane offset + immediate: one address register pair serves all loads of a list)
-                uint64_t rkA[EPL], rkB[EPL];
-                uint8_t rcA[EPL], rcB[EPL];
+                uint64_t rkA[LU], rkB[LU];
+                uint8_t rcA[LU], rcB[LU];
                 const char* pkA = reinterpret_cast<const char*>(kA + (1 + ia));
                 const char* pkB = reinterpret_cast<const char*>(kB + (1 + ib));
                 const uint8_t* pcA = tA + (1 + ia);
                 const uint8_t* pcB = tB + (1 + ib);
                 const uint32_t lane8 = (uint32_t)lane * 8u, lane1 = (uint32_t)lane;
 #pragma unroll
-                for (int u = 0; u < EPL; ++u) {
+                for (int u = 0; u < LU; ++u) {
                     const bool in = lane + 64 * u < nAt;
                     rkA[u] = in ? *reinterpret_cast<const uint64_t*>(pkA + lane8 + 512u * u) : 0ull;
                     rcA[u] = in ? pcA[lane1 + 64u * u] : (uint8_t)0;
                 }
 #pragma unroll
-                for (int u = 0; u < EPL; ++u) {
+                for (int u = 0; u < LU; ++u) {
                     const bool in = lane + 64 * u < nBt;
                     rkB[u] = in ? *reinterpret_cast<const uint64_t*>(pkB + lane8 + 512u * u) : 0ull;
                     rcB[u] = in ? pcB[lane1 + 64u * u] : (uint8_t)0;
                 }
 #pragma unroll
-                for (int u = 0; u < EPL; ++u) {
+                for (int u = 0; u < LU; ++u) {
                     const int t = lane + 64 * u;
                     if (t < nAt) { sA[t] = rkA[u]; cA[t] = rcA[u]; }
                 }
 #pragma unroll
-                for (int u = 0; u < EPL; ++u) {
+                for (int u = 0; u < LU; ++u) {
                     const int t = lane + 64 * u;
                     if (t < nBt) { sB[t] = rkB[u]; cB[t] = rcB[u]; }
                 }
@@ -2834,7 +2838,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? (CMAX <= LCHD
                     j += takeA ? 0 : 1;
                     {
                         const int nidx = takeA ? i : j, nend = takeA ? i1 : j1;
-                        const uint64_t nk = (takeA ? sA : sB)[min(nidx, TILE - 1)];
+                        const uint64_t nk = (takeA ? sA : sB)[min(nidx, LT - 1)];
                         const uint64_t nh = nidx < nend ? nk : kPadKey;
                         ka = takeA ? nh : ka;
                         kb = takeA ? kb : nh;
