@@ -1198,22 +1198,54 @@ const DevConfig* __restrict__ cfgp, EnvSides sides, double thr, int cap, DeviceS
         bitonic_sort_lds<NT>(key, val, n2, tid);
     }
     ESTAMP(2);
-    if (env.cdf_keys) {
-        if constexpr (NT == 64) keys_to_cdf_wave(key, count, lane, cfgp);
-        else keys_to_cdf_lds<NT>(key, count, tid, cfgp);
-    }
-    ESTAMP(3);
     uint64_t* ok_ = env.key + e * env.stride;
     uint8_t* oc_ = env.cat + e * env.stride;
     // categories outside the map are reported HERE (pmf.rs:38-42 raises for a point of a used environment, which is exactly
     // what gets written below) and stored as 0: the sweep kernels do not test categories again
     bool bad = false;
-    for (int i = tid; i < count; i += NT) {
-        const uint8_t v = val[i];
-        bad |= (int)v >= cfg.n_categories;
-        ok_[i] = key[i];
-        oc_[i] = (int)v < cfg.n_categories ? v : (uint8_t)0;
+    bool written = false;
+    if constexpr (NT == 64) {
+        if (env.cdf_keys) {
+            // One pass: sorted distance -> F(distance) -> global memory, the monotonicity of the converted keys checked on the
+            // way (F is monotone; its floating-point evaluation may produce a last-bit inversion between neighbours, which the
+            // running maximum of the separate path below repairs -- rare enough to pay a second pass then).  The separate
+            // conversion pass over LDS, its barrier and the second read of the keys were a tenth of this kernel.
+            const WfEntry wf = cfg.wf[0];
+            const double* __restrict__ prm = cfg.wf_params + wf.offset;
+            const double winv = cfg.wf_inv[0];
+            bool inv = false;
+            double carry = 0.0;  // F of the previous round's last key (F >= 0)
+            for (int i0 = 0; i0 < count; i0 += 64) {
+                const int i = i0 + lane;
+                const bool act = i < count;
+                const double f = act ? cdf_lean(wf.kind, prm, wf.n_params, winv, u2d(key[act ? i : 0])) + 0.0 : INFINITY;
+                double prev = wave_shr1_f64(f);
+                if (lane == 0) prev = carry;
+                inv |= act && f < prev;
+                carry = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(f), 63), __builtin_amdgcn_readlane(__double2loint(f), 63));
+                if (act) {
+                    const uint8_t v = val[i];
+                    bad |= (int)v >= cfg.n_categories;
+                    ok_[i] = d2u(f);
+                    oc_[i] = (int)v < cfg.n_categories ? v : (uint8_t)0;
+                }
+            }
+            written = !__ballot(inv);
+        }
     }
+    if (!written) {
+        if (env.cdf_keys) {
+            if constexpr (NT == 64) keys_to_cdf_wave(key, count, lane, cfgp);
+            else keys_to_cdf_lds<NT>(key, count, tid, cfgp);
+        }
+        for (int i = tid; i < count; i += NT) {
+            const uint8_t v = val[i];
+            bad |= (int)v >= cfg.n_categories;
+            ok_[i] = key[i];
+            oc_[i] = (int)v < cfg.n_categories ? v : (uint8_t)0;
+        }
+    }
+    ESTAMP(3);
     if (__ballot(bad) && (tid & 63) == 0) atomicOr(&st->flags, ST_BAD_CATEGORY);
     if (tid == 0) env.len[e] = count;
     ESTAMP(4);
