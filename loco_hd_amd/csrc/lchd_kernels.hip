@@ -2369,6 +2369,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? (CMAX <= LCHD
     // points per environment, so 256 entries hold a whole list (4 KB of keys per wave instead of 7) and a tile of 512 events
     // holds a whole pair
     constexpr int LT = CNT8 ? 256 : TILE, LU = LT / 64;
+    static_assert(!CNT8 || (kCount8MaxEnv <= LT && 2 * (kCount8MaxEnv - 1) <= TILE), "a whole list per staging buffer, a whole pair per tile");
     static_assert(EPL <= 15, "4-bit chunk-local counters");
     constexpr int FB = CNT8 ? 8 : 16;     // bits per count field
     constexpr int FPW = 64 / FB;          // count fields per u64 word
