@@ -119,8 +119,23 @@ def make_c3(rank: int, same_on_all_ranks: bool):
 
 
 def tile_structure_pairs(nd: int, world: int):
-    """Strong-scaling partition of the upper triangle of the nd x nd decoy-pair matrix: square tiles (so that a rank touches
-    ~2 x tile decoys instead of all of them), dealt to the ranks largest first, always to the rank with the fewest pairs."""
+    """Strong-scaling partition of the upper triangle of the nd x nd decoy-pair matrix into `world` shares of whole decoy pairs.
+    A rank builds the environments of every decoy its pairs touch, so the shares are made of square TILES of the pair matrix
+    (a tile of e x e pairs touches 2e decoys; e^2 pairs in a row of the matrix would touch e^2 + 1).
+    world = g^2 / 2 for an even g (2, 8, 18, 32): the decoys are cut into g groups; each of the g (g - 1) / 2 off-diagonal tiles is
+    one share, and the g diagonal tiles (half as many pairs each) go two to a share -- every rank touches 2 groups = 2 nd / g
+    decoys (world 8: 25 of 50) and the shares are equal to within a group's rounding.
+    Otherwise: tiles of about half a share, dealt largest first to the rank with the fewest pairs."""
+    g = 2
+    while g * g // 2 < world:
+        g += 2
+    if g * g // 2 == world:
+        bounds = [round(k * nd / g) for k in range(g + 1)]
+        groups = [range(bounds[k], bounds[k + 1]) for k in range(g)]
+        shares = [[(a, b) for a in groups[i] for b in groups[j]] for i in range(g) for j in range(i + 1, g)]
+        diag = [[(a, b) for a in groups[i] for b in groups[i] if a < b] for i in range(g)]
+        shares += [diag[2 * k] + diag[2 * k + 1] for k in range(g // 2)]
+        return shares
     g = 1
     while g * (g + 1) // 2 < 2 * world:
         g += 1
