@@ -265,6 +265,8 @@ static Tuning tuning_from_env() {  // the ONLY place that reads LCHD_* hooks (te
     t.no_count8 = getenv("LCHD_NO_COUNT8") != nullptr;
     t.old_rows = getenv("LCHD_OLD_ROWS") != nullptr;
     t.no_tables = getenv("LCHD_NO_SD_TABLES") != nullptr;
+    t.no_env_group = getenv("LCHD_NO_ENV_GROUP") != nullptr;
+    t.env_apw = env_int("LCHD_ENV_APW", 0);
     t.force_cmax = env_int("LCHD_FORCE_CMAX", 0);
     t.cap_hint = env_int("LCHD_CAP_HINT", 0);
     return t;
@@ -709,10 +711,11 @@ struct GridPlan {
     int n_cells;
 };
 
-static GridPlan plan_grid(const lchd_cloud* cl, double thr) {
+static GridPlan plan_grid(const lchd_cloud* cl, double thr, int reach) {
     GridPlan g{};
-    // cells are at least (1 + 1e-9) * thr wide so that |dx| < thr can never skip a cell through rounding
-    const double cell0 = thr * (1.0 + 1e-9);
+    // cells are at least (1 + 1e-9) * thr / reach wide so that |dx| < thr can never leave the (2 reach + 1)^3 neighbourhood of
+    // the anchor's cell through rounding (reach 1: k_env_cells / k_env_collect; reach 2: k_env_group)
+    const double cell0 = thr / reach * (1.0 + 1e-9);
     long long total = 1;
     for (int k = 0; k < 3; ++k) {
         const double ext = cl->bbmax[k] - cl->bbmin[k];
@@ -781,7 +784,7 @@ static void carve_pass(Arena& ar, int64_t n_a, int cells_a, int64_t envs_a, int6
         b.wpre = ar.take<uint32_t>((m + 31) / 32 + 2);
         b.chunk_base = ar.take<uint32_t>((m >> 18) + 2);
         b.cell_start = ar.take<uint32_t>((size_t)n_cells + 1);
-        b.rec = ar.take<CellRec>(m);
+        b.rec = ar.take<CellRec>(m + kEnvGroupRecPad);  // (k_env_group reads up to 7 records past a cell row's end)
         b.pos_of = ar.take<uint32_t>(m);
         b.uniq = ar.take<AnchorRec>(ne);
         b.scan_tmp = ar.take<uint32_t>(std::max<size_t>(m, (size_t)n_cells) / 4096 + 4);
@@ -832,7 +835,9 @@ static int prims_enqueue(lchd_ctx* c) {
     const int64_t n_pairs = P.n_pairs;
     const double thr = P.thr;
     const int cap = P.cap;
-    const GridPlan ga = plan_grid(a, thr), gb = plan_grid(b, thr);
+    // environments of the default capacity: several per wavefront on a grid of half-threshold cells (lchd_env_group.hip)
+    const bool group = cap == kEnvGroupCap && !c->tune.no_env_group && a->n < ((int64_t)1 << 29) && b->n < ((int64_t)1 << 29);
+    const GridPlan ga = plan_grid(a, thr, group ? 2 : 1), gb = plan_grid(b, thr, group ? 2 : 1);
     // Both sides the SAME device object (all-vs-all over one batch of structures, a structure against itself): an anchor's
     // environment does not depend on the side it is used on (src/locohd.rs:514-542 is one closure for both), so the cell
     // list and every environment are built once -- the anchors of both columns share side A's flags, slots and store.
@@ -882,7 +887,13 @@ static int prims_enqueue(lchd_ctx* c) {
     mark(c, 2);  // (cell lists and anchor de-duplication are one phase now; "anchors" reads 0)
     const bool tag_list = c->h_cfg.tag_mode != 0;
     const EnvSide esa{cva, gva, sa.uniq, sa.env, max_env_a, sa.raw_key, sa.raw_cat}, esb{cvb, gvb, sb.uniq, sb.env, max_env_b, sb.raw_key, sb.raw_cat};
-    if (!launch_env_cells(s, cap, c->d_cfg, tag_list, esa, esb, thr, c->d_status))
+    if (group) {
+        // anchors per wavefront: enough wavefronts to fill the chip a few times over, as many anchors each as that leaves
+        const int64_t total = max_env_a + max_env_b;
+        const int apw = c->tune.env_apw > 0 ? c->tune.env_apw : (int)std::max<int64_t>(2, std::min<int64_t>(16, total / 12288));
+        if (!launch_env_group(s, c->d_cfg, tag_list, esa, esb, thr, apw, c->d_status))
+            return fail(LCHD_EDEVICE, "the grouped environment kernel rejected its launch configuration");
+    } else if (!launch_env_cells(s, cap, c->d_cfg, tag_list, esa, esb, thr, c->d_status))
         return fail(LCHD_EUNSUPPORTED, "no environment kernel variant with capacity %d", cap);
     mark(c, 3);
     SweepArgs sw{};

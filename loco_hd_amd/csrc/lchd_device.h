@@ -66,6 +66,8 @@ struct Tuning {
     bool old_rows = false;          // LCHD_OLD_ROWS: dense rows through k_env_rows (three distance passes) for every length
     bool no_count8 = false;         // LCHD_NO_COUNT8: never the 8-bit-count sweep
     bool no_tables = false;         // LCHD_NO_SD_TABLES: generic distances without the per-launch power / log tables
+    bool no_env_group = false;      // LCHD_NO_ENV_GROUP: environments of the default capacity through k_env_cells (one per wavefront) too
+    int env_apw = 0;                // LCHD_ENV_APW: anchors per wavefront of k_env_group (0: chosen from the number of anchors)
     int force_cmax = 0;             // LCHD_FORCE_CMAX: at least this many category slots
     int cap_hint = 0;               // LCHD_CAP_HINT: first environment capacity to try
 };
@@ -183,6 +185,12 @@ struct EnvSides {
     EnvSide s[2];
 };
 bool launch_env_cells(hipStream_t s, int cap, const DevConfig* cfg, bool tag_list, const EnvSide& a, const EnvSide& b, double thr,
+                      DeviceStatus* st);
+// The default capacity (environments of at most kEnvGroupCap points), several environments per wavefront (lchd_env_group.hip).
+// Needs a grid whose cells are at least thr / 2 wide (the search walks the 5 x 5 x 5 neighbourhood), record arrays padded by
+// kEnvGroupRecPad records, fewer than 2^29 records per side and environment slots of at least kEnvGroupCap points.
+constexpr int kEnvGroupCap = 512, kEnvGroupRecPad = 8;
+bool launch_env_group(hipStream_t s, const DevConfig* cfg, bool tag_list, const EnvSide& a, const EnvSide& b, double thr, int anchors_per_wave,
                       DeviceStatus* st);
 
 // dense rows: either distances from coordinates (dmx == nullptr) or given rows (dmx != nullptr, leading dim ld)
