@@ -182,6 +182,7 @@ struct lchd_ctx {
     size_t io_cap = 0;
     std::vector<char> cfg_blob_host;  // last configuration blob uploaded (identical configurations are not uploaded again)
     int cap_hint = 512;
+    bool group_small = false;  // the last pass had no environment beyond kEnvGroupSmallUpTo points: k_env_group's small instantiation
     int shrink_votes = 0;  // consecutive passes whose largest environment would fit half of cap_hint
     // timing
     bool timing = false;
@@ -197,6 +198,7 @@ struct lchd_ctx {
         double thr = 0.0;
         double* out = nullptr;
         int cap = 0;
+        bool group = false, group_small = false;  // which environment kernel the enqueued pass uses
         SweepArgs sw{};
     } pend;
     // multi-GPU sharding helpers (lchd_shard_*): device state, host-mapped counts, the plan they belong to
@@ -837,6 +839,8 @@ static int prims_enqueue(lchd_ctx* c) {
     const int cap = P.cap;
     // environments of the default capacity: several per wavefront on a grid of half-threshold cells (lchd_env_group.hip)
     const bool group = cap == kEnvGroupCap && !c->tune.no_env_group && a->n < ((int64_t)1 << 29) && b->n < ((int64_t)1 << 29);
+    P.group = group;
+    P.group_small = false;
     const GridPlan ga = plan_grid(a, thr, group ? 2 : 1), gb = plan_grid(b, thr, group ? 2 : 1);
     // Both sides the SAME device object (all-vs-all over one batch of structures, a structure against itself): an anchor's
     // environment does not depend on the side it is used on (src/locohd.rs:514-542 is one closure for both), so the cell
@@ -891,7 +895,8 @@ static int prims_enqueue(lchd_ctx* c) {
         // anchors per wavefront: enough wavefronts to fill the chip a few times over, as many anchors each as that leaves
         const int64_t total = max_env_a + max_env_b;
         const int apw = c->tune.env_apw > 0 ? c->tune.env_apw : (int)std::max<int64_t>(2, std::min<int64_t>(16, total / 12288));
-        if (!launch_env_group(s, c->d_cfg, tag_list, esa, esb, thr, apw, c->d_status))
+        P.group_small = c->group_small;
+        if (!launch_env_group(s, c->d_cfg, tag_list, P.group_small, esa, esb, thr, apw, c->d_status))
             return fail(LCHD_EDEVICE, "the grouped environment kernel rejected its launch configuration");
     } else if (!launch_env_cells(s, cap, c->d_cfg, tag_list, esa, esb, thr, c->d_status))
         return fail(LCHD_EUNSUPPORTED, "no environment kernel variant with capacity %d", cap);
@@ -959,9 +964,13 @@ extern "C" int lchd_ctx_finish(lchd_ctx* c) {
             if (biggest > 65535)
                 return fail(LCHD_EUNSUPPORTED, "an environment holds %lld points; this build handles at most 65535 per environment "
                                                "(the category counts of the sweep are 16-bit fields)", (long long)biggest);
-            P.cap = next_pow2_host(biggest);
-            c->cap_hint = P.cap;
-            c->shrink_votes = 0;
+            if (P.group && P.group_small && biggest <= kEnvGroupCap) {
+                c->group_small = false;  // the small instantiation of k_env_group overflowed: the same capacity with the regular one
+            } else {
+                P.cap = next_pow2_host(std::max<int64_t>(biggest, P.cap + 1));
+                c->cap_hint = P.cap;
+                c->shrink_votes = 0;
+            }
             if (int rc = prims_enqueue(c)) return rc;
             continue;
         }
@@ -972,6 +981,7 @@ extern "C" int lchd_ctx_finish(lchd_ctx* c) {
         } else {
             c->shrink_votes = 0;
         }
+        if (biggest > 0) c->group_small = biggest <= kEnvGroupSmallUpTo;
         if (c->h_status->n_small != ~0ull)  // what the pairs looked like this time picks the sweep kernels of the next pass of this configuration
             c->sweep_hint = 4 | (2 * c->h_status->n_duo >= (unsigned long long)P.n_pairs ? 1 : 0) |
                             (2 * c->h_status->n_c8 >= (unsigned long long)P.n_pairs ? 2 : 0);

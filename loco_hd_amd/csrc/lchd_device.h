@@ -189,9 +189,10 @@ bool launch_env_cells(hipStream_t s, int cap, const DevConfig* cfg, bool tag_lis
 // The default capacity (environments of at most kEnvGroupCap points), several environments per wavefront (lchd_env_group.hip).
 // Needs a grid whose cells are at least thr / 2 wide (the search walks the 5 x 5 x 5 neighbourhood), record arrays padded by
 // kEnvGroupRecPad records, fewer than 2^29 records per side and environment slots of at least kEnvGroupCap points.
-constexpr int kEnvGroupCap = 512, kEnvGroupRecPad = 8;
-bool launch_env_group(hipStream_t s, const DevConfig* cfg, bool tag_list, const EnvSide& a, const EnvSide& b, double thr, int anchors_per_wave,
-                      DeviceStatus* st);
+// small_cap: the instantiation for environments of at most kEnvGroupCapSmall points (less LDS, one more wavefront per SIMD).
+constexpr int kEnvGroupCap = 512, kEnvGroupCapSmall = 320, kEnvGroupSmallUpTo = 288, kEnvGroupRecPad = 8;
+bool launch_env_group(hipStream_t s, const DevConfig* cfg, bool tag_list, bool small_cap, const EnvSide& a, const EnvSide& b, double thr,
+                      int anchors_per_wave, DeviceStatus* st);
 
 // dense rows: either distances from coordinates (dmx == nullptr) or given rows (dmx != nullptr, leading dim ld)
 struct RowExtras {            // all null for from_coords / from_dmxs

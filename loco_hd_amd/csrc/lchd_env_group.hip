@@ -17,12 +17,10 @@
 // Semantics are those of k_env_cells: keep p iff sum(diff^2) < thr^2 (uncontracted, same summation order) and (p is the anchor
 // itself or the tag rule accepts), distance = sqrt(sum), ascending order (ties in any order: zero-width intervals), optional
 // F(distance) keys, categories outside the map flagged and stored as 0.  An environment of more than 512 points, or an anchor
-// with more than kGTab candidate groups, is reported as ST_ENV_OVERFLOW and the host repeats the pass with k_env_cells.
+// with more than kGTab candidate groups, is reported as ST_ENV_OVERFLOW and the host repeats the pass with the larger
+// instantiation or with k_env_cells.
 #include "lchd_kcommon.h"
 
-#ifndef LCHD_GROUP_WAVES
-#define LCHD_GROUP_WAVES 5   // wavefronts per SIMD the kernel is compiled for (its 8 KB of LDS admit 20 workgroups per CU)
-#endif
 #ifndef LCHD_GROUP_U
 #define LCHD_GROUP_U 4   // search steps (64 candidates each) whose record loads are issued together
 #endif
@@ -31,20 +29,25 @@ namespace lchd {
 
 #define LCHD_AS4 __attribute__((address_space(4)))  // the constant address space: kernel arguments, the configuration blob
 
-constexpr int kGCap = kEnvGroupCap;  // points of one group (flat LDS buffer)
+// Two instantiations: CAP = points of one group (flat LDS buffer) = the largest environment the instantiation handles.
+//   <kEnvGroupCap, 5 waves/SIMD>       8.0 KB of LDS, 20 workgroups per CU
+//   <kEnvGroupCapSmall, 6 waves/SIMD>  6.1 KB, 24 workgroups per CU: ~5 % faster where every environment fits (the host picks it
+//                                      when the previous pass of the context had no environment beyond kEnvGroupSmallUpTo points)
 constexpr int kGMax = 8;             // environments per group
 constexpr int kGBuckets = 512;       // distance buckets of a group's sort (split evenly between its environments), 16-bit counters
 constexpr int kGTab = 224;           // candidate groups (8 records each) per anchor; the table is padded to whole search rounds
 
+template <int CAP>
 struct GroupLds {
-    uint64_t key[kGCap];               // d^2 while a group is being collected, then sorted distances
-    uint16_t val[kGCap];               // category | environment-in-group << 8
+    uint64_t key[CAP];                 // d^2 while a group is being collected, then sorted distances
+    uint16_t val[CAP];                 // category | environment-in-group << 8
     uint32_t hist[kGBuckets / 2 + 4];  // two 16-bit bucket counters per word (+ the end marker)
     uint32_t tab[2][kGTab];            // (byte offset of the first record) | records (1..8; 0 = padding), per half-wave anchor
     uint32_t gstart[kGMax], gcount[kGMax];
 };
-static_assert(sizeof(GroupLds) <= 8192, "20 workgroups per CU (160 KB of LDS)");
+static_assert(sizeof(GroupLds<kEnvGroupCap>) <= 8192 && sizeof(GroupLds<kEnvGroupCapSmall>) <= 6400, "20 / 24 workgroups per CU (160 KB of LDS)");
 static_assert(alignof(EnvSides) == 8 && sizeof(void*) == 8, "kernel-argument layout assumed by k_env_group");
+static_assert(kEnvGroupCap == 512, "k_env_group addresses environment slots with << 9");
 
 #ifdef LCHD_SWEEP_STAMPS
 __device__ unsigned long long g_envg_stamps[8];
@@ -80,10 +83,11 @@ __device__ __forceinline__ const LCHD_AS4 T* as_const(const T* p) {  // memory t
     return (const LCHD_AS4 T*)(unsigned long long)p;
 }
 
-template <bool TAGLIST>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LCHD_GROUP_WAVES, LCHD_GROUP_WAVES))) void k_env_group(
+template <bool TAGLIST, int kGCap, int WAVES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_env_group(
     const DevConfig* __restrict__ cfgp, EnvSides sides, double thr, int apw, int nwa, DeviceStatus* st) {
-    __shared__ __attribute__((aligned(16))) GroupLds lds;
+    static_assert(kGCap % 64 == 0 && kGCap <= kEnvGroupCap, "whole wavefronts; environment slots hold kEnvGroupCap points");
+    __shared__ __attribute__((aligned(16))) GroupLds<kGCap> lds;
     const int side = (int)blockIdx.x >= nwa ? 1 : 0;
     const int lane = threadIdx.x;
 #ifdef LCHD_SWEEP_STAMPS
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LCHD_GROUP_W
                 }
                 ++j;
                 do_flush = true;
-            } else if (ngrp > 0 && fill + (int)((float)(NG * 8) * seen_pts * __frcp_rn(seen_cand)) > kGCap) {
+            } else if (ngrp > 0 && fill + (int)((float)(NG * 8) * seen_pts * __builtin_amdgcn_rcpf(seen_cand)) > kGCap) {
                 do_flush = true;  // (the anchor is searched after the flush, into an empty buffer)
             } else {
                 // ---------------------------------------------------------------------------------- radius search of anchor j
@@ -427,7 +431,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LCHD_GROUP_W
                 carry_f = readlane_f64(f, 63);
                 carry_q = (uint32_t)__builtin_amdgcn_readlane((int)q, 63);
                 if (act) {
-                    const uint32_t o = (uint32_t)(((e_first + (int)q) << 9) + (i - (int)st_q));  // slot stride = kGCap = 512; < 2^31 (host)
+                    const uint32_t o = (uint32_t)(((e_first + (int)q) << 9) + (i - (int)st_q));  // slot stride = kEnvGroupCap = 512; < 2^31 (host)
                     bad |= (int)cat >= n_cat;
                     okey[o] = d2u(f);
                     ocat[o] = (int)cat < n_cat ? (uint8_t)cat : (uint8_t)0;
@@ -458,19 +462,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LCHD_GROUP_W
     if (__builtin_amdgcn_ballot_w64(bad) && lane == 0) atomicOr(&st->flags, ST_BAD_CATEGORY);
 }
 
-bool launch_env_group(hipStream_t s, const DevConfig* cfg, bool tag_list, const EnvSide& a, const EnvSide& b, double thr, int anchors_per_wave,
-                      DeviceStatus* st) {
+bool launch_env_group(hipStream_t s, const DevConfig* cfg, bool tag_list, bool small_cap, const EnvSide& a, const EnvSide& b, double thr,
+                      int anchors_per_wave, DeviceStatus* st) {
     if (a.max_envs + b.max_envs <= 0) return true;
     // slots of exactly kEnvGroupCap points, 32-bit element offsets into the store and 32-bit byte offsets into the record arrays
-    if (anchors_per_wave < 1 || a.env.stride != kGCap || (b.max_envs > 0 && b.env.stride != kGCap)) return false;
+    if (anchors_per_wave < 1 || a.env.stride != kEnvGroupCap || (b.max_envs > 0 && b.env.stride != kEnvGroupCap)) return false;
     if (a.max_envs >= (1 << 22) || b.max_envs >= (1 << 22) || a.c.n >= (1 << 27) || b.c.n >= (1 << 27)) return false;
     EnvSides sides;
     sides.s[0] = a;
     sides.s[1] = b;
     const int64_t nwa = (a.max_envs + anchors_per_wave - 1) / anchors_per_wave, nwb = (b.max_envs + anchors_per_wave - 1) / anchors_per_wave;
     const dim3 grid((unsigned)(nwa + nwb));
-    if (tag_list) k_env_group<true><<<grid, 64, 0, s>>>(cfg, sides, thr, anchors_per_wave, (int)nwa, st);
-    else k_env_group<false><<<grid, 64, 0, s>>>(cfg, sides, thr, anchors_per_wave, (int)nwa, st);
+    if (small_cap) {
+        if (tag_list) k_env_group<true, kEnvGroupCapSmall, 6><<<grid, 64, 0, s>>>(cfg, sides, thr, anchors_per_wave, (int)nwa, st);
+        else k_env_group<false, kEnvGroupCapSmall, 6><<<grid, 64, 0, s>>>(cfg, sides, thr, anchors_per_wave, (int)nwa, st);
+    } else {
+        if (tag_list) k_env_group<true, kEnvGroupCap, 5><<<grid, 64, 0, s>>>(cfg, sides, thr, anchors_per_wave, (int)nwa, st);
+        else k_env_group<false, kEnvGroupCap, 5><<<grid, 64, 0, s>>>(cfg, sides, thr, anchors_per_wave, (int)nwa, st);
+    }
     return true;
 }
 
