@@ -183,6 +183,7 @@ struct lchd_ctx {
     std::vector<char> cfg_blob_host;  // last configuration blob uploaded (identical configurations are not uploaded again)
     int cap_hint = 512;
     bool group_small = false;  // the last pass had no environment beyond kEnvGroupSmallUpTo points: k_env_group's small instantiation
+    int64_t last_biggest = 0;  // largest environment of the last pass (0: unknown): anchors per wavefront of k_env_group
     int shrink_votes = 0;  // consecutive passes whose largest environment would fit half of cap_hint
     // timing
     bool timing = false;
@@ -892,9 +893,11 @@ static int prims_enqueue(lchd_ctx* c) {
     const bool tag_list = c->h_cfg.tag_mode != 0;
     const EnvSide esa{cva, gva, sa.uniq, sa.env, max_env_a, sa.raw_key, sa.raw_cat}, esb{cvb, gvb, sb.uniq, sb.env, max_env_b, sb.raw_key, sb.raw_cat};
     if (group) {
-        // anchors per wavefront: enough wavefronts to fill the chip a few times over, as many anchors each as that leaves
-        const int64_t total = max_env_a + max_env_b;
-        const int apw = c->tune.env_apw > 0 ? c->tune.env_apw : (int)std::max<int64_t>(2, std::min<int64_t>(16, total / 12288));
+        // anchors per wavefront: as many as fit ONE group of the kernel's LDS buffer (measured, env phase in ms for 1 / 2 / 4 / 8 /
+        // 16 anchors: C4, ~96-point environments 3.87 / 2.88 / 2.68 / 2.69 / 2.96; C5, ~200 points 0.81 / 0.75 / 0.75 / 0.78 / 0.81 --
+        // more anchors per wavefront only lengthen the tail of the launch)
+        const int apw = c->tune.env_apw > 0 ? c->tune.env_apw
+                                            : (c->last_biggest > 0 && c->last_biggest <= 140 ? 4 : (c->last_biggest > kEnvGroupSmallUpTo ? 1 : 2));
         P.group_small = c->group_small;
         if (!launch_env_group(s, c->d_cfg, tag_list, P.group_small, esa, esb, thr, apw, c->d_status))
             return fail(LCHD_EDEVICE, "the grouped environment kernel rejected its launch configuration");
@@ -981,7 +984,7 @@ extern "C" int lchd_ctx_finish(lchd_ctx* c) {
         } else {
             c->shrink_votes = 0;
         }
-        if (biggest > 0) c->group_small = biggest <= kEnvGroupSmallUpTo;
+        if (biggest > 0) { c->group_small = biggest <= kEnvGroupSmallUpTo; c->last_biggest = biggest; }
         if (c->h_status->n_small != ~0ull)  // what the pairs looked like this time picks the sweep kernels of the next pass of this configuration
             c->sweep_hint = 4 | (2 * c->h_status->n_duo >= (unsigned long long)P.n_pairs ? 1 : 0) |
                             (2 * c->h_status->n_c8 >= (unsigned long long)P.n_pairs ? 2 : 0);

@@ -51,7 +51,7 @@ static_assert(kEnvGroupCap == 512, "k_env_group addresses environment slots with
 
 #ifdef LCHD_SWEEP_STAMPS
 __device__ unsigned long long g_envg_stamps[8];
-#define GSTAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) atomicAdd(&g_envg_stamps[i], t_ - gstamp_last); gstamp_last = t_; } while (0)
+#define GSTAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0 && (blockIdx.x & 63) == 0) atomicAdd(&g_envg_stamps[i], t_ - gstamp_last); gstamp_last = t_; } while (0)
 #else
 #define GSTAMP(i) do { } while (0)
 #endif
@@ -83,18 +83,24 @@ __device__ __forceinline__ const LCHD_AS4 T* as_const(const T* p) {  // memory t
     return (const LCHD_AS4 T*)(unsigned long long)p;
 }
 
+#ifndef LCHD_GROUP_WPB
+#define LCHD_GROUP_WPB 1   // independent wavefronts per workgroup (each with its own LDS block; no workgroup barrier anywhere)
+#endif
 template <bool TAGLIST, int kGCap, int WAVES>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_env_group(
+__global__ __launch_bounds__(64 * LCHD_GROUP_WPB) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_env_group(
     const DevConfig* __restrict__ cfgp, EnvSides sides, double thr, int apw, int nwa, DeviceStatus* st) {
     static_assert(kGCap % 64 == 0 && kGCap <= kEnvGroupCap, "whole wavefronts; environment slots hold kEnvGroupCap points");
-    __shared__ __attribute__((aligned(16))) GroupLds<kGCap> lds;
-    const int side = (int)blockIdx.x >= nwa ? 1 : 0;
-    const int lane = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) GroupLds<kGCap> lds_all[LCHD_GROUP_WPB];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    GroupLds<kGCap>& lds = lds_all[wave];
+    const int wid = (int)blockIdx.x * LCHD_GROUP_WPB + wave;  // nwa wavefronts build side A, the rest side B
+    const int side = wid >= nwa ? 1 : 0;
+    const int lane = threadIdx.x & 63;
 #ifdef LCHD_SWEEP_STAMPS
     unsigned long long gstamp_last = __builtin_amdgcn_s_memtime();
 #endif
     const int n_uniq = (int)st->n_unique[side];
-    const int e_begin = ((int)blockIdx.x - (side ? nwa : 0)) * apw;
+    const int e_begin = (wid - (side ? nwa : 0)) * apw;
     if (e_begin >= n_uniq) return;
     const int e_end = min(e_begin + apw, n_uniq);
     // this side's block of the kernel arguments (cfgp at offset 0, `sides` behind it)
@@ -472,13 +478,14 @@ bool launch_env_group(hipStream_t s, const DevConfig* cfg, bool tag_list, bool s
     sides.s[0] = a;
     sides.s[1] = b;
     const int64_t nwa = (a.max_envs + anchors_per_wave - 1) / anchors_per_wave, nwb = (b.max_envs + anchors_per_wave - 1) / anchors_per_wave;
-    const dim3 grid((unsigned)(nwa + nwb));
+    constexpr int WPB = LCHD_GROUP_WPB;
+    const dim3 grid((unsigned)((nwa + nwb + WPB - 1) / WPB));
     if (small_cap) {
-        if (tag_list) k_env_group<true, kEnvGroupCapSmall, 6><<<grid, 64, 0, s>>>(cfg, sides, thr, anchors_per_wave, (int)nwa, st);
-        else k_env_group<false, kEnvGroupCapSmall, 6><<<grid, 64, 0, s>>>(cfg, sides, thr, anchors_per_wave, (int)nwa, st);
+        if (tag_list) k_env_group<true, kEnvGroupCapSmall, 6><<<grid, 64 * WPB, 0, s>>>(cfg, sides, thr, anchors_per_wave, (int)nwa, st);
+        else k_env_group<false, kEnvGroupCapSmall, 6><<<grid, 64 * WPB, 0, s>>>(cfg, sides, thr, anchors_per_wave, (int)nwa, st);
     } else {
-        if (tag_list) k_env_group<true, kEnvGroupCap, 5><<<grid, 64, 0, s>>>(cfg, sides, thr, anchors_per_wave, (int)nwa, st);
-        else k_env_group<false, kEnvGroupCap, 5><<<grid, 64, 0, s>>>(cfg, sides, thr, anchors_per_wave, (int)nwa, st);
+        if (tag_list) k_env_group<true, kEnvGroupCap, 5><<<grid, 64 * WPB, 0, s>>>(cfg, sides, thr, anchors_per_wave, (int)nwa, st);
+        else k_env_group<false, kEnvGroupCap, 5><<<grid, 64 * WPB, 0, s>>>(cfg, sides, thr, anchors_per_wave, (int)nwa, st);
     }
     return true;
 }
