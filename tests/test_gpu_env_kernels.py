@@ -1,0 +1,127 @@
+"""The thresholded environment build has two kernels and a fall-back chain between them (loco_hd_amd/csrc/lchd_env_group.hip,
+lchd_kernels.hip): k_env_group (several environments per wavefront, 320- and 512-point instantiations, half-threshold grid)
+and k_env_cells / k_env_collect (one environment per workgroup, growing capacity).  Every link of the chain is forced here onto
+inputs the CPU oracle can follow (reference: env_from_idx, /root/reference/src/locohd.rs:514-542)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TIGHT = 1e-11
+CATS = ["A", "B", "C", "D", "E"]
+
+
+@pytest.fixture(scope="module")
+def lh():
+    import loco_hd_amd
+
+    return loco_hd_amd
+
+
+def prims(mod, seq, xyz, tags=None):
+    tags = [""] * len(seq) if tags is None else tags
+    return [mod.PrimitiveAtom(s, t, c) for s, t, c in zip(seq, tags, xyz)]
+
+
+def score(mod, seq_a, xyz_a, seq_b, xyz_b, anchors, thr, wf=("hyper_exp", [1.0, 0.1]), rule=None, tags_a=None, tags_b=None, repeat=1):
+    lchd = mod.LoCoHD(CATS, mod.WeightFunction(*wf), *([] if rule is None else [mod.TagPairingRule(rule)]))
+    pa, pb = prims(mod, seq_a, xyz_a, tags_a), prims(mod, seq_b, xyz_b, tags_b)
+    return [np.asarray(lchd.from_primitives(pa, pb, anchors, thr)) for _ in range(repeat)]
+
+
+def test_grouped_and_single_environment_kernels_agree(lh, oracle, monkeypatch):
+    """Protein-like density: the first call of an object runs the 512-point instantiation with 2 anchors per wavefront, the
+    later ones the instantiation / anchors per wavefront picked from the first call's largest environment; all of them, every
+    forced number of anchors per wavefront and the one-environment-per-workgroup kernel give bitwise identical scores."""
+    rng = np.random.default_rng(71)
+    for n, side, thr in ((900, 26.0, 10.0), (700, 31.0, 10.0), (400, 12.0, 4.0)):
+        sa, xa = rng.choice(CATS, n).tolist(), rng.uniform(0, side, (n, 3))
+        sb, xb = rng.choice(CATS, n - 50).tolist(), rng.uniform(0, side, (n - 50, 3))
+        anchors = [(int(i), int(j)) for i, j in zip(rng.integers(0, n, 600), rng.integers(0, n - 50, 600))]
+        want = score(oracle, sa, xa, sb, xb, anchors, thr)[0]
+        got = score(lh, sa, xa, sb, xb, anchors, thr, repeat=3)
+        for g in got:
+            assert np.max(np.abs(g - want)) < TIGHT
+            assert np.array_equal(g, got[0])
+        for hook in ({"LCHD_NO_ENV_GROUP": "1"}, {"LCHD_ENV_APW": "1"}, {"LCHD_ENV_APW": "3"}, {"LCHD_ENV_APW": "7"}, {"LCHD_ENV_APW": "40"}):
+            for k, v in hook.items():
+                monkeypatch.setenv(k, v)
+            alt = score(lh, sa, xa, sb, xb, anchors, thr, repeat=2)
+            for k in hook:
+                monkeypatch.delenv(k)
+            for a in alt:
+                assert np.array_equal(a, got[0]), hook
+
+
+def test_grouped_kernel_with_tag_rules(lh, oracle):
+    """Both tag-rule instantiations of the grouped kernel (one comparison / pair-list search), residues of three atoms."""
+    rng = np.random.default_rng(72)
+    n = 600
+    sa, xa = rng.choice(CATS, n).tolist(), rng.uniform(0, 24.0, (n, 3))
+    sb, xb = rng.choice(CATS, n).tolist(), rng.uniform(0, 24.0, (n, 3))
+    tags = [f"A/{i // 3}-RES" for i in range(n)]
+    names = sorted(set(tags))
+    pairs = [(names[int(i)], names[int(j)]) for i, j in zip(rng.integers(0, len(names), 4000), rng.integers(0, len(names), 4000))]
+    anchors = [(i, i) for i in range(0, n, 2)]
+    for rule in ({"accept_same": False}, {"accept_same": True},
+                 {"tag_pairs": set(pairs), "accepted_pairs": True, "ordered": False},
+                 {"tag_pairs": set(pairs), "accepted_pairs": False, "ordered": True}):
+        want = score(oracle, sa, xa, sb, xb, anchors, 10.0, wf=("uniform", [3.0, 10.0]), rule=rule, tags_a=tags, tags_b=tags)[0]
+        for g in score(lh, sa, xa, sb, xb, anchors, 10.0, wf=("uniform", [3.0, 10.0]), rule=rule, tags_a=tags, tags_b=tags, repeat=2):
+            assert np.max(np.abs(g - want)) < TIGHT, rule
+
+
+def test_fallback_chain_of_the_environment_kernels(lh, oracle):
+    """Environments of 300 .. 320 points (the small instantiation's limit), 321 .. 512 (small -> regular instantiation),
+    beyond 512 (-> k_env_cells with a larger capacity) and a neighbourhood with more candidate groups than the grouped
+    kernel's table holds although the environment itself is small (-> k_env_cells).  ONE LoCoHD object scores a sparse
+    structure in front of every case, so that each case starts from the small instantiation (a context picks its kernel
+    from what its previous pass saw)."""
+    rng = np.random.default_rng(73)
+    filler = rng.uniform(40.0, 70.0, (300, 3))  # far away from the probe anchor
+    xs = rng.uniform(0.0, 30.0, (500, 3))       # the sparse structure (~40 points per environment); also side B of every case
+    ss = rng.choice(CATS, 500).tolist()
+    sparse_anchors = [(int(i), int(j)) for i, j in zip(rng.integers(0, 500, 100), rng.integers(0, 500, 100))]
+    mods = {}
+    for mod in (lh, oracle):
+        mods[mod] = (mod.LoCoHD(CATS, mod.WeightFunction("hyper_exp", [1.0, 0.1])), prims(mod, ss, xs))
+    for n_in, n_shell in ((310, 0), (330, 0), (500, 0), (520, 0), (700, 0), (120, 2600)):
+        centre = np.array([20.0, 20.0, 20.0])
+        v = rng.normal(size=(n_in, 3))
+        inner = centre + v / np.linalg.norm(v, axis=1)[:, None] * rng.uniform(0.2, 7.9, (n_in, 1))
+        s_ = rng.normal(size=(n_shell, 3))
+        shell = centre + s_ / np.maximum(np.linalg.norm(s_, axis=1)[:, None], 1e-9) * rng.uniform(8.05, 9.5, (n_shell, 1))  # just outside thr = 8
+        xa = np.concatenate([centre[None], inner, shell, filler])
+        sa = rng.choice(CATS, len(xa)).tolist()
+        anchors = [(0, int(j)) for j in rng.integers(0, 500, 40)] + [(int(i), int(j)) for i, j in zip(rng.integers(0, len(xa), 200), rng.integers(0, 500, 200))]
+        res = {}
+        for mod, (lchd, pb) in mods.items():
+            pa = prims(mod, sa, xa)
+            out = []
+            for _ in range(2):  # (the second round starts from the capacity / instantiation the first one ended with)
+                out.append(np.asarray(lchd.from_primitives(pb, pb, sparse_anchors, 8.0)))
+                out.append(np.asarray(lchd.from_primitives(pb, pb, sparse_anchors, 8.0)))
+                out.append(np.asarray(lchd.from_primitives(pa, pb, anchors, 8.0)))
+            res[mod] = out
+        for g, w in zip(res[lh], res[oracle]):
+            assert np.max(np.abs(g - w)) < TIGHT, (n_in, n_shell)
+
+
+def test_grouped_kernel_on_lattices_and_flat_structures(lh, oracle):
+    """Exact distance ties (a cubic lattice: whole shells of equal keys share one sort bucket), a planar and a collinear
+    structure (most of the 5 x 5 x 5 neighbourhood is outside the grid), a structure smaller than one cell."""
+    rng = np.random.default_rng(74)
+    g = np.arange(9, dtype=np.float64) * 1.5
+    lattice = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    planar = np.concatenate([rng.uniform(0, 40, (500, 2)), np.zeros((500, 1))], 1)
+    line = np.stack([np.linspace(0, 90, 400), np.full(400, 3.0), np.full(400, -2.0)], 1)
+    tiny = rng.uniform(0, 1.5, (60, 3))
+    for xa in (lattice, planar, line, tiny):
+        n = len(xa)
+        xb = xa + rng.normal(0, 0.3, xa.shape) if xa is not lattice else xa.copy()
+        sa, sb = rng.choice(CATS, n).tolist(), rng.choice(CATS, n).tolist()
+        anchors = [(int(i), int(j)) for i, j in zip(rng.integers(0, n, 300), rng.integers(0, n, 300))]
+        for thr, wf in ((6.0, ("uniform", [1.0, 6.0])), (4.0, ("dagum", [2.5, 3.0, 1.2]))):
+            want = score(oracle, sa, xa, sb, xb, anchors, thr, wf=wf)[0]
+            for got in score(lh, sa, xa, sb, xb, anchors, thr, wf=wf, repeat=2):
+                assert np.max(np.abs(got - want)) < TIGHT
