@@ -162,13 +162,18 @@ def profile_numbers(workload: str):
         return None
 
 
-def roofline_block(workload: str, kernel: str, algo_bytes: float, launch_ms: float, launches_per_step: int = 1):
+def roofline_block(workload: str, kernel: str, algo_bytes: float, launch_ms: float, launches_per_step: int = 1, step_ms: float = 0.0):
     achieved = algo_bytes / max(launch_ms, 1e-9) / 1e6  # GB/s
-    block = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+    block = {"bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
              "traffic": None, "kernel": kernel, "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": launch_ms,
              "launches_per_step": launches_per_step,
-             "note": "frac = ALGORITHMIC bytes (SURVEY.md 8d) / live kernel time / 8 TB/s; the kernels of this path are VALU-issue "
-                     "bound, not bandwidth bound: see hbm_measured_frac and valu_issue_frac"}
+             "note": "achieved / peak / frac = ALGORITHMIC bytes (SURVEY.md 8d) of the dominant kernel / its live launch time against the "
+                     "8 TB/s HBM peak, as section 8d defines the figure; frac_step = the algorithmic bytes of the WHOLE step / ms_per_step / "
+                     "peak (what the byte model actually covers: points in, score out).  What binds the kernels of this path is VALU "
+                     "issue, not bandwidth (`bound`): valu_issue_frac = SQ_ACTIVE_INST_VALU x 4 cycles / 1024 SIMDs / kernel cycles, "
+                     "hbm_measured_frac = PMC traffic / time / peak"}
+    if step_ms > 0.0:
+        block["frac_step"] = algo_bytes * launches_per_step / (step_ms * 1e-3) / (HBM_PEAK_GBS * 1e9)
     prof = profile_numbers(workload)
     if prof and prof.get("kernel") and prof["kernel"].split("<")[0] in kernel:
         block["traffic"] = prof.get("traffic_bytes_per_launch")
@@ -216,7 +221,12 @@ def cpu_baseline(w, gpu_scores: np.ndarray, budget_s: float = 12.0):
     m = int(min(len(w["pairs"]), max(10_000, rate * budget_s)))
     ref, dt = run(m)
     err = float(np.max(np.abs(ref - gpu_scores[:m])))
-    return {"value": m / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+    one = orc.LoCoHD([f"c{i}" for i in range(w["C"])], orc.WeightFunction(*w["wf"]), n_of_threads=1)
+    m1 = int(min(len(w["pairs"]), max(2_000, rate / cores * 3.0)))  # ~3 s on one core
+    t0 = time.perf_counter()
+    one.from_arrays(w["xyz_a"], w["cat_a"], tag, w["xyz_b"], w["cat_b"], tag, w["pairs"][:m1], w["thr"])
+    dt1 = time.perf_counter() - t0
+    return {"value": m / dt, "unit": "pairs/s", "cores": cores, "kind": "port", "value_1thread": m1 / dt1,
             "sample": f"first {m} anchor pairs of the same workload, {dt:.1f} s, C oracle (oracle/locohd_oracle.c) with "
                       f"{cores} pthreads over anchor pairs; reference Rust core not buildable in this image"}, err, m
 
@@ -264,7 +274,7 @@ def base_result(args, world, total_pairs, elapsed, label, extra_cfg):
         "metric": "anchor-pair LoCoHD scores/sec", "value": total_pairs * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": label, "setup_passes_before_warmup": PRIME_STEPS, **extra_cfg},
+        "config": {"workload": label, "setup_passes_before_warmup": PRIME_STEPS, "streams": getattr(args, "streams", 1), **extra_cfg},
     }
 
 
@@ -369,8 +379,8 @@ def run_c4(args, torch, dist, dev, rank, world, use_dist):
                  f"chunks of {chunk} frames")
         result = base_result(args, world, p * world, elapsed, label, {"pairs_per_gpu": p, "mean_env_points_per_pair": env_points[0] / p,
                                                                       "sharding": "frames across ranks, no exchange step, scores stay on their rank"})
-        result["roofline"] = roofline_block("c4", {"env": "k_env_cells (side A + side B)", "sweep": "k_sweep_duo"}[dom], algo / len(starts),
-                                            phase[dom] / len(starts), len(starts))
+        result["roofline"] = roofline_block("c4", {"env": "k_env_group (side A + side B)", "sweep": "k_sweep_duo"}[dom], algo / len(starts),
+                                            phase[dom] / len(starts), len(starts), step_ms=result["ms_per_step"])
         result["kernel_ms"] = phase
         result["extras"] = {"k_frames_centroids": {"ms_per_step": phase["convert"], "algorithmic_bytes_per_step": conv_bytes,
                                                    "GB_per_s": conv_bytes / max(phase["convert"], 1e-9) / 1e6,
@@ -412,22 +422,32 @@ def run_c3(args, torch, dist, dev, rank, world, use_dist):
     strong = args.scaling == "strong"
     w = make_c3(rank, same_on_all_ranks=strong)
     lchd = lh.LoCoHD(w["types"], lh.WeightFunction("uniform", [3.0, 10.0]), lh.TagPairingRule({"accept_same": False}))
-    # two sessions take the steps in turn (see run_pairs): the host never sleeps in a wait while the GPU has nothing queued
-    sessions = [DeviceSession(lchd, device=dev.index) for _ in range(2)]
+    # two sessions take the steps in turn, on two streams with --streams 2 (see run_pairs)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)] if args.streams == 2 else [torch.cuda.current_stream(dev)] * 2
+    sessions = []
+    for st_ in streams:
+        with torch.cuda.stream(st_):
+            sessions.append(DeviceSession(lchd, device=dev.index))
     sess = sessions[0]
-    batches = []
     for s_ in sessions:
         s_.enable_timing(True)
-        b_, offs = s_.upload_batch(w["decoys"])
-        batches.append(b_)
-    batch = batches[0]
     la = np.arange(0, w["n"], 3)
     emu = args.emulate_world if (strong and args.emulate_world > 1 and world == 1) else 0
     shares = tile_structure_pairs(w["nd"], emu or world) if strong else [w["spairs"]]
     out_holder, phases_holder = {}, {}
 
     def run_share(my_spairs, tag):
-        pairs = np.concatenate([np.stack([offs[a] + la, offs[b] + la], 1) for a, b in my_spairs]) if my_spairs else np.zeros((0, 2), np.int64)
+        # A rank holds only the decoys its share of decoy pairs touches (strong scaling: 25 of the 50 at 8 ranks), as one batch
+        # per session; `local` maps a decoy to its position in that batch.
+        touched = sorted({d for ab in my_spairs for d in ab})
+        local = {d: i for i, d in enumerate(touched)}
+        batches, offs = [], None
+        for s_ in sessions:
+            if touched:
+                b_, offs = s_.upload_batch([w["decoys"][d] for d in touched])
+                batches.append(b_)
+        pairs = (np.concatenate([np.stack([offs[local[a]] + la, offs[local[b]] + la], 1) for a, b in my_spairs])
+                 if my_spairs else np.zeros((0, 2), np.int64))
         anchors = torch.from_numpy(np.ascontiguousarray(pairs)).to(dev)
         p = anchors.shape[0]
         outs = [torch.empty(max(p, 1), dtype=torch.float64, device=dev) for _ in range(2)]
@@ -438,6 +458,7 @@ def run_c3(args, torch, dist, dev, rank, world, use_dist):
         pending, in_flight, counter = [None, None], [False, False], [0]
         phase_ms = {"cells": 0.0, "anchors": 0.0, "env": 0.0, "sweep": 0.0}
         collect = [False]
+        torch.cuda.synchronize()
 
         def finish(k):
             if in_flight[k]:
@@ -450,30 +471,32 @@ def run_c3(args, torch, dist, dev, rank, world, use_dist):
         def step():
             k = counter[0] % 2
             counter[0] += 1
-            finish(k)
-            if pending[k] is not None:
-                pending[k].wait()
-                pending[k] = None
-            if p:
-                sessions[k].from_primitives_async(batches[k], batches[k], anchors, w["thr"], outs[k])
-                in_flight[k] = True
-            if use_dist and args.gather == "step":
-                pads[k][:p].copy_(outs[k][:p])
-                pending[k] = gather_scores(pads[k], gathered[k], world, rank, force_collective=True, async_op=True)
-
-        def drain():
-            for k in range(2):
+            with torch.cuda.stream(streams[k]):
                 finish(k)
                 if pending[k] is not None:
                     pending[k].wait()
                     pending[k] = None
+                if p:
+                    sessions[k].from_primitives_async(batches[k], batches[k], anchors, w["thr"], outs[k])
+                    in_flight[k] = True
+                if use_dist and args.gather == "step":
+                    pads[k][:p].copy_(outs[k][:p])
+                    pending[k] = gather_scores(pads[k], gathered[k], world, rank, force_collective=True, async_op=True)
+
+        def drain():
+            for k in range(2):
+                with torch.cuda.stream(streams[k]):
+                    finish(k)
+                    if pending[k] is not None:
+                        pending[k].wait()
+                        pending[k] = None
 
         def start_collect():
             collect[0] = True
 
         elapsed = Harness(args, torch, dist, dev, use_dist).run(step, drain, start_collect)
         collect[0] = False
-        out_holder[tag] = (outs[(counter[0] - 1) % 2][:p], pairs, p)
+        out_holder[tag] = (outs[(counter[0] - 1) % 2][:p], pairs, p, batches[0] if batches else None, len(touched))
         phases_holder[tag] = {k: v / max(args.steps, 1) for k, v in phase_ms.items()}
         return elapsed
 
@@ -488,7 +511,7 @@ def run_c3(args, torch, dist, dev, rank, world, use_dist):
         strong = False  # the reference step of the estimate: the whole job on this GPU
     my = shares[rank] if strong else w["spairs"]
     elapsed = run_share(my, "main")
-    out, pairs, p = out_holder["main"]
+    out, pairs, p, batch, n_touched = out_holder["main"]
     phase_ms = phases_holder["main"]
     total_pairs = len(w["spairs"]) * len(la) * (1 if args.scaling == "strong" else world)
     result = None
@@ -500,14 +523,16 @@ def run_c3(args, torch, dist, dev, rank, world, use_dist):
         dom = max(("env", "sweep"), key=lambda k: phase_ms[k])
         result = base_result(args, world, total_pairs, elapsed, w["label"],
                              {"pairs_this_rank": p, "mean_env_points_per_pair": env_points / max(p, 1),
-                              "sharding": ("tiles of the 50 x 50 decoy-pair matrix, one set per rank; every rank holds all decoys"
+                              "sharding": (f"tiles of the 50 x 50 decoy-pair matrix, one set per rank; a rank holds the decoys its tiles touch ({n_touched} here)"
                                            if args.scaling == "strong" else "every rank scores its own all-vs-all job"),
                               **collective_note(args, world, use_dist)})
-        result["roofline"] = roofline_block("c3", {"env": "k_env_cells", "sweep": "k_sweep_duo<8>"}[dom], algo, phase_ms[dom])
+        result["roofline"] = roofline_block("c3", {"env": "k_env_group", "sweep": "k_sweep_duo<8>"}[dom], algo, phase_ms[dom], step_ms=result["ms_per_step"])
         result["kernel_ms"] = phase_ms
         if emulated:
             emulated["single_gpu_ms"] = elapsed / args.steps * 1e3
             emulated["estimated_speedup_without_collective"] = emulated["single_gpu_ms"] / max(emulated["per_rank_ms"])
+            emulated["estimated_speedup_median_rank"] = emulated["single_gpu_ms"] / float(np.median(emulated["per_rank_ms"]))
+            emulated["note"] = "the W ranks' shares timed one after the other on ONE GPU, no collective: an estimate, not a measurement on W GPUs"
             result["extras"] = {"emulated_strong_scaling": emulated}
         if not args.no_cpu_baseline and world == 1:
             from oracle import oracle as orc  # checker / baseline only
@@ -572,7 +597,7 @@ def run_c2b(args, torch, dist, dev, rank, world, use_dist):
         result = base_result(args, world, n * world, elapsed, w["label"], {"pairs_per_gpu": n, "mean_env_points_per_pair": 2 * n,
                                                                            "sharding": "replicas only (one from_coords call per rank)"})
         result["scaling"] = "weak"
-        result["roofline"] = roofline_block("c2b" if n == 10_000 else f"c2b_{n}", {"env": "k_env_rows2 (both structures' rows in one launch)", "sweep": "k_sweep"}[dom], algo, phase_ms[dom])
+        result["roofline"] = roofline_block("c2b" if n == 10_000 else f"c2b_{n}", {"env": "k_env_rows2 (both structures' rows in one launch)", "sweep": "k_sweep"}[dom], algo, phase_ms[dom], step_ms=result["ms_per_step"])
         result["kernel_ms"] = phase_ms
         if not args.no_cpu_baseline and world == 1:
             from oracle import oracle as orc  # checker / baseline only
@@ -617,9 +642,18 @@ def run_pairs(args, torch, dist, dev, rank, world, use_dist):
     # Two sessions (contexts with their own workspace) take the steps in turn: step k+1 is enqueued while step k still runs, so
     # the GPU does not idle during the status hand-over and the host's launch work of a step (a step is still one complete
     # pass; both sessions enqueue on the same stream, so the passes themselves run one after the other).
-    sessions = [DeviceSession(lchd, device=dev.index) for _ in range(2)]
+    # --streams 2 (default for N > 1): each session enqueues on a stream of its own, so the kernels of step k+1 fill the launch
+    # gaps and the tail of step k (independent passes; every pass and every collective of the timed steps still completes inside
+    # the timed region).  --streams 1 (default at N = 1): both sessions share one stream, the passes run strictly one after the
+    # other and the per-kernel event times are those of the kernels alone (the roofline figures need that).
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)] if args.streams == 2 else [torch.cuda.current_stream(dev)] * 2
+    sessions = []
+    for st_ in streams:
+        with torch.cuda.stream(st_):
+            sessions.append(DeviceSession(lchd, device=dev.index))  # (binds the session to the current stream)
     sess = sessions[0]
     clouds = [(s_.upload(w["xyz_a"], w["cat_a"]), s_.upload(w["xyz_b"], w["cat_b"])) for s_ in sessions]
+    torch.cuda.synchronize()
     cloud_a, cloud_b = clouds[0]
     anchors = torch.from_numpy(w["pairs"]).to(dev)
     p = anchors.shape[0]
@@ -643,6 +677,7 @@ def run_pairs(args, torch, dist, dev, rank, world, use_dist):
         else:
             outs = [torch.empty(p, dtype=torch.float64, device=dev) for _ in range(2)]
             gathered = [torch.empty(p * vworld, dtype=torch.float64, device=dev) if (collective and rank == 0) else None for _ in range(2)]
+        torch.cuda.synchronize()  # (the buffers above were filled on the default stream; the steps run on the sessions' streams)
 
         def finish(k):  # wait for the pass enqueued on session k (raises on a device-side error), book its kernel times
             if in_flight[k]:
@@ -662,6 +697,10 @@ def run_pairs(args, torch, dist, dev, rank, world, use_dist):
         def step():
             k = counter[0] % 2
             counter[0] += 1
+            with torch.cuda.stream(streams[k]):
+                step_on(k)
+
+        def step_on(k):
             finish(k)  # the session's previous pass (two steps ago) and its buffers
             wait_gather(k)
             if strong:
@@ -670,11 +709,11 @@ def run_pairs(args, torch, dist, dev, rank, world, use_dist):
                 import ctypes as C
 
                 counts = (C.c_int64 * vworld)()
-                N.check(N.lib().lchd_shard_plan_dev(sessions[k]._ctx, C.c_void_p(anchors.data_ptr()), p, w["n"], vworld, counts))
+                N.check(N.lib().lchd_shard_plan_dev(sessions[k]._ctx, C.c_void_p(anchors.data_ptr()), p, w["n"], w["n"], vworld, counts))
                 counts = [int(v) for v in counts]
                 n_mine = counts[vrank]
                 assert n_mine <= slot, (n_mine, slot)
-                N.check(N.lib().lchd_shard_select_dev(sessions[k]._ctx, C.c_void_p(anchors.data_ptr()), p, w["n"], vrank,
+                N.check(N.lib().lchd_shard_select_dev(sessions[k]._ctx, C.c_void_p(anchors.data_ptr()), p, w["n"], w["n"], vrank,
                                                       C.c_void_p(sels[k].data_ptr()), C.c_void_p(locals_[k][1].data_ptr())))
                 if collect[0]:
                     phase_ms["shard"] += (time.perf_counter() - t0) * 1e3
@@ -692,8 +731,9 @@ def run_pairs(args, torch, dist, dev, rank, world, use_dist):
 
         def drain():
             for k in range(2):
-                finish(k)
-                wait_gather(k)
+                with torch.cuda.stream(streams[k]):
+                    finish(k)
+                    wait_gather(k)
 
         def start_collect():
             collect[0] = True
@@ -725,6 +765,8 @@ def run_pairs(args, torch, dist, dev, rank, world, use_dist):
     if emulated:
         emulated["single_gpu_ms"] = elapsed / args.steps * 1e3
         emulated["estimated_speedup_without_collective"] = emulated["single_gpu_ms"] / max(emulated["per_rank_ms"])
+        emulated["estimated_speedup_median_rank"] = emulated["single_gpu_ms"] / float(np.median(emulated["per_rank_ms"]))
+        emulated["note"] = "the W ranks' shares timed one after the other on ONE GPU, no collective: an estimate, not a measurement on W GPUs"
         extras["emulated_strong_scaling"] = emulated
     if rank == 0 and args.workload == "c2a" and not args.no_cpu_baseline and not strong:  # profiling runs launch only the timed steps
         n_atoms = w["n"]
@@ -740,10 +782,24 @@ def run_pairs(args, torch, dist, dev, rank, world, use_dist):
         tu = (time.perf_counter() - tu) / 20
         extras["unique_anchor_call"] = {"pairs": int(n_atoms), "ms_per_call": tu * 1e3, "pairs_per_s": n_atoms / tu,
                                         "note": "every anchor used once: no environment re-use between pairs"}
+    value_incl = None
+    if rank == 0 and not args.no_cpu_baseline and not strong:
+        # the same job through the host-pointer entry point (lchd_from_primitives: packing into the pinned
+        # staging block + ONE H2D copy of structures and pairs + the pass + ONE D2H copy of the scores, all inside the call)
+        pa = lh.api._Packed(w["xyz_a"], w["cat_a"], np.zeros(w["n"], np.int32))
+        pb = lh.api._Packed(w["xyz_b"], w["cat_b"], np.zeros(w["n"], np.int32))
+        host_scores = lchd.from_packed(pa, pb, w["pairs"], w["thr"])  # (first call: the context's staging block grows)
+        th = time.perf_counter()
+        for _ in range(3):
+            host_scores = lchd.from_packed(pa, pb, w["pairs"], w["thr"])
+        th = (time.perf_counter() - th) / 3
+        value_incl = {"value": p / th, "unit": "pairs/s", "ms_per_call": th * 1e3,
+                      "what": "LoCoHD.from_packed on host arrays: staging + H2D of both structures and the pair list + pass + D2H of the scores"}
+        extras["host_call_scores_equal_device_resident"] = None  # filled below
     # environment points of this rank's pairs (algorithmic bytes), and the scores to check
     if strong:
         n_mine = state["main_n_mine"]
-        sel, idx, _ = select_shard(anchors, w["n"], world, rank, session=sess)
+        sel, idx, _ = select_shard(anchors, w["n"], world, rank, session=sess, n_atoms_b=w["n"])
         check = torch.empty(n_mine, dtype=torch.float64, device=dev)
         sess.from_primitives(cloud_a, cloud_b, sel, w["thr"], out=check)
         env_points = sess.last_env_points()
@@ -766,7 +822,7 @@ def run_pairs(args, torch, dist, dev, rank, world, use_dist):
     if rank == 0:
         algo_bytes = env_points * 28 + 16 * pairs_this_rank  # B_pair = (n_A + n_B) * 28 B + 8 B + 8 B
         dom = max(("env", "sweep"), key=lambda k: phase_ms[k])
-        dom_name = {"env": "k_env_cells (side A + side B in one launch)",
+        dom_name = {"env": "k_env_group (side A + side B in one launch)",
                     "sweep": "k_sweep (its launch and the k_pair_meta record pass in front of it)"}[dom]
         result = base_result(args, world, total_pairs, elapsed, w["label"],
                              {"pairs_total" if strong else "pairs_per_gpu": p, "pairs_this_rank": pairs_this_rank,
@@ -774,9 +830,12 @@ def run_pairs(args, torch, dist, dev, rank, world, use_dist):
                               "sharding": ("pairs binned by their side-A anchor (library kernels, every rank the same rule), every rank holds both structures"
                                            if strong else "every rank scores its own pair list of the same two structures"),
                               **collective_note(args, world, use_dist)})
-        result["roofline"] = roofline_block(args.workload, dom_name, algo_bytes, phase_ms[dom])
+        result["roofline"] = roofline_block(args.workload, dom_name, algo_bytes, phase_ms[dom], step_ms=result["ms_per_step"])
         result["kernel_ms"] = phase_ms
         result["extras"] = extras
+        if value_incl is not None:
+            result["value_incl_h2d_d2h"] = value_incl
+            extras["host_call_scores_equal_device_resident"] = bool(scores is not None and np.array_equal(host_scores, scores))
         if not args.no_cpu_baseline and world == 1 and scores is not None:  # the CPU leg (and the parity gate on its sample) runs at N = 1 only
             base, err, m = cpu_baseline(w, scores)
             result["cpu_baseline"] = base
@@ -812,8 +871,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2a", choices=["c2a", "c2b", "c3", "c4", "c5"])
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="multi-GPU: weak = the named workload per GPU, strong = the named workload in total, sharded across the GPUs")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="multi-GPU: strong (default for --gpus N > 1: BASELINE.json's 8-GPU configurations are fixed-size jobs and its target "
+                         "is '>= 6x at 8 GPUs') = the named workload in total, sharded across the GPUs; weak = the named workload per GPU")
     ap.add_argument("--frames", type=int, default=5000, help="c4: frames of the trajectory")
     ap.add_argument("--chunk", type=int, default=1250, help="c4: frames per scoring pass")
     ap.add_argument("--pairs", type=int, default=1_000_000, help="c2a / c5: anchor pairs (per GPU when weak, in total when strong)")
@@ -821,10 +881,17 @@ def main():
                     help="multi-GPU: RCCL gather of the scores to rank 0 inside every timed step (default for N > 1) or once behind the timed region")
     ap.add_argument("--emulate-world", type=int, default=0, help="one GPU, --scaling strong: time every rank's share of a W-GPU job in turn")
     ap.add_argument("--dense-atoms", type=int, default=10_000, help="c2b: atoms per structure (= anchor pairs; the environment is the whole structure)")
+    ap.add_argument("--streams", type=int, default=None, choices=[1, 2],
+                    help="c2a / c5 / c3: HIP streams the two alternating sessions enqueue on (default: 1 at N = 1 -- clean per-kernel times --, "
+                         "2 for N > 1 and --emulate-world: consecutive steps overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg, the parity gate and the extras (profiling runs)")
     args = ap.parse_args()
     if args.gather is None:
         args.gather = "step"
+    if args.streams is None:
+        args.streams = 2 if (args.gpus > 1 or args.emulate_world > 1) else 1
+    if args.scaling is None:  # c2b has no sharding (one from_coords call): replicas only
+        args.scaling = "strong" if (args.gpus > 1 or args.emulate_world > 1) and args.workload != "c2b" else "weak"
 
     import torch
     import torch.distributed as dist

@@ -211,16 +211,20 @@ int lchd_group_last_counts(const lchd_group *group, int64_t *counts_out);
 /* One process per GPU (torch.distributed / MPI style): every rank holds the whole pair list on its device and runs the
  * SAME deterministic partition (a pure function of the list, so no communication is needed to agree on it):
  *   bin(p) = floor(anchor_a(p) * 1024 / n_atoms_a),  rank(bin) = min(world - 1, floor(#pairs in lower bins * world / n_pairs)).
+ * A list whose side-A partition is unbalanced (a rank would hold more than 1.25 n_pairs / world + 1 pairs: ONE reference anchor
+ * against thousands, /root/reference/python_codes/kras_scan.py:46-52) is binned by its side-B anchors instead (n_atoms_b > 0),
+ * and if that partition is unbalanced too (or n_atoms_b <= 0) cut into contiguous slices, rank(p) = floor(p * world / n_pairs):
+ * the reference's par_iter balances any list (src/locohd.rs:545-557), so must this.
  * lchd_shard_plan_dev computes it (one kernel on a side stream of the context + a wait for that kernel only: the pair list
  * must be complete in device memory when it is called) and returns the pair count of every rank;
  * lchd_shard_select_dev compacts THIS rank's pairs (d_sel_anchors [counts[rank]][2], d_sel_index [counts[rank]] = their
  * positions in the full list; enqueued on the context's stream, no wait);
  * lchd_unshard_scores_dev, on the gathering rank, puts score k of rank r at its pair's original position:
  * d_gathered is [world][2][stride] doubles -- rank r's scores, then its d_sel_index reinterpreted as doubles. */
-int lchd_shard_plan_dev(lchd_ctx *ctx, const int64_t *d_anchors, int64_t n_pairs, int64_t n_atoms_a, int32_t world,
-                        int64_t *counts_out);
-int lchd_shard_select_dev(lchd_ctx *ctx, const int64_t *d_anchors, int64_t n_pairs, int64_t n_atoms_a, int32_t rank,
-                          int64_t *d_sel_anchors, int64_t *d_sel_index);
+int lchd_shard_plan_dev(lchd_ctx *ctx, const int64_t *d_anchors, int64_t n_pairs, int64_t n_atoms_a, int64_t n_atoms_b,
+                        int32_t world, int64_t *counts_out);
+int lchd_shard_select_dev(lchd_ctx *ctx, const int64_t *d_anchors, int64_t n_pairs, int64_t n_atoms_a, int64_t n_atoms_b,
+                          int32_t rank, int64_t *d_sel_anchors, int64_t *d_sel_index);
 int lchd_unshard_scores_dev(lchd_ctx *ctx, const double *d_gathered, const int64_t *counts, int32_t world, int64_t stride,
                             double *d_out, int64_t n_pairs);
 

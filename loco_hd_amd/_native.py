@@ -90,8 +90,8 @@ _PROTOS = {
     "lchd_group_size": (_i32, [_VP]),
     "lchd_group_from_primitives": (C.c_int, [_VP, C.POINTER(ConfigC), _DP, _IP, _IP, _i64, _DP, _IP, _IP, _i64, _LP, _IP, _i64, _f64, _DP]),
     "lchd_group_last_counts": (C.c_int, [_VP, _LP]),
-    "lchd_shard_plan_dev": (C.c_int, [_VP, _VP, _i64, _i64, _i32, _LP]),
-    "lchd_shard_select_dev": (C.c_int, [_VP, _VP, _i64, _i64, _i32, _VP, _VP]),
+    "lchd_shard_plan_dev": (C.c_int, [_VP, _VP, _i64, _i64, _i64, _i32, _LP]),
+    "lchd_shard_select_dev": (C.c_int, [_VP, _VP, _i64, _i64, _i64, _i32, _VP, _VP]),
     "lchd_unshard_scores_dev": (C.c_int, [_VP, _VP, _LP, _i32, _i64, _VP, _i64]),
     "lchd_ctx_enable_timing": (C.c_int, [_VP, _i32]),
     "lchd_ctx_last_ms": (C.c_double, [_VP, C.c_char_p]),

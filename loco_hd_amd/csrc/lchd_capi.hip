@@ -200,6 +200,7 @@ struct lchd_ctx {
         double* out = nullptr;
         int cap = 0;
         bool group = false, group_small = false;  // which environment kernel the enqueued pass uses
+        int sweep_info = 0;                        // launch_sweep's return value
         SweepArgs sw{};
     } pend;
     // multi-GPU sharding helpers (lchd_shard_*): device state, host-mapped counts, the plan they belong to
@@ -211,7 +212,7 @@ struct lchd_ctx {
     int64_t* h_counts = nullptr;
     uint32_t* d_bad = nullptr;
     int shard_world = 0;
-    int64_t shard_pairs = 0, shard_atoms = 0;
+    int64_t shard_pairs = 0, shard_atoms = 0, shard_atoms_b = 0;
     // most recent sweep (for lchd_ctx_last_env_points)
     SweepArgs last{};
     bool last_valid = false;
@@ -917,7 +918,7 @@ static int prims_enqueue(lchd_ctx* c) {
     sw.n_pairs = n_pairs;
     sw.out = P.out;
     sw.meta = pb.pair_meta;
-    launch_sweep(s, c->tune, c->h_cfg.n_categories, c->hellinger2, c->unit_weights, c->wf_pow, c->sweep_hint, sw);
+    P.sweep_info = launch_sweep(s, c->tune, c->h_cfg.n_categories, c->hellinger2, c->unit_weights, c->wf_pow, c->sweep_hint, sw);
     mark(c, 4);
     if (a->ev_used) { HIP_TRY(hipEventRecord(a->ev_used, s)); a->used_valid = true; }
     if (b->ev_used) { HIP_TRY(hipEventRecord(b->ev_used, s)); b->used_valid = true; }
@@ -984,10 +985,20 @@ extern "C" int lchd_ctx_finish(lchd_ctx* c) {
         } else {
             c->shrink_votes = 0;
         }
+        if ((P.sweep_info & 2) && c->h_status->n_small != ~0ull) {
+            // the companion sweep for the larger pairs was left out because the previous pass had none: did this one?
+            const unsigned long long taken = (P.sweep_info & 1) ? c->h_status->n_c8 : c->h_status->n_duo;
+            if (taken < (unsigned long long)P.n_pairs) {
+                c->sweep_hint &= ~(8 | 16);
+                if (int rc = prims_enqueue(c)) return rc;
+                continue;
+            }
+        }
         if (biggest > 0) { c->group_small = biggest <= kEnvGroupSmallUpTo; c->last_biggest = biggest; }
         if (c->h_status->n_small != ~0ull)  // what the pairs looked like this time picks the sweep kernels of the next pass of this configuration
             c->sweep_hint = 4 | (2 * c->h_status->n_duo >= (unsigned long long)P.n_pairs ? 1 : 0) |
-                            (2 * c->h_status->n_c8 >= (unsigned long long)P.n_pairs ? 2 : 0);
+                            (2 * c->h_status->n_c8 >= (unsigned long long)P.n_pairs ? 2 : 0) |
+                            (c->h_status->n_duo == (unsigned long long)P.n_pairs ? 8 : 0) | (c->h_status->n_c8 == (unsigned long long)P.n_pairs ? 16 : 0);
         c->last = P.sw;
         c->last_valid = true;
         return status_to_rc(f, DRV_PRIMS);
@@ -1361,17 +1372,30 @@ extern "C" int lchd_from_primitives(lchd_ctx* c, const lchd_config* cfg, const d
 // ------------------------------------------------------------------------------------------------
 // Sharding of an anchor-pair list by side-A anchor: the rule of lchd_kernels.hip (k_shard_plan), on the host
 // ------------------------------------------------------------------------------------------------
-static void shard_rule_host(const int64_t* anchors, int64_t n_pairs, int64_t n_atoms_a, int world, std::vector<uint16_t>& rank_of_bin) {
-    std::vector<uint64_t> hist(kShardBins, 0);
-    auto bin_of = [&](int64_t a) { a = a < 0 ? 0 : (a >= n_atoms_a ? n_atoms_a - 1 : a); return (int)((a * kShardBins) / n_atoms_a); };
-    for (int64_t p = 0; p < n_pairs; ++p) ++hist[bin_of(anchors[2 * p])];
-    rank_of_bin.assign(kShardBins, 0);
-    uint64_t pre = 0;
-    for (int b = 0; b < kShardBins; ++b) {
-        const uint64_t r = n_pairs > 0 ? (pre * (uint64_t)world) / (uint64_t)n_pairs : 0;
-        rank_of_bin[b] = (uint16_t)std::min<uint64_t>(r, (uint64_t)world - 1);
-        pre += hist[b];
+// key side 0: bins of the side-A anchor; 1: of the side-B anchor (side A's partition is unbalanced: a rank would hold more than
+// 1.25 P / world + 1 pairs -- one reference anchor against thousands, python_codes/kras_scan.py:46-52); 2: contiguous slices
+static int shard_rule_host(const int64_t* anchors, int64_t n_pairs, int64_t n_atoms_a, int64_t n_atoms_b, int world, std::vector<uint16_t>& rank_of_bin) {
+    auto bin_of = [](int64_t a, int64_t n) { a = a < 0 ? 0 : (a >= n ? n - 1 : a); return (int)((a * kShardBins) / n); };
+    std::vector<uint64_t> ha(kShardBins, 0), hb(kShardBins, 0);
+    for (int64_t p = 0; p < n_pairs; ++p) {
+        ++ha[bin_of(anchors[2 * p], n_atoms_a)];
+        if (n_atoms_b > 0) ++hb[bin_of(anchors[2 * p + 1], n_atoms_b)];
     }
+    auto plan_side = [&](const std::vector<uint64_t>& hist) {  // fills rank_of_bin; true: balanced
+        std::vector<uint64_t> cnt((size_t)world, 0);
+        rank_of_bin.assign(kShardBins, 0);
+        uint64_t pre = 0;
+        for (int b = 0; b < kShardBins; ++b) {
+            const uint64_t r = std::min<uint64_t>(n_pairs > 0 ? (pre * (uint64_t)world) / (uint64_t)n_pairs : 0, (uint64_t)world - 1);
+            rank_of_bin[b] = (uint16_t)r;
+            cnt[r] += hist[b];
+            pre += hist[b];
+        }
+        return *std::max_element(cnt.begin(), cnt.end()) * 4ull * (uint64_t)world <= 5ull * (uint64_t)n_pairs + 4ull * (uint64_t)world;
+    };
+    if (plan_side(ha)) return 0;
+    if (n_atoms_b > 0 && plan_side(hb)) return 1;
+    return 2;
 }
 
 struct lchd_group {
@@ -1418,19 +1442,21 @@ extern "C" int lchd_group_from_primitives(lchd_group* g, const lchd_config* cfg,
             if (int rc = lchd_ctx_set_config(c, cfg)) return rc;  // the reference validates its arguments even for an empty list
         return LCHD_OK;
     }
-    // the pair list, binned by side-A anchor: device r gets the positions subset[r]
+    // the pair list, binned by anchor (the rule of k_shard_plan): device r gets the positions subset[r]
     std::vector<std::vector<int64_t>> subset((size_t)world);
     if (world == 1 || n_a <= 0) {
         subset[0].resize((size_t)n_pairs);
         for (int64_t p = 0; p < n_pairs; ++p) subset[0][(size_t)p] = p;
     } else {
         std::vector<uint16_t> rob;
-        shard_rule_host(anchors, n_pairs, n_a, world, rob);
+        const int mode = shard_rule_host(anchors, n_pairs, n_a, n_b, world, rob);
         for (int r = 0; r < world; ++r) subset[(size_t)r].reserve((size_t)(n_pairs / world + n_pairs / (4 * world) + 16));
         for (int64_t p = 0; p < n_pairs; ++p) {
-            int64_t a = anchors[2 * p];
-            a = a < 0 ? 0 : (a >= n_a ? n_a - 1 : a);
-            subset[rob[(size_t)((a * kShardBins) / n_a)]].push_back(p);
+            if (mode == 2) { subset[(size_t)((p * world) / n_pairs)].push_back(p); continue; }
+            const int64_t n = mode == 1 ? n_b : n_a;
+            int64_t a = anchors[2 * p + (mode == 1 ? 1 : 0)];
+            a = a < 0 ? 0 : (a >= n ? n - 1 : a);
+            subset[rob[(size_t)((a * kShardBins) / n)]].push_back(p);
         }
     }
     // enqueue every device's pass (asynchronous), then collect: the devices work concurrently
@@ -1461,7 +1487,7 @@ static int ensure_shard_state(lchd_ctx* c) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->shard_sel_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(&c->d_shard, sizeof(ShardState));
     if (e == hipSuccess) e = hipMemsetAsync(c->d_shard, 0, sizeof(ShardState), c->shard_stream);
-    if (e == hipSuccess) e = hipHostMalloc(&c->h_counts, sizeof(int64_t) * kShardMaxWorld);
+    if (e == hipSuccess) e = hipHostMalloc(&c->h_counts, sizeof(int64_t) * (kShardMaxWorld + 1));
     if (e == hipSuccess) e = hipMalloc(&c->d_bad, sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemsetAsync(c->d_bad, 0, sizeof(uint32_t), c->shard_stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->shard_stream);
@@ -1476,40 +1502,41 @@ static int ensure_shard_state(lchd_ctx* c) {
     }
     return LCHD_OK;
 }
-extern "C" int lchd_shard_plan_dev(lchd_ctx* c, const int64_t* d_anchors, int64_t n_pairs, int64_t n_atoms_a, int32_t world, int64_t* counts_out) {
+extern "C" int lchd_shard_plan_dev(lchd_ctx* c, const int64_t* d_anchors, int64_t n_pairs, int64_t n_atoms_a, int64_t n_atoms_b, int32_t world,
+                                   int64_t* counts_out) {
     if (!c || !counts_out) return fail(LCHD_EVALUE, "null argument");
     if (world < 1 || world > kShardMaxWorld) return fail(LCHD_EVALUE, "world size %d outside [1, %d]", world, kShardMaxWorld);
     if (n_pairs < 0 || n_atoms_a < 1) return fail(LCHD_EVALUE, "bad pair / atom count");
     for (int r = 0; r < world; ++r) counts_out[r] = 0;
     c->shard_world = 0;
-    if (n_pairs == 0) { c->shard_world = world; c->shard_pairs = 0; c->shard_atoms = n_atoms_a; return LCHD_OK; }
+    if (n_pairs == 0) { c->shard_world = world; c->shard_pairs = 0; c->shard_atoms = n_atoms_a; c->shard_atoms_b = n_atoms_b; return LCHD_OK; }
     if (!d_anchors) return fail(LCHD_EVALUE, "null anchor pointer");
     CTX_GUARD(c);
     if (int rc = ensure_shard_state(c)) return rc;
     // On the context's side stream: the pair list is an INPUT (the caller has it ready), so the plan neither waits for the
     // scoring passes queued on the context's stream nor makes the host wait for them.
     if (c->shard_sel_pending) { HIP_TRY(hipStreamWaitEvent(c->shard_stream, c->shard_sel_ev, 0)); c->shard_sel_pending = false; }
-    launch_shard_plan(c->shard_stream, d_anchors, n_pairs, n_atoms_a, world, c->d_shard, c->h_counts);
+    launch_shard_plan(c->shard_stream, d_anchors, n_pairs, n_atoms_a, n_atoms_b, world, c->d_shard, c->h_counts);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->shard_ev, c->shard_stream));
     HIP_TRY(hipStreamSynchronize(c->shard_stream));
     int64_t total = 0;
     for (int r = 0; r < world; ++r) { counts_out[r] = c->h_counts[r]; total += counts_out[r]; }
     if (total != n_pairs) return fail(LCHD_EDEVICE, "the shard plan accounts for %lld of %lld pairs", (long long)total, (long long)n_pairs);
-    c->shard_world = world; c->shard_pairs = n_pairs; c->shard_atoms = n_atoms_a;
+    c->shard_world = world; c->shard_pairs = n_pairs; c->shard_atoms = n_atoms_a; c->shard_atoms_b = n_atoms_b;
     return LCHD_OK;
 }
-extern "C" int lchd_shard_select_dev(lchd_ctx* c, const int64_t* d_anchors, int64_t n_pairs, int64_t n_atoms_a, int32_t rank,
+extern "C" int lchd_shard_select_dev(lchd_ctx* c, const int64_t* d_anchors, int64_t n_pairs, int64_t n_atoms_a, int64_t n_atoms_b, int32_t rank,
                                      int64_t* d_sel_anchors, int64_t* d_sel_index) {
     if (!c) return fail(LCHD_EVALUE, "null context");
-    if (c->shard_world < 1 || n_pairs != c->shard_pairs || n_atoms_a != c->shard_atoms)
+    if (c->shard_world < 1 || n_pairs != c->shard_pairs || n_atoms_a != c->shard_atoms || n_atoms_b != c->shard_atoms_b)
         return fail(LCHD_EVALUE, "lchd_shard_plan_dev has not been called for this pair list");
     if (rank < 0 || rank >= c->shard_world) return fail(LCHD_EVALUE, "rank %d outside the planned world of %d", rank, c->shard_world);
     if (n_pairs == 0 || c->h_counts[rank] == 0) return LCHD_OK;  // nothing for this rank: the outputs may be null
     if (!d_anchors || !d_sel_anchors || !d_sel_index) return fail(LCHD_EVALUE, "null pointer");
     CTX_GUARD(c);
     HIP_TRY(hipStreamWaitEvent(c->stream, c->shard_ev, 0));
-    launch_shard_select(c->stream, d_anchors, n_pairs, n_atoms_a, rank, c->d_shard, d_sel_anchors, d_sel_index);
+    launch_shard_select(c->stream, d_anchors, n_pairs, n_atoms_a, n_atoms_b, rank, c->shard_world, c->d_shard, d_sel_anchors, d_sel_index);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->shard_sel_ev, c->stream));
     c->shard_sel_pending = true;
@@ -1555,7 +1582,7 @@ static int sweep_rows(lchd_ctx* c, const EnvStore& ea, const EnvStore& eb, const
     sw.n_pairs = rows;
     sw.out = d_out;
     sw.meta = d_meta;
-    launch_sweep(c->stream, c->tune, c->h_cfg.n_categories, c->hellinger2, c->unit_weights, c->wf_pow, 0, sw);
+    (void)launch_sweep(c->stream, c->tune, c->h_cfg.n_categories, c->hellinger2, c->unit_weights, c->wf_pow, 0, sw);
     mark(c, 4);
     HIP_TRY(hipGetLastError());
     c->status_dirty = false;  // the record pass of this sequence resets the device status

@@ -253,8 +253,11 @@ struct SweepArgs {
 // k_pair_meta counted in the previous pass of this configuration: 4 | 1 (pairs of at most 224 merged events were the
 // majority: k_sweep_duo + the indirect k_sweep) | 2 (pairs with both environments <= 255 points were: the 8-bit-count k_sweep
 // + the indirect one); neither: the plain k_sweep only.  Any choice is correct for any input; the hint only picks the launch set.
-void launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinger2, bool unit_weights, bool wf_pow, int sweep_hint,
-                  const SweepArgs& a);
+// ... | 8 (every pair of the previous pass had at most 224 events) | 16 (... both environments <= 255 points): the companion
+// launch for the larger pairs is left out.  Returns 1 (the "small" rule of this pass was the 8-bit-count one) | 2 (the companion
+// launch was left out: the caller must check this pass's counts, HostStatus::n_duo / n_c8 against the number of pairs).
+int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinger2, bool unit_weights, bool wf_pow, int sweep_hint,
+                 const SweepArgs& a);
 // trajectory frames: replicate the template's labels / unpack [frames][atoms][3] into SoA + bounding box keys
 void launch_frames_labels(hipStream_t s, const uint8_t* tcat, const int32_t* ttag, int64_t n_tmpl, int32_t n_frames, uint8_t* cat,
                           int32_t* tag, int32_t* sid);
@@ -271,12 +274,13 @@ int bbox_parts_capacity();
 void launch_fill_sqrt_tables(hipStream_t s, double* sqrt_tab, double* rsqrt_tab);  // 65536 entries each
 void launch_fill_pow_tables(hipStream_t s, double* tab /* [2][65536] */, double exponent);  // k^(1/e), k^(-1/e)
 
-// Multi-GPU sharding of an anchor-pair list by side-A anchor (see lchd_kernels.hip).  ShardState lives in device memory,
-// zero-initialised once; hist / cursor / done are zero again after every plan.
+// Multi-GPU sharding of an anchor-pair list by anchor bins (see lchd_kernels.hip).  ShardState lives in device memory,
+// zero-initialised once; hist / hist_b / cursor / done are zero again after every plan.
 constexpr int kShardBins = 1024, kShardMaxWorld = 64;
 struct ShardState {
-    uint32_t hist[kShardBins];
+    uint32_t hist[kShardBins], hist_b[kShardBins];
     uint16_t rank_of_bin[kShardBins];
+    int32_t mode, pad;   // key side of the last plan: 0 side-A anchor, 1 side-B anchor, 2 pair index
     int64_t counts[kShardMaxWorld];
     unsigned long long cursor;
     DoneState done;
@@ -284,10 +288,10 @@ struct ShardState {
 struct ShardCounts {
     int64_t n[kShardMaxWorld];
 };
-void launch_shard_plan(hipStream_t s, const int64_t* anchors, int64_t n_pairs, int64_t n_atoms_a, int world, ShardState* st,
-                       int64_t* counts_host /* host-mapped [world] */);
-void launch_shard_select(hipStream_t s, const int64_t* anchors, int64_t n_pairs, int64_t n_atoms_a, int rank, ShardState* st,
-                         int64_t* sel_anchors, int64_t* sel_index);
+void launch_shard_plan(hipStream_t s, const int64_t* anchors, int64_t n_pairs, int64_t n_atoms_a, int64_t n_atoms_b /* <= 0: unknown */,
+                       int world, ShardState* st, int64_t* counts_host /* host-mapped [kShardMaxWorld + 1]: counts, then the key side */);
+void launch_shard_select(hipStream_t s, const int64_t* anchors, int64_t n_pairs, int64_t n_atoms_a, int64_t n_atoms_b, int rank, int world,
+                         ShardState* st, int64_t* sel_anchors, int64_t* sel_index);
 void launch_unshard_scores(hipStream_t s, const double* gathered, const ShardCounts& counts, int world, int64_t stride, double* out,
                            int64_t n_pairs, uint32_t* bad);
 void launch_env_points(hipStream_t s, const SweepArgs& a, unsigned long long* out);

@@ -3360,9 +3360,9 @@ __global__ void k_pair_meta(SweepArgs args) {
     }
 }
 
-void launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinger2, bool unit_weights, bool wf_pow, int sweep_hint,
-                  const SweepArgs& a_in) {
-    if (a_in.n_pairs <= 0) return;
+int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinger2, bool unit_weights, bool wf_pow, int sweep_hint,
+                 const SweepArgs& a_in) {
+    if (a_in.n_pairs <= 0) return 0;
     SweepArgs a = a_in;
     a.duo_enabled = 0;
     a.forced = 0;
@@ -3381,7 +3381,7 @@ void launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool helling
         else if (cm <= 24) k_sweep<24, MODE_H2U, F_KEY, true, false, true><<<g, NTH, 0, s>>>(a);
         else if (cm <= 28) k_sweep<28, MODE_H2U, F_KEY, true, false, true><<<g, NTH, 0, s>>>(a);
         else k_sweep<32, MODE_H2U, F_KEY, true, false, true><<<g, NTH, 0, s>>>(a);
-        return;
+        return 0;
     }
     const bool wide = n_categories > 32 || t.force_wide;
     const int64_t blocks = (a.n_pairs + kSweepWaves - 1) / kSweepWaves;
@@ -3407,6 +3407,11 @@ void launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool helling
     const bool use_c8 = fast_cfg && !t.no_count8 && (cmax > 16 || c8_small_slots);
     a.small_rule = use_c8 ? 1 : 0;
     const int hint = !known ? 0 : ((use_c8 ? c8_major : duo_major) ? 1 : 2);
+    // ... | 8 (EVERY pair of the previous pass had at most 224 events) | 16 (... both environments <= 255 points): the companion
+    // launch for the larger pairs would find nothing to do and is left out; the host checks the counts of THIS pass afterwards
+    // and repeats it with the full launch set if a larger pair turned up after all (the returned bit 2 says the launch was left out)
+    const bool no_others = hint == 1 && (hint_bits & (use_c8 ? 16 : 8)) != 0;
+    const int info = (use_c8 ? 1 : 0) | (no_others ? 2 : 0);
     {
         const int64_t nb = (a.n_pairs + 255) / 256;
         const int mgrid = (int)(nb < kMetaPartials ? nb : kMetaPartials);
@@ -3417,7 +3422,7 @@ void launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool helling
         if (!hellinger2) launch_sweep_wide<MODE_GEN>(s, n_categories, a.n_pairs, fm, a);
         else if (unit_weights) launch_sweep_wide<MODE_H2U>(s, n_categories, a.n_pairs, fm, a);
         else launch_sweep_wide<MODE_H2W>(s, n_categories, a.n_pairs, fm, a);
-        return;
+        return 0;
     }
     if (use_duo || use_c8) {
         // Without a hint the small-pair kernel, its companion and the plain sweep are all launched and the number of small
@@ -3431,19 +3436,19 @@ void launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool helling
             if (use_duo) {
                 const int64_t dblocks = (a.n_pairs + 2 * kSweepWaves - 1) / (2 * kSweepWaves);
                 const unsigned dgrid = (unsigned)(dblocks < 8192 ? dblocks : 8192);
-                if (cmax <= 8) { k_sweep_duo<8><<<dgrid, NTH, 0, s>>>(a); k_sweep<8, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
-                else if (cmax <= 12) { k_sweep_duo<12><<<dgrid, NTH, 0, s>>>(a); k_sweep<12, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
-                else { k_sweep_duo<16><<<dgrid, NTH, 0, s>>>(a); k_sweep<16, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+                if (cmax <= 8) { k_sweep_duo<8><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<8, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+                else if (cmax <= 12) { k_sweep_duo<12><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<12, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+                else { k_sweep_duo<16><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<16, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
             } else {
-                if (cmax <= 8) { k_sweep<8, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); k_sweep<8, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
-                else if (cmax <= 12) { k_sweep<12, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); k_sweep<12, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
-                else if (cmax <= 16) { k_sweep<16, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); k_sweep<16, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
-                else if (cmax <= 20) { k_sweep<20, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); k_sweep<20, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
-                else if (cmax <= 24) { k_sweep<24, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); k_sweep<24, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
-                else if (cmax <= 28) { k_sweep<28, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); k_sweep<28, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
-                else { k_sweep<32, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); k_sweep<32, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+                if (cmax <= 8) { k_sweep<8, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); if (!no_others) k_sweep<8, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+                else if (cmax <= 12) { k_sweep<12, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); if (!no_others) k_sweep<12, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+                else if (cmax <= 16) { k_sweep<16, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); if (!no_others) k_sweep<16, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+                else if (cmax <= 20) { k_sweep<20, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); if (!no_others) k_sweep<20, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+                else if (cmax <= 24) { k_sweep<24, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); if (!no_others) k_sweep<24, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+                else if (cmax <= 28) { k_sweep<28, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); if (!no_others) k_sweep<28, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+                else { k_sweep<32, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); if (!no_others) k_sweep<32, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
             }
-            if (hint == 1) return;
+            if (hint == 1) return info;
         }
     }
     if (!hellinger2) launch_sweep_f<MODE_GEN, false>(s, cmax, grid, fmode, a);
@@ -3454,6 +3459,7 @@ void launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool helling
         if (small) launch_sweep_f<MODE_H2W, true>(s, cmax, grid, fmode, a);
         else launch_sweep_f<MODE_H2W, false>(s, cmax, grid, fmode, a);
     }
+    return info & 1;
 }
 
 // Kernels that may be launched with more than 64 KB of dynamic LDS need the limit raised per DEVICE: lchd_ctx_create calls this
@@ -3522,55 +3528,88 @@ namespace lchd {
 // k_shard_select: this rank's pairs, compacted (order = workgroup arrival, the original positions travel with them);
 // k_unshard_scores: on the gathering rank, score k of rank r goes to its pair's original position.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int shard_bin(int64_t a, int64_t n_atoms_a) {
-    a = a < 0 ? 0 : (a >= n_atoms_a ? n_atoms_a - 1 : a);
-    return (int)((a * kShardBins) / n_atoms_a);
+__device__ __forceinline__ int shard_bin(int64_t a, int64_t n_atoms) {
+    a = a < 0 ? 0 : (a >= n_atoms ? n_atoms - 1 : a);
+    return (int)((a * kShardBins) / n_atoms);
 }
-__global__ __launch_bounds__(1024) void k_shard_plan(const int64_t* __restrict__ anchors, int64_t n_pairs, int64_t n_atoms_a, int world,
-                                                      ShardState* st, int64_t* counts_host) {
-    __shared__ uint32_t h[kShardBins];
+// The rule (loco_hd_amd/dist.py: shard_rule; lchd_capi.hip: shard_rule_host -- the same arithmetic in all three places):
+//   key side   0: bins of the side-A anchor; if that partition is unbalanced (a rank would hold more than 1.25 P / world + 1
+//              pairs: a list with one reference anchor against thousands, python_codes/kras_scan.py:46-52) 1: bins of the side-B
+//              anchor; if that one is unbalanced too (or n_atoms_b is not given) 2: contiguous slices of the pair list
+//   rank(bin) = min(world - 1, floor(#pairs in lower bins * world / P));   key side 2: rank(pair p) = floor(p * world / P)
+__global__ __launch_bounds__(1024) void k_shard_plan(const int64_t* __restrict__ anchors, int64_t n_pairs, int64_t n_atoms_a, int64_t n_atoms_b,
+                                                      int world, ShardState* st, int64_t* counts_host) {
+    __shared__ uint32_t ha[kShardBins], hb[kShardBins];
     __shared__ bool last_s;
     __shared__ uint32_t wsum[16];
     __shared__ unsigned long long cnt_s[kShardMaxWorld];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    h[tid] = 0u;  // kShardBins == blockDim.x == 1024
+    ha[tid] = 0u;  // kShardBins == blockDim.x == 1024
+    hb[tid] = 0u;
     __syncthreads();
-    for (int64_t p = blockIdx.x * 1024ll + tid; p < n_pairs; p += (int64_t)gridDim.x * 1024)
-        atomicAdd(&h[shard_bin(anchors[2 * p], n_atoms_a)], 1u);
+    const bool with_b = n_atoms_b > 0;
+    for (int64_t p = blockIdx.x * 1024ll + tid; p < n_pairs; p += (int64_t)gridDim.x * 1024) {
+        const longlong2 ab = reinterpret_cast<const longlong2*>(anchors)[p];
+        atomicAdd(&ha[shard_bin(ab.x, n_atoms_a)], 1u);
+        if (with_b) atomicAdd(&hb[shard_bin(ab.y, n_atoms_b)], 1u);
+    }
     __syncthreads();
-    {   // returning form, and the value is consumed: the atomic has been PERFORMED when the wave passes this point
+    {   // returning form, and the value is consumed: the atomics have been PERFORMED when the wave passes this point
         uint32_t r = 0;
-        if (h[tid]) r = atomicAdd(&st->hist[tid], h[tid]);
+        if (ha[tid]) r = atomicAdd(&st->hist[tid], ha[tid]);
+        if (hb[tid]) r += atomicAdd(&st->hist_b[tid], hb[tid]);
         asm volatile("" ::"v"(r));
     }
     __syncthreads();
     if (tid == 0) last_s = last_workgroup_done(&st->done, 0ull, 0u);  // (the workgroup's histogram atomics completed before the barrier)
     __syncthreads();
     if (!last_s) return;
-    // exclusive scan of the 1024 bins (one per thread), then rank(b) and the per-rank counts
-    const uint32_t v = __hip_atomic_load(&st->hist[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t incl = wave_incl_scan_u32(v);
-    if (lane == 63) wsum[wave] = incl;
-    if (tid < kShardMaxWorld) cnt_s[tid] = 0ull;
-    __syncthreads();
-    unsigned long long pre = incl - v;
-    for (int w = 0; w < wave; ++w) pre += wsum[w];
-    int r = (int)((pre * (unsigned long long)world) / (unsigned long long)n_pairs);
-    r = r < world - 1 ? r : world - 1;
-    st->rank_of_bin[tid] = (uint16_t)r;
-    if (v) atomicAdd(&cnt_s[r], (unsigned long long)v);
+    // the last workgroup: for a key side, the exclusive scan of its 1024 bins (one per thread), rank(b) and the per-rank counts;
+    // side A first, side B if A's partition is unbalanced, contiguous slices if B's is too
+    const uint32_t va = __hip_atomic_load(&st->hist[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t vb = __hip_atomic_load(&st->hist_b[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    auto plan_side = [&](uint32_t v) -> bool {  // true: balanced (no rank holds more than 1.25 P / world + 1 pairs)
+        const uint32_t incl = wave_incl_scan_u32(v);
+        __syncthreads();
+        if (lane == 63) wsum[wave] = incl;
+        if (tid < kShardMaxWorld) cnt_s[tid] = 0ull;
+        __syncthreads();
+        unsigned long long pre = incl - v;
+        for (int w = 0; w < wave; ++w) pre += wsum[w];
+        int r = (int)((pre * (unsigned long long)world) / (unsigned long long)n_pairs);
+        r = r < world - 1 ? r : world - 1;
+        st->rank_of_bin[tid] = (uint16_t)r;
+        if (v) atomicAdd(&cnt_s[r], (unsigned long long)v);
+        __syncthreads();
+        unsigned long long mx = 0;
+        for (int w = 0; w < world; ++w) mx = cnt_s[w] > mx ? cnt_s[w] : mx;
+        return mx * 4ull * (unsigned long long)world <= 5ull * (unsigned long long)n_pairs + 4ull * (unsigned long long)world;
+    };
+    int mode = 0;
+    if (!plan_side(va)) mode = (with_b && plan_side(vb)) ? 1 : 2;
     st->hist[tid] = 0u;
+    st->hist_b[tid] = 0u;
     __syncthreads();
-    if (tid < world) { st->counts[tid] = (int64_t)cnt_s[tid]; counts_host[tid] = (int64_t)cnt_s[tid]; }
-    if (tid == 0) st->cursor = 0ull;
+    if (tid < world) {
+        long long c = (long long)cnt_s[tid];
+        if (mode == 2) {  // pairs p with floor(p * world / P) == tid: [ceil(tid P / world), ceil((tid + 1) P / world))
+            const long long lo = ((long long)tid * n_pairs + world - 1) / world, hi = ((long long)(tid + 1) * n_pairs + world - 1) / world;
+            c = hi - lo;
+        }
+        st->counts[tid] = c;
+        counts_host[tid] = c;
+    }
+    if (tid == 0) { st->cursor = 0ull; st->mode = mode; counts_host[kShardMaxWorld] = mode; }
 }
-__global__ __launch_bounds__(256) void k_shard_select(const int64_t* __restrict__ anchors, int64_t n_pairs, int64_t n_atoms_a, int rank,
-                                                      ShardState* st, int64_t* __restrict__ sel_anchors, int64_t* __restrict__ sel_index) {
+__global__ __launch_bounds__(256) void k_shard_select(const int64_t* __restrict__ anchors, int64_t n_pairs, int64_t n_atoms_a, int64_t n_atoms_b,
+                                                      int rank, int world, ShardState* st, int64_t* __restrict__ sel_anchors,
+                                                      int64_t* __restrict__ sel_index) {
     __shared__ uint32_t wcnt[4];
     __shared__ unsigned long long base_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int PER = 8;  // pairs per thread and round: one cursor atomic per 2048 pairs
     const uint16_t* __restrict__ rob = st->rank_of_bin;
+    const int mode = st->mode;
     for (int64_t p0 = (int64_t)blockIdx.x * 256 * PER; p0 < n_pairs; p0 += (int64_t)gridDim.x * 256 * PER) {
         longlong2 ab[PER];
         uint32_t mine = 0;
@@ -3579,7 +3618,10 @@ __global__ __launch_bounds__(256) void k_shard_select(const int64_t* __restrict_
             const int64_t p = p0 + (int64_t)tid * PER + u;  // a thread owns PER consecutive pairs: original order inside a round
             if (p < n_pairs) {
                 ab[u] = reinterpret_cast<const longlong2*>(anchors)[p];
-                if (rob[shard_bin(ab[u].x, n_atoms_a)] == (uint16_t)rank) mine |= 1u << u;
+                int r;
+                if (mode == 2) r = (int)((p * world) / n_pairs);
+                else r = rob[mode == 1 ? shard_bin(ab[u].y, n_atoms_b) : shard_bin(ab[u].x, n_atoms_a)];
+                if (r == rank) mine |= 1u << u;
             }
         }
         const uint32_t c = (uint32_t)__popc(mine);
@@ -3613,15 +3655,16 @@ __global__ void k_unshard_scores(const double* __restrict__ gathered, ShardCount
         }
     }
 }
-void launch_shard_plan(hipStream_t s, const int64_t* anchors, int64_t n_pairs, int64_t n_atoms_a, int world, ShardState* st,
+void launch_shard_plan(hipStream_t s, const int64_t* anchors, int64_t n_pairs, int64_t n_atoms_a, int64_t n_atoms_b, int world, ShardState* st,
                        int64_t* counts_host) {
     const int64_t nb = (n_pairs + 8191) / 8192;
-    k_shard_plan<<<(unsigned)(nb < 256 ? (nb > 0 ? nb : 1) : 256), 1024, 0, s>>>(anchors, n_pairs, n_atoms_a, world, st, counts_host);
+    k_shard_plan<<<(unsigned)(nb < 256 ? (nb > 0 ? nb : 1) : 256), 1024, 0, s>>>(anchors, n_pairs, n_atoms_a, n_atoms_b, world, st, counts_host);
 }
-void launch_shard_select(hipStream_t s, const int64_t* anchors, int64_t n_pairs, int64_t n_atoms_a, int rank, ShardState* st,
-                         int64_t* sel_anchors, int64_t* sel_index) {
+void launch_shard_select(hipStream_t s, const int64_t* anchors, int64_t n_pairs, int64_t n_atoms_a, int64_t n_atoms_b, int rank, int world,
+                         ShardState* st, int64_t* sel_anchors, int64_t* sel_index) {
     const int64_t nb = (n_pairs + 2047) / 2048;
-    k_shard_select<<<(unsigned)(nb < 1024 ? (nb > 0 ? nb : 1) : 1024), 256, 0, s>>>(anchors, n_pairs, n_atoms_a, rank, st, sel_anchors, sel_index);
+    k_shard_select<<<(unsigned)(nb < 1024 ? (nb > 0 ? nb : 1) : 1024), 256, 0, s>>>(anchors, n_pairs, n_atoms_a, n_atoms_b, rank, world, st, sel_anchors,
+                                                                                    sel_index);
 }
 void launch_unshard_scores(hipStream_t s, const double* gathered, const ShardCounts& counts, int world, int64_t stride, double* out,
                            int64_t n_pairs, uint32_t* bad) {

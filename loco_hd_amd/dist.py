@@ -14,6 +14,11 @@ output i still belongs to anchor pair i (order-preserving like the reference's i
     bin(p)  = floor(a_p * 1024 / n_atoms_a)                            a_p = side-A anchor of pair p (clamped into range)
     rank(b) = min(world - 1, floor(#pairs in bins < b * world / P))
 
+A list whose side-A partition is unbalanced -- some rank would hold more than 1.25 P / world + 1 pairs: ONE reference anchor
+against thousands, the call shape of /root/reference/python_codes/kras_scan.py:46-52 -- is binned by its side-B anchors instead,
+and if that partition is unbalanced too (or `n_atoms_b` is not given), cut into contiguous slices rank(p) = floor(p * world / P):
+the reference's par_iter balances any list (src/locohd.rs:545-557), and so does this rule.
+
 On CUDA tensors with a `DeviceSession` the partition runs in the library's own kernels (lchd_shard_plan_dev /
 lchd_shard_select_dev / lchd_unshard_scores_dev: two launches and one wait); the torch expressions below are the same rule
 for CPU tensors (the gloo tests) and the cross-check of the kernels.
@@ -33,21 +38,32 @@ def shard_bounds(n_pairs: int, world: int, rank: int) -> Tuple[int, int, int]:
     return lo, min(lo + chunk, n_pairs), chunk
 
 
-def shard_rule(anchors, n_atoms_a: int, world: int):
+def shard_rule(anchors, n_atoms_a: int, world: int, n_atoms_b: Optional[int] = None):
     """The partition rule in torch (any device): returns (rank_of_pair int64 [P], counts list[world])."""
     import torch
 
     p = anchors.shape[0]
-    a = anchors[:, 0].clamp(0, max(int(n_atoms_a) - 1, 0))
-    bins = (a * SHARD_BINS) // int(n_atoms_a)
-    hist = torch.bincount(bins, minlength=SHARD_BINS)
-    before = torch.cumsum(hist, 0) - hist
-    rank_of_bin = torch.clamp((before * world) // max(p, 1), max=world - 1)
-    counts = torch.zeros(world, dtype=torch.int64, device=anchors.device).index_add_(0, rank_of_bin, hist)
-    return rank_of_bin[bins], [int(v) for v in counts.tolist()]
+
+    def plan_side(col, n_atoms):
+        a = anchors[:, col].clamp(0, max(int(n_atoms) - 1, 0))
+        bins = (a * SHARD_BINS) // int(n_atoms)
+        hist = torch.bincount(bins, minlength=SHARD_BINS)
+        before = torch.cumsum(hist, 0) - hist
+        rank_of_bin = torch.clamp((before * world) // max(p, 1), max=world - 1)
+        counts = torch.zeros(world, dtype=torch.int64, device=anchors.device).index_add_(0, rank_of_bin, hist)
+        balanced = int(counts.max()) * 4 * world <= 5 * p + 4 * world  # no rank holds more than 1.25 P / world + 1 pairs
+        return rank_of_bin[bins], [int(v) for v in counts.tolist()], balanced
+
+    rank_of_pair, counts, ok = plan_side(0, n_atoms_a)
+    if not ok and n_atoms_b:
+        rank_of_pair, counts, ok = plan_side(1, n_atoms_b)
+    if not ok:  # contiguous slices of the pair list
+        rank_of_pair = (torch.arange(p, dtype=torch.int64, device=anchors.device) * world) // max(p, 1)
+        counts = [int(v) for v in torch.bincount(rank_of_pair, minlength=world).tolist()]
+    return rank_of_pair, counts
 
 
-def select_shard(anchors, n_atoms_a: int, world: int, rank: int, session=None):
+def select_shard(anchors, n_atoms_a: int, world: int, rank: int, session=None, n_atoms_b: Optional[int] = None):
     """This rank's pairs: (sel_anchors [n][2], sel_index [n] = positions in the full list, counts of every rank)."""
     import torch
 
@@ -57,15 +73,16 @@ def select_shard(anchors, n_atoms_a: int, world: int, rank: int, session=None):
 
         assert anchors.dtype == torch.int64 and anchors.is_contiguous()
         counts = (C.c_int64 * world)()
-        N.check(N.lib().lchd_shard_plan_dev(session._ctx, C.c_void_p(anchors.data_ptr()), p, int(n_atoms_a), world, counts))
+        nb = int(n_atoms_b) if n_atoms_b else 0
+        N.check(N.lib().lchd_shard_plan_dev(session._ctx, C.c_void_p(anchors.data_ptr()), p, int(n_atoms_a), nb, world, counts))
         counts = [int(v) for v in counts]
         n = counts[rank]
         sel = torch.empty((n, 2), dtype=torch.int64, device=anchors.device)
         idx = torch.empty(n, dtype=torch.int64, device=anchors.device)
-        N.check(N.lib().lchd_shard_select_dev(session._ctx, C.c_void_p(anchors.data_ptr()), p, int(n_atoms_a), rank,
+        N.check(N.lib().lchd_shard_select_dev(session._ctx, C.c_void_p(anchors.data_ptr()), p, int(n_atoms_a), nb, rank,
                                               C.c_void_p(sel.data_ptr()), C.c_void_p(idx.data_ptr())))
         return sel, idx, counts
-    rank_of_pair, counts = shard_rule(anchors, n_atoms_a, world)
+    rank_of_pair, counts = shard_rule(anchors, n_atoms_a, world, n_atoms_b)
     idx = (rank_of_pair == rank).nonzero().reshape(-1)
     return anchors[idx].contiguous(), idx, counts
 
@@ -106,11 +123,12 @@ def unshard(gathered, counts: List[int], stride: int, n_pairs: int, out=None, se
 
 
 def score_sharded(score_fn: Callable, anchors, world: int, rank: int, group=None, n_atoms_a: Optional[int] = None, session=None,
-                  partition: str = "anchor", force_collective: bool = False):
+                  partition: str = "anchor", force_collective: bool = False, n_atoms_b: Optional[int] = None):
     """Score this rank's share of `anchors` with `score_fn(anchor_subset [n][2]) -> 1-D float64 tensor [n]` and gather.
 
     `anchors` is the FULL [P][2] int64 tensor (same on every rank).  Returns the full [P] score tensor on rank 0 (output i
-    belongs to anchor pair i) and None elsewhere.  partition="anchor" needs n_atoms_a (the size of structure A);
+    belongs to anchor pair i) and None elsewhere.  partition="anchor" needs n_atoms_a (the size of structure A; with n_atoms_b
+    a list that is degenerate on side A is binned by side B);
     "contiguous" is the plain slice (best when consecutive pairs share anchors already, e.g. (i, perm(i)) lists).
     With `session` (a DeviceSession on this rank's GPU) partition and restore run in the library's kernels."""
     import torch
@@ -129,7 +147,7 @@ def score_sharded(score_fn: Callable, anchors, world: int, rank: int, group=None
         raise ValueError(f"unknown partition {partition!r}")
     if n_atoms_a is None:
         raise ValueError('partition="anchor" needs n_atoms_a')
-    sel, idx, counts = select_shard(anchors, n_atoms_a, world, rank, session)
+    sel, idx, counts = select_shard(anchors, n_atoms_a, world, rank, session, n_atoms_b)
     stride = max(max(counts), 1)
     local = torch.zeros((2, stride), dtype=torch.float64, device=dev)
     n = counts[rank]

@@ -49,9 +49,11 @@ def test_workload_generators_are_deterministic_and_shaped():
 
 def test_roofline_block_arithmetic(tmp_path, monkeypatch):
     blk = bench.roofline_block("no_such_workload", "k_sweep", 9.6e9, 1.6)
-    assert blk["bound"] == "hbm" and blk["unit"] == "GB/s" and blk["peak"] == bench.HBM_PEAK_GBS
+    assert blk["bound"] == "valu" and blk["unit"] == "GB/s" and blk["peak"] == bench.HBM_PEAK_GBS
     assert blk["achieved"] == pytest.approx(9.6e9 / 1.6e-3 / 1e9) and blk["frac"] == pytest.approx(blk["achieved"] / blk["peak"])
-    assert blk["traffic"] is None and "hbm_measured_frac" not in blk
+    assert blk["traffic"] is None and "hbm_measured_frac" not in blk and "frac_step" not in blk
+    blk = bench.roofline_block("no_such_workload", "k_sweep", 9.6e9, 1.6, launches_per_step=2, step_ms=4.0)
+    assert blk["frac_step"] == pytest.approx(2 * 9.6e9 / 4.0e-3 / 8e12)
     # with a committed profile of the workload: measured traffic and the issue utilisation travel with the line
     prof = {"kernel": "k_sweep<12, 0, 0, true, false, false, true>", "traffic_bytes_per_launch": 2.7e9, "valu_issue_frac": 0.9, "binding": "valu issue"}
     monkeypatch.setattr(bench, "profile_numbers", lambda w: prof)

@@ -103,14 +103,24 @@ def test_anchor_partition_rule():
             sel, idx, c2 = select_shard(a, n_atoms, world, r)
             assert c2 == counts and len(idx) == counts[r] and torch.equal(sel, a[idx])
             covered.append(idx.numpy())
-            if len(sel):
+            if len(sel) and p >= 1000:  # (side-A bins: every rank owns a contiguous range of side-A anchors)
                 assert int(sel[:, 0].min()) > hi_prev or int(sel[:, 0].min()) // max(n_atoms // 1024, 1) >= hi_prev // max(n_atoms // 1024, 1)
                 hi_prev = int(sel[:, 0].max())
         assert np.array_equal(np.sort(np.concatenate(covered)) if covered else np.zeros(0), np.arange(p))
-    # KRas-scan shape (python_codes/kras_scan.py:46-52): one reference anchor against thousands -> one rank gets everything
+    # KRas-scan shape (python_codes/kras_scan.py:46-52): one reference anchor against thousands.  Side A's histogram is
+    # degenerate (one bin holds everything), so the rule bins by side B -- or, without the size of structure B, cuts the list
+    # into contiguous slices; the reference's par_iter balances this list trivially (src/locohd.rs:545-557), and so must this.
     a = torch.from_numpy(np.stack([np.zeros(4000, np.int64), np.arange(4000)], 1))
-    _, counts = shard_rule(a, 5000, 4)
-    assert sorted(counts) == [0, 0, 0, 4000]
+    for n_b in (4000, None):
+        rank_of_pair, counts = shard_rule(a, 5000, 4, n_b)
+        assert sum(counts) == 4000 and max(counts) <= 1000 + 8, counts
+        for r in range(4):
+            sel, idx, c2 = select_shard(a, 5000, 4, r, n_atoms_b=n_b)
+            assert c2 == counts and torch.equal(sel, a[idx]) and torch.equal(idx, (rank_of_pair == r).nonzero().reshape(-1))
+    # both sides degenerate: one pair repeated -> contiguous slices
+    a = torch.from_numpy(np.stack([np.full(999, 5), np.full(999, 7)], 1))
+    _, counts = shard_rule(a, 10, 4, 10)
+    assert sum(counts) == 999 and max(counts) - min(counts) <= 1, counts
     # indices outside the structure are clamped into the first / last bin (the scoring pass reports them)
     a = torch.tensor([[-5, 0], [10**9, 1], [3, 2]], dtype=torch.int64)
     _, counts = shard_rule(a, 100, 2)

@@ -46,20 +46,28 @@ def test_partition_kernels_equal_the_torch_rule(setup):
     lists = {
         "random": (setup["anchors"], setup["n"]),
         "big": (torch.from_numpy(np.stack([rng.integers(0, 200_000, 1_000_003), rng.integers(0, 200_000, 1_000_003)], 1)).cuda(), 200_000),
-        "one_anchor": (torch.from_numpy(np.stack([np.full(5000, 17), np.arange(5000)], 1)).cuda(), 6000),
-        "out_of_range": (torch.tensor([[-3, 0], [10**12, 1], [5, 2], [99, 3]], dtype=torch.int64).cuda(), 100),
-        "single_pair": (torch.tensor([[7, 7]], dtype=torch.int64).cuda(), 10),
+        # one reference anchor against thousands (python_codes/kras_scan.py:46-52): binned by side B, or -- without the size of
+        # structure B / with both sides degenerate -- cut into contiguous slices
+        "one_anchor": (torch.from_numpy(np.stack([np.full(5000, 17), np.arange(5000)], 1)).cuda(), 6000, 5000),
+        "one_anchor_no_b": (torch.from_numpy(np.stack([np.full(5000, 17), np.arange(5000)], 1)).cuda(), 6000, None),
+        "one_pair_repeated": (torch.from_numpy(np.stack([np.full(4097, 3), np.full(4097, 9)], 1)).cuda(), 50, 60),
+        "out_of_range": (torch.tensor([[-3, 0], [10**12, 1], [5, 2], [99, 3]], dtype=torch.int64).cuda(), 100, 100),
+        "single_pair": (torch.tensor([[7, 7]], dtype=torch.int64).cuda(), 10, 10),
     }
-    for name, (anc, n_atoms) in lists.items():
+    lists["random"] = lists["random"] + (setup["n"],)
+    lists["big"] = lists["big"] + (200_000,)
+    for name, (anc, n_atoms, n_atoms_b) in lists.items():
         anc = anc.contiguous()
         p = anc.shape[0]
         for world in (1, 2, 3, 8, 64):
-            rank_of_pair, counts = shard_rule(anc, n_atoms, world)
+            rank_of_pair, counts = shard_rule(anc, n_atoms, world, n_atoms_b)
+            if name.startswith("one_") and world in (2, 3, 8):
+                assert max(counts) <= p // world + 64, (name, world, counts)  # balanced, whichever key side the rule fell back to
             stride = max(max(counts), 1)
             gathered = torch.zeros((world, 2, stride), dtype=torch.float64, device="cuda")
             fake = torch.arange(p, dtype=torch.float64, device="cuda") * 0.5 + 1.0  # "score" of pair i
             for r in range(world):
-                sel, idx, c2 = select_shard(anc, n_atoms, world, r, session=sess)
+                sel, idx, c2 = select_shard(anc, n_atoms, world, r, session=sess, n_atoms_b=n_atoms_b)
                 assert c2 == counts, (name, world, r)
                 want_idx = (rank_of_pair == r).nonzero().reshape(-1)
                 assert torch.equal(torch.sort(idx).values, want_idx), (name, world, r)  # same SET (the kernel's order is arrival order)
