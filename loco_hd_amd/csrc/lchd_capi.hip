@@ -271,6 +271,7 @@ static Tuning tuning_from_env() {  // the ONLY place that reads LCHD_* hooks (te
     t.no_tables = getenv("LCHD_NO_SD_TABLES") != nullptr;
     t.no_env_group = getenv("LCHD_NO_ENV_GROUP") != nullptr;
     t.env_apw = env_int("LCHD_ENV_APW", 0);
+    t.sweep_grid = env_int("LCHD_SWEEP_GRID", 0);
     t.force_cmax = env_int("LCHD_FORCE_CMAX", 0);
     t.cap_hint = env_int("LCHD_CAP_HINT", 0);
     return t;

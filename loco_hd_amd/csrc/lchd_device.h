@@ -67,6 +67,7 @@ struct Tuning {
     bool no_count8 = false;         // LCHD_NO_COUNT8: never the 8-bit-count sweep
     bool no_tables = false;         // LCHD_NO_SD_TABLES: generic distances without the per-launch power / log tables
     bool no_env_group = false;      // LCHD_NO_ENV_GROUP: environments of the default capacity through k_env_cells (one per wavefront) too
+    int sweep_grid = 0;             // LCHD_SWEEP_GRID: most workgroups of a sweep launch (0: 8192)
     int env_apw = 0;                // LCHD_ENV_APW: anchors per wavefront of k_env_group (0: chosen from the number of anchors)
     int force_cmax = 0;             // LCHD_FORCE_CMAX: at least this many category slots
     int cap_hint = 0;               // LCHD_CAP_HINT: first environment capacity to try

@@ -356,26 +356,43 @@ __global__ void k_prep_count(const int64_t* __restrict__ anchors, int64_t n_pair
     if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(&st->flags, ST_BAD_ANCHOR);
 }
 
-// exclusive scan of n u32 by the calling 1024-thread workgroup, each thread a run of consecutive items; out[n] = total
+// exclusive scan of n u32 by the calling 1024-thread workgroup; out[n] = total.  Chunks of 4096 items are staged through LDS:
+// coalesced loads, every thread scans four consecutive LDS entries, coalesced stores.  (Each thread walking its own run of
+// consecutive items in global memory -- the first version -- is a chain of dependent, uncoalesced loads: 50 us for the 3 x 10^4
+// cells of a 2 x 10^5-atom structure, more than the two streaming kernels around it together.)  In place (out == in) is allowed.
 __device__ __forceinline__ uint32_t scan_wg_1024(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int64_t n, bool popcount,
                                                  uint32_t* wsum /* [16] */) {
+    __shared__ uint32_t stage[4096];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t per = (n + 1023) / 1024, lo = min((int64_t)tid * per, n), hi = min(lo + per, n);
-    uint32_t sum = 0;
-    for (int64_t k = lo; k < hi; ++k) sum += popcount ? (uint32_t)__popc(in[k]) : in[k];
-    const uint32_t incl = wave_incl_scan_u32(sum);
-    __syncthreads();
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    uint32_t pre = incl - sum, total = 0;
-    for (int w = 0; w < 16; ++w) { if (w < wave) pre += wsum[w]; total += wsum[w]; }
-    for (int64_t k = lo; k < hi; ++k) {
-        const uint32_t v = popcount ? (uint32_t)__popc(in[k]) : in[k];
-        out[k] = pre;
-        pre += v;
+    uint32_t carry = 0;
+    for (int64_t c0 = 0; c0 < n; c0 += 4096) {
+        __syncthreads();  // (stage / wsum of the previous chunk have been read)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t i = c0 + tid + 1024 * k;
+            const uint32_t v = i < n ? in[i] : 0u;
+            stage[tid + 1024 * k] = popcount ? (uint32_t)__popc(v) : v;
+        }
+        __syncthreads();
+        const uint4 v4 = reinterpret_cast<const uint4*>(stage)[tid];
+        const uint32_t sum = v4.x + v4.y + v4.z + v4.w;
+        const uint32_t incl = wave_incl_scan_u32(sum);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t pre = carry + incl - sum, total = 0;
+        for (int w = 0; w < 16; ++w) { if (w < wave) pre += wsum[w]; total += wsum[w]; }
+        reinterpret_cast<uint4*>(stage)[tid] = make_uint4(pre, pre + v4.x, pre + v4.x + v4.y, pre + v4.x + v4.y + v4.z);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t i = c0 + tid + 1024 * k;
+            if (i < n) out[i] = stage[tid + 1024 * k];
+        }
+        carry += total;
     }
-    if (tid == 1023) out[n] = total;
-    return total;
+    __syncthreads();
+    if (tid == 1023) out[n] = carry;
+    return carry;
 }
 // 32 byte flags -> one word of the bit set (the flag array is padded to a multiple of 32 bytes, 16-byte aligned)
 __device__ __forceinline__ uint32_t flags_word(const uint8_t* __restrict__ flag8, int64_t w) {
@@ -3387,7 +3404,8 @@ int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinge
     const int64_t blocks = (a.n_pairs + kSweepWaves - 1) / kSweepWaves;
     // grid-stride: LDS tables are built once per block.  8192 workgroups = 8 rounds of the 1024 that are resident at a time: finer
     // than that the table loads show, coarser the last round's imbalance does (measured on C2a: 4096 +2.8 %, 16384 +0.5 %)
-    const unsigned grid = (unsigned)(blocks < 8192 ? blocks : 8192);
+    const int64_t gcap = t.sweep_grid > 0 ? t.sweep_grid : 8192;
+    const unsigned grid = (unsigned)(blocks < gcap ? blocks : gcap);
     const int cmax = std::max(n_categories, t.force_cmax);  // (force_cmax: test hook)
     const bool small = a.env_a.stride <= kSqrtTab && a.env_b.stride <= kSqrtTab && !t.force_bigenv;  // every count fits the LDS tables
     const int fmode = (a.env_a.cdf_keys && a.env_b.cdf_keys) ? F_KEY : (wf_pow ? F_ANY : F_FAST);
@@ -3435,7 +3453,7 @@ int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinge
             constexpr int NTH = 64 * kSweepWaves;
             if (use_duo) {
                 const int64_t dblocks = (a.n_pairs + 2 * kSweepWaves - 1) / (2 * kSweepWaves);
-                const unsigned dgrid = (unsigned)(dblocks < 8192 ? dblocks : 8192);
+                const unsigned dgrid = (unsigned)(dblocks < gcap ? dblocks : gcap);
                 if (cmax <= 8) { k_sweep_duo<8><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<8, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
                 else if (cmax <= 12) { k_sweep_duo<12><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<12, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
                 else { k_sweep_duo<16><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<16, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
