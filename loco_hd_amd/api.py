@@ -77,15 +77,41 @@ class WeightFunction:
         return f"WeightFunction({self._name!r}, {self._params!r})"
 
 
+# Bumped by every PrimitiveAtom SETTER (not by construction): LoCoHD caches the packed form of the lists it is given and a
+# cached list is only valid while none of its atoms has been changed (see LoCoHD._packed_lists).
+_ATOM_MUTATIONS = [0]
+
+
 class PrimitiveAtom:
     """primitive_atom.rs:4-25: a record with get+set attributes."""
 
-    __slots__ = ("primitive_type", "tag", "_coordinates")
+    __slots__ = ("_primitive_type", "_tag", "_coordinates")
 
     def __init__(self, primitive_type: str, tag: str, coordinates: Sequence[float]) -> None:
-        self.primitive_type = primitive_type
-        self.tag = tag
-        self.coordinates = coordinates
+        self._primitive_type = primitive_type
+        self._tag = tag
+        v = [float(x) for x in coordinates]
+        if len(v) != 3:
+            raise ValueError(f"expected a sequence of length 3 (got {len(v)})")
+        self._coordinates = v
+
+    @property
+    def primitive_type(self) -> str:
+        return self._primitive_type
+
+    @primitive_type.setter
+    def primitive_type(self, value: str) -> None:
+        _ATOM_MUTATIONS[0] += 1
+        self._primitive_type = value
+
+    @property
+    def tag(self) -> str:
+        return self._tag
+
+    @tag.setter
+    def tag(self, value: str) -> None:
+        _ATOM_MUTATIONS[0] += 1
+        self._tag = value
 
     @property
     def coordinates(self) -> List[float]:
@@ -96,10 +122,17 @@ class PrimitiveAtom:
         v = [float(x) for x in value]
         if len(v) != 3:
             raise ValueError(f"expected a sequence of length 3 (got {len(v)})")
+        _ATOM_MUTATIONS[0] += 1
         self._coordinates = v
 
+    def __getstate__(self):
+        return (self._primitive_type, self._tag, self._coordinates)
+
+    def __setstate__(self, state):
+        self._primitive_type, self._tag, self._coordinates = state
+
     def __repr__(self) -> str:
-        return f"PrimitiveAtom({self.primitive_type!r}, {self.tag!r}, {self._coordinates!r})"
+        return f"PrimitiveAtom({self._primitive_type!r}, {self._tag!r}, {self._coordinates!r})"
 
 
 class TagPairingRule:
@@ -216,6 +249,8 @@ class LoCoHD:
             self._device = self._devices[0]  # the single-device entry points (from_anchors, from_dmxs, from_coords)
         self._ctx = None
         self._group = None
+        self._pack_cache: List[Any] = []   # most recent first: (list, its items, mutation stamp, parent entry, packed, interner)
+        self._anchor_cache = None
         self._wf_names = list(self._w_func) if isinstance(self._w_func, dict) else None
 
     # ---- getters (#[pyo3(get)], :45-52) -------------------------------------------------------------
@@ -372,11 +407,60 @@ class LoCoHD:
     def from_primitives(self, prim_a: Sequence[PrimitiveAtom], prim_b: Sequence[PrimitiveAtom], anchor_pairs,
                         threshold_distance: float) -> List[float]:
         """src/locohd.rs:479-567."""
+        pairs, idx = self._anchor_arrays(anchor_pairs)
+        pa, pb, interner = self._packed_lists(prim_a, prim_b)
+        return self.from_packed(pa, pb, pairs, threshold_distance, wf_index=idx, interner=interner).tolist()
+
+    # The reference's callers score the same structures over and over (one native structure against every decoy,
+    # python_codes/casp14/casp14_extend_with_locohd.py:72-79; one reference frame against a trajectory,
+    # python_codes/trajectory_analyzer.py:112-120), and extracting a few thousand Python objects costs several times the device
+    # call.  The packed form of a list is therefore kept: an entry is valid while the list still holds the very same atom
+    # objects (compared by identity in native code; the entry keeps them alive, so an address cannot be re-used) and no
+    # PrimitiveAtom setter has run since.  Only plain lists / tuples of exactly PrimitiveAtom are cached.
+    _CACHE_ENTRIES = 8
+
+    def _cache_lookup(self, prims, parent):
+        for k, e in enumerate(self._pack_cache):
+            if e[0] is prims and e[3] is parent and e[2] == _ATOM_MUTATIONS[0] and _fastpack.same_items(prims, e[1]):
+                if k:
+                    self._pack_cache.insert(0, self._pack_cache.pop(k))
+                return e
+        return None
+
+    def _packed_lists(self, prim_a, prim_b):
+        """(packed A, packed B, interner): tags are interned over A, then B, like one fresh interner per call."""
+        if _fastpack is None or not hasattr(_fastpack, "same_items"):
+            interner: Dict[str, int] = {}
+            return self.pack(prim_a, interner), self.pack(prim_b, interner), interner
+        entries = []
+        parent, parent_cached = None, True
+        for prims in (prim_a, prim_b):
+            e = self._cache_lookup(prims, parent) if parent_cached else None
+            if e is None:
+                interner = dict(parent[5]) if parent is not None else {}
+                packed = self.pack(prims, interner)
+                items = _fastpack.items_tuple(prims, PrimitiveAtom) if parent_cached else None
+                e = (prims, items, _ATOM_MUTATIONS[0], parent, packed, interner)
+                parent_cached = items is not None
+                if parent_cached:
+                    self._pack_cache.insert(0, e)
+                    del self._pack_cache[self._CACHE_ENTRIES:]
+            entries.append(e)
+            parent = e
+        interner = entries[1][5]
+        return entries[0][4], entries[1][4], (dict(interner) if self._tpr._pairs else interner)  # (_config interns the rule's tags)
+
+    def _anchor_arrays(self, anchor_pairs):
+        """([P][2] int64 anchors, weight-function indices or None); the conversion of an unchanged list of tuples is kept."""
+        c = self._anchor_cache
+        if c is not None and c[0] is anchor_pairs and _fastpack is not None and hasattr(_fastpack, "same_items") and _fastpack.same_items(anchor_pairs, c[1]):
+            return c[2], c[3]
         pairs, keys = self._split_anchor_pairs(anchor_pairs)
         idx = self._wf_indices(keys, len(pairs))
-        interner: Dict[str, int] = {}
-        pa, pb = self.pack(prim_a, interner), self.pack(prim_b, interner)
-        return self.from_packed(pa, pb, pairs, threshold_distance, wf_index=idx, interner=interner).tolist()
+        arr = np.ascontiguousarray(pairs, dtype=np.int64).reshape(-1, 2)
+        items = _fastpack.items_tuple(anchor_pairs, tuple) if (_fastpack is not None and hasattr(_fastpack, "items_tuple")) else None
+        self._anchor_cache = (anchor_pairs, items, arr, idx) if items is not None else None
+        return arr, idx
 
     def from_primitives_batch(self, structures: Sequence[Sequence[PrimitiveAtom]],
                               jobs: Sequence[Tuple[int, int, Sequence[Tuple[int, int]]]],

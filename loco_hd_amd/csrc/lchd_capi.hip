@@ -898,8 +898,11 @@ static int prims_enqueue(lchd_ctx* c) {
         // anchors per wavefront: as many as fit ONE group of the kernel's LDS buffer (measured, env phase in ms for 1 / 2 / 4 / 8 /
         // 16 anchors: C4, ~96-point environments 3.87 / 2.88 / 2.68 / 2.69 / 2.96; C5, ~200 points 0.81 / 0.75 / 0.75 / 0.78 / 0.81 --
         // more anchors per wavefront only lengthen the tail of the launch)
+        // A call with few anchors is bound by the latency of one wavefront's chain, not by throughput: one anchor per wavefront
+        // until there are enough of them to fill the chip twice (3000-atom structure pair: 19.9 -> 11.7 us).
+        const int by_size = c->last_biggest > 0 && c->last_biggest <= 140 ? 4 : (c->last_biggest > kEnvGroupSmallUpTo ? 1 : 2);
         const int apw = c->tune.env_apw > 0 ? c->tune.env_apw
-                                            : (c->last_biggest > 0 && c->last_biggest <= 140 ? 4 : (c->last_biggest > kEnvGroupSmallUpTo ? 1 : 2));
+                                            : (int)std::max<int64_t>(1, std::min<int64_t>(by_size, (max_env_a + max_env_b) / 8192));
         P.group_small = c->group_small;
         if (!launch_env_group(s, c->d_cfg, tag_list, P.group_small, esa, esb, thr, apw, c->d_status))
             return fail(LCHD_EDEVICE, "the grouped environment kernel rejected its launch configuration");

@@ -15,7 +15,15 @@
 #include <Python.h>
 #include <stdint.h>
 
-static PyObject *s_coords_private, *s_coords_public, *s_type, *s_tag;
+static PyObject *s_coords_private, *s_coords_public, *s_type, *s_tag, *s_type_private, *s_tag_private;
+
+/* attribute `priv` (the slot of loco_hd_amd.PrimitiveAtom: no property call), else `pub` (any object with the public names) */
+static PyObject *get_attr2(PyObject *p, PyObject *priv, PyObject *pub) {
+    PyObject *v = PyObject_GetAttr(p, priv);
+    if (v) return v;
+    PyErr_Clear();
+    return PyObject_GetAttr(p, pub);
+}
 
 static int get_buffer(PyObject *obj, Py_buffer *view, Py_ssize_t itemsize, Py_ssize_t need_items, const char *what) {
     if (PyObject_GetBuffer(obj, view, PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS) != 0) return -1;
@@ -66,7 +74,7 @@ static PyObject *pack_into(PyObject *self, PyObject *args) {
         Py_DECREF(cs);
         if (!ok) break;
         /* category: index in the LoCoHD instance's map, -1 if absent (src/locohd/pmf.rs:38-42 raises later) */
-        PyObject *t = PyObject_GetAttr(p, s_type);
+        PyObject *t = get_attr2(p, s_type_private, s_type);
         if (!t) { ok = 0; break; }
         PyObject *idx = PyDict_GetItemWithError(categories, t); /* borrowed */
         if (!idx && PyErr_Occurred()) { Py_DECREF(t); ok = 0; break; }
@@ -86,7 +94,7 @@ static PyObject *pack_into(PyObject *self, PyObject *args) {
             cat[i] = -1;
         }
         /* tag: interned in order of first appearance */
-        PyObject *g = PyObject_GetAttr(p, s_tag);
+        PyObject *g = get_attr2(p, s_tag_private, s_tag);
         if (!g) { ok = 0; break; }
         PyObject *id = PyDict_GetItemWithError(interner, g); /* borrowed */
         if (!id && PyErr_Occurred()) { Py_DECREF(g); ok = 0; break; }
@@ -148,7 +156,42 @@ static PyObject *cats_into(PyObject *self, PyObject *args) {
     Py_RETURN_NONE;
 }
 
+/* items_tuple(seq, cls) -> tuple(seq) if seq is a list / tuple whose items are all EXACTLY of type cls (cls may be None: any
+ * items), else None.  same_items(seq, tup) -> True iff seq is a list / tuple with the very same item objects as tup.
+ * The pair implements the identity check of LoCoHD's packed-structure cache: the tuple keeps the items alive (an address cannot be
+ * re-used by another object), so "same objects" + "no PrimitiveAtom setter ran since" means "same content". */
+static PyObject *items_tuple(PyObject *self, PyObject *args) {
+    PyObject *seq, *cls;
+    if (!PyArg_ParseTuple(args, "OO", &seq, &cls)) return NULL;
+    if (!PyList_CheckExact(seq) && !PyTuple_CheckExact(seq)) Py_RETURN_NONE;
+    const Py_ssize_t n = PySequence_Fast_GET_SIZE(seq);
+    PyObject **items = PySequence_Fast_ITEMS(seq);
+    if (cls != Py_None)
+        for (Py_ssize_t i = 0; i < n; ++i)
+            if ((PyObject *)Py_TYPE(items[i]) != cls) Py_RETURN_NONE;
+    PyObject *tup = PyTuple_New(n);
+    if (!tup) return NULL;
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        Py_INCREF(items[i]);
+        PyTuple_SET_ITEM(tup, i, items[i]);
+    }
+    return tup;
+}
+static PyObject *same_items(PyObject *self, PyObject *args) {
+    PyObject *seq, *tup;
+    if (!PyArg_ParseTuple(args, "OO!", &seq, &PyTuple_Type, &tup)) return NULL;
+    if (!PyList_CheckExact(seq) && !PyTuple_CheckExact(seq)) Py_RETURN_FALSE;
+    const Py_ssize_t n = PySequence_Fast_GET_SIZE(seq);
+    if (n != PyTuple_GET_SIZE(tup)) Py_RETURN_FALSE;
+    PyObject **a = PySequence_Fast_ITEMS(seq), **b = PySequence_Fast_ITEMS(tup);
+    for (Py_ssize_t i = 0; i < n; ++i)
+        if (a[i] != b[i]) Py_RETURN_FALSE;
+    Py_RETURN_TRUE;
+}
+
 static PyMethodDef methods[] = {
+    {"items_tuple", items_tuple, METH_VARARGS, "items_tuple(seq, cls): tuple(seq) if every item is exactly of type cls, else None"},
+    {"same_items", same_items, METH_VARARGS, "same_items(seq, tup): the very same item objects?"},
     {"cats_into", cats_into, METH_VARARGS, "cats_into(labels, categories, cat): category indices of a sequence of labels (-1: not in the map)"},
     {"pack_into", pack_into, METH_VARARGS, "pack_into(prims, categories, interner, xyz, cat, tag): fill SoA buffers from a sequence of PrimitiveAtom"},
     {NULL, NULL, 0, NULL}};
@@ -160,6 +203,8 @@ PyMODINIT_FUNC PyInit__fastpack(void) {
     s_coords_public = PyUnicode_InternFromString("coordinates");
     s_type = PyUnicode_InternFromString("primitive_type");
     s_tag = PyUnicode_InternFromString("tag");
-    if (!s_coords_private || !s_coords_public || !s_type || !s_tag) return NULL;
+    s_type_private = PyUnicode_InternFromString("_primitive_type");
+    s_tag_private = PyUnicode_InternFromString("_tag");
+    if (!s_coords_private || !s_coords_public || !s_type || !s_tag || !s_type_private || !s_tag_private) return NULL;
     return PyModule_Create(&moduledef);
 }

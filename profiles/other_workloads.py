@@ -72,11 +72,19 @@ sd = (nn / 0.023) ** (1 / 3)
 pa = [lh.PrimitiveAtom(types[i % 8], f"A/{i // 3}-RES", rs.uniform(0, sd, 3)) for i in range(nn)]
 pb = [lh.PrimitiveAtom(types[i % 8], f"A/{i // 3}-RES", rs.uniform(0, sd, 3)) for i in range(nn)]
 anc = [(i, i) for i in range(0, nn, 3)]
-t = timed(lambda: lchd.from_primitives(pa, pb, anc, 10.0), reps=20, warm=3)
+t = timed(lambda: lchd.from_primitives(pa, pb, anc, 10.0), reps=20, warm=3)  # the same lists again and again: served from the packed-list cache
+t_first = timed(lambda: lchd.from_primitives(list(pa), list(pb), list(anc), 10.0), reps=20, warm=3)  # new list objects every call: full extraction
+pb_k = [[lh.PrimitiveAtom(types[i % 8], f"A/{i // 3}-RES", rs.uniform(0, sd, 3)) for i in range(nn)] for _ in range(8)]
+kk = [0]
+def one_vs_many():  # the casp14 loop: one native structure against another decoy every call (side A cached, side B extracted)
+    kk[0] += 1
+    return lchd.from_primitives(pa, list(pb_k[kk[0] % 8]), anc, 10.0)
+t_mixed = timed(one_vs_many, reps=24, warm=3)
 it = {}
 ka, kb = lchd.pack(pa, it), lchd.pack(pb, it)
 t2 = timed(lambda: lchd.from_packed(ka, kb, np.asarray(anc, dtype=np.int64), 10.0, interner=it), reps=50, warm=3)
-res["reference_style_call_3000_atoms_1000_pairs"] = {"from_primitives_lists_ms": t, "c_abi_host_pointer_call_ms": t2}
+res["reference_style_call_3000_atoms_1000_pairs"] = {"from_primitives_lists_ms": t, "from_primitives_new_lists_every_call_ms": t_first,
+                                                     "from_primitives_same_a_new_b_ms": t_mixed, "c_abi_host_pointer_call_ms": t2}
 
 # ---- C2a clouds with other configurations (sweep phase per 10^6 pairs) ------------------------------------------------
 w = bench.make_workload("c2a", 0, 1_000_000)

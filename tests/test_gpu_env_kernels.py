@@ -125,3 +125,62 @@ def test_grouped_kernel_on_lattices_and_flat_structures(lh, oracle):
             want = score(oracle, sa, xa, sb, xb, anchors, thr, wf=wf)[0]
             for got in score(lh, sa, xa, sb, xb, anchors, thr, wf=wf, repeat=2):
                 assert np.max(np.abs(got - want)) < TIGHT
+
+
+def test_packed_list_cache_sees_every_change(lh, oracle):
+    """LoCoHD keeps the packed form of the PrimitiveAtom lists it was given (the reference's callers pass the same structure
+    again and again, python_codes/casp14/casp14_extend_with_locohd.py:72-79).  Every way of changing what a list means between
+    two calls must be seen: an atom's setter, an item replaced, the list grown, another anchor list, another tag."""
+    rng = np.random.default_rng(75)
+    n = 400
+    sa, xa = rng.choice(CATS, n).tolist(), rng.uniform(0, 20.0, (n, 3))
+    sb, xb = rng.choice(CATS, n).tolist(), rng.uniform(0, 20.0, (n, 3))
+    tags = [f"r{i // 4}" for i in range(n)]
+    anchors = [(i, (7 * i) % n) for i in range(0, n, 2)]
+    state = {}
+    for mod in (lh, oracle):
+        state[mod] = dict(lchd=mod.LoCoHD(CATS, mod.WeightFunction("uniform", [2.0, 9.0]), mod.TagPairingRule({"accept_same": False})),
+                          pa=prims(mod, sa, xa, tags), pb=prims(mod, sb, xb, tags), anchors=list(anchors))
+
+    def both():
+        got = {mod: np.asarray(st["lchd"].from_primitives(st["pa"], st["pb"], st["anchors"], 9.0)) for mod, st in state.items()}
+        assert np.max(np.abs(got[lh] - got[oracle])) < TIGHT
+        return got[lh]
+
+    first = both()
+    assert np.array_equal(both(), first) and np.array_equal(both(), first)  # served from the cache, bitwise the same
+    for mod, st in state.items():  # setters of atoms already in the lists
+        st["pa"][10].coordinates = [1.0, 2.0, 3.0]
+        st["pb"][11].primitive_type = "E" if sb[11] != "E" else "A"
+        st["pa"][12].tag = "somewhere else"
+    second = both()
+    assert not np.array_equal(second, first)
+    for mod, st in state.items():  # an item replaced by a new atom (same length)
+        st["pb"][20] = mod.PrimitiveAtom("C", "r5", [3.0, 3.0, 3.0])
+    third = both()
+    assert not np.array_equal(third, second)
+    for mod, st in state.items():  # the list grows; an anchor pair is replaced (same list object)
+        st["pa"].append(mod.PrimitiveAtom("D", "new", [4.0, 4.0, 4.0]))
+        st["anchors"][0] = (n, 3)
+    fourth = both()
+    assert fourth[0] != third[0]
+    # a second LoCoHD object on the same lists shares nothing with the first one's cache
+    other = lh.LoCoHD(CATS, lh.WeightFunction("uniform", [2.0, 9.0]), lh.TagPairingRule({"accept_same": True}))
+    same_tags = np.asarray(other.from_primitives(state[lh]["pa"], state[lh]["pb"], state[lh]["anchors"], 9.0))
+    want = np.asarray(oracle.LoCoHD(CATS, oracle.WeightFunction("uniform", [2.0, 9.0]), oracle.TagPairingRule({"accept_same": True}))
+                      .from_primitives(state[oracle]["pa"], state[oracle]["pb"], state[oracle]["anchors"], 9.0))
+    assert np.max(np.abs(same_tags - want)) < TIGHT
+    # one list on both sides, tuples instead of lists, objects that merely look like PrimitiveAtoms (never cached)
+    class Duck:
+        def __init__(self, a):
+            self.primitive_type, self.tag, self.coordinates = a.primitive_type, a.tag, a.coordinates
+    lchd = state[lh]["lchd"]
+    pa = state[lh]["pa"]
+    self_scores = np.asarray(lchd.from_primitives(pa, pa, [(i, i) for i in range(50)], 9.0))
+    assert np.all(self_scores == 0.0)
+    ducks = [Duck(a) for a in pa]
+    d1 = np.asarray(lchd.from_primitives(tuple(pa), ducks, [(i, i) for i in range(50)], 9.0))
+    assert np.all(d1 == 0.0)
+    ducks[3].coordinates = [9.0, 9.0, 9.0]
+    d2 = np.asarray(lchd.from_primitives(tuple(pa), ducks, [(i, i) for i in range(50)], 9.0))
+    assert d2[3] > 0.0

@@ -164,3 +164,36 @@ def test_native_pack_equals_python_pack():
         lchd.pack([Duck("a", "t", (1, 2))], {})
     with pytest.raises(AttributeError):
         lchd.pack([object()], {})
+
+
+def test_primitive_atom_record_and_native_identity_helpers():
+    """primitive_atom.rs:4-25: get + set attributes; the setters also stamp the module's mutation counter (LoCoHD's packed-list
+    cache), construction does not.  _fastpack.items_tuple / same_items compare by identity."""
+    import pickle
+
+    import loco_hd_amd as lh
+    from loco_hd_amd import api
+
+    before = api._ATOM_MUTATIONS[0]
+    a = lh.PrimitiveAtom("A", "t", (1, 2, 3))
+    assert (a.primitive_type, a.tag, a.coordinates) == ("A", "t", [1.0, 2.0, 3.0]) and api._ATOM_MUTATIONS[0] == before
+    a.primitive_type, a.tag, a.coordinates = "B", "u", [4, 5, 6]
+    assert (a.primitive_type, a.tag, a.coordinates) == ("B", "u", [4.0, 5.0, 6.0]) and api._ATOM_MUTATIONS[0] == before + 3
+    c = a.coordinates
+    c[0] = 99.0  # a copy, as in the reference (the getter clones)
+    assert a.coordinates[0] == 4.0
+    with pytest.raises(ValueError):
+        a.coordinates = [1.0, 2.0]
+    with pytest.raises(ValueError):
+        lh.PrimitiveAtom("A", "t", [1.0])
+    b = pickle.loads(pickle.dumps(a))
+    assert (b.primitive_type, b.tag, b.coordinates) == ("B", "u", [4.0, 5.0, 6.0])
+    if api._fastpack is not None:
+        items = [lh.PrimitiveAtom("A", "", [0, 0, i]) for i in range(5)]
+        tup = api._fastpack.items_tuple(items, lh.PrimitiveAtom)
+        assert isinstance(tup, tuple) and all(x is y for x, y in zip(tup, items))
+        assert api._fastpack.same_items(items, tup) and api._fastpack.same_items(tuple(items), tup)
+        assert not api._fastpack.same_items(items[:4], tup) and not api._fastpack.same_items(items[::-1], tup)
+        assert api._fastpack.items_tuple(items + ["x"], lh.PrimitiveAtom) is None
+        assert api._fastpack.items_tuple(np.asarray(items, dtype=object), lh.PrimitiveAtom) is None  # lists / tuples only
+        assert api._fastpack.items_tuple([(1, 2), (3, 4)], tuple) is not None and api._fastpack.items_tuple([(1, 2), [3, 4]], tuple) is None
