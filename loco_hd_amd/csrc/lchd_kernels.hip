@@ -2095,7 +2095,13 @@ __device__ unsigned long long g_sweep_stamps[8];
 // tile and to keep per lane, and 3 KB less LDS per wavefront, which lets the many-slot variants run at 3 waves per SIMD
 // instead of 2.  Pairs with a larger environment are left to the INDIRECT instantiation of the 16-bit kernel.
 template <int CMAX, int MODE, int FMODE, bool LDSTAB, bool INDIRECT = false, bool INLINE_META = false, bool CNT8 = false>
-__global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? (CMAX <= LCHD_GEN_W3MAX ? 3 : 2) : (CMAX <= 12 ? 4 : (CMAX <= LCHD_SWEEP_W3MAX ? 3 : (CNT8 ? LCHD_C8_WAVES : 2))))) void k_sweep(SweepArgs args) {
+#ifndef LCHD_EXACT_H2_LOOP
+#define LCHD_EXACT_H2_LOOP 1
+#endif
+#ifndef LCHD_C8S_WAVES
+#define LCHD_C8S_WAVES 4   // waves per SIMD the 8-bit-count sweep with at most 12 category slots is compiled for
+#endif
+__global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? (CMAX <= LCHD_GEN_W3MAX ? 3 : 2) : (CMAX <= 12 ? (CNT8 ? LCHD_C8S_WAVES : 4) : (CMAX <= LCHD_SWEEP_W3MAX ? 3 : (CNT8 ? LCHD_C8_WAVES : 2))))) void k_sweep(SweepArgs args) {
     static_assert(!(INDIRECT && INLINE_META), "the indirect instantiation reads the records of k_pair_meta");
     static_assert(!CNT8 || (MODE == MODE_H2U && FMODE == F_KEY && LDSTAB && !INDIRECT && !INLINE_META), "8-bit counts: default configuration only");
     // Merged events per lane per tile.  The per-tile prologue (staging, merge path, scan of the packed counts, state reload)
@@ -2129,7 +2135,10 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? (CMAX <= LCHD
 #ifndef LCHD_C8_REGCNT
 #define LCHD_C8_REGCNT 0
 #endif
-    constexpr bool LDSCNT = H2 && LDSTAB && NW > 3 && (LCHD_LDS_COUNTS != 0) && !(CNT8 && LCHD_C8_REGCNT);  // (16-bit fields: from 13 category slots on)
+#ifndef LCHD_C8_LDSCNT_ALL
+#define LCHD_C8_LDSCNT_ALL 1   // the 8-bit-count sweeps keep their per-lane counts in LDS for every slot count (<= 12 slots: their 2 KB per wave do not cost a wave of occupancy, and the byte read-modify-write replaces the word select + 4-bit counter chains: C2a sweep 1.577 -> 1.523 ms)
+#endif
+    constexpr bool LDSCNT = H2 && LDSTAB && (NW > 3 || (CNT8 && LCHD_C8_LDSCNT_ALL)) && (LCHD_LDS_COUNTS != 0) && !(CNT8 && LCHD_C8_REGCNT);  // (16-bit fields: from 13 category slots on)
     __shared__ uint64_t lc_[LDSCNT ? WPB : 1][LDSCNT ? 2 * NW * 64 : 1];
     // When pairs with at most kDuoTile merged events are the majority of a launch, k_sweep_duo sweeps them two per wavefront
     // and the INDIRECT instantiation of this kernel picks the remaining ones out of the pair records; otherwise the plain
@@ -2374,6 +2383,21 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? (CMAX <= LCHD
         // exact squared Hellinger distance in the literal difference-of-roots form (statistical_distances.rs:4-10)
         auto exact_h2 = [&]() -> double {
             double acc2 = 0.0;
+            if constexpr (LDSCNT && CMAX > 16 && (LCHD_EXACT_H2_LOOP != 0)) {
+                // many slots, counts in LDS: a runtime loop over the count words (one copy of the eight-field body): the rarely
+                // taken path no longer sizes the kernel's register allocation
+#pragma unroll 1
+                for (int k = 0; k < NW; ++k) {
+                    const uint64_t wa = *reinterpret_cast<const uint64_t*>(lcl + k * 512), wb = *reinterpret_cast<const uint64_t*>(lcl + kLcSide + k * 512);
+#pragma unroll
+                    for (int f = 0; f < FPW; ++f) {
+                        const int ca = (int)((wa >> (f * FB)) & FMASK), cb = (int)((wb >> (f * FB)) & FMASK);
+                        const double d = root_of(FPW * k + f, ca) * ra - root_of(FPW * k + f, cb) * rb;  // (padded slots: 0 - 0)
+                        acc2 = fma(d, d, acc2);
+                    }
+                }
+                return 0.5 * acc2;
+            }
 #pragma unroll
             for (int k = 0; k < NW; ++k) {
                 // the chunk-start words go through an empty volatile asm: they do not change during the event loop, and the
