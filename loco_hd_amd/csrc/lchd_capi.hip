@@ -126,6 +126,7 @@ extern "C" int lchd_config_validate(int64_t n_given, int64_t n_map, const double
 struct lchd_cloud {
     double *x = nullptr, *y = nullptr, *z = nullptr;
     uint8_t* cat = nullptr;
+    uint8_t* cat_hi = nullptr;  // high byte of the category ids (allocated when an id beyond 254 occurs: more than 255 categories)
     int32_t* tag = nullptr;
     int32_t* sid = nullptr;  // batch of structures: structure id per atom (nullptr = one structure)
     int32_t n_struct = 1;
@@ -148,7 +149,7 @@ struct lchd_cloud {
     hipEvent_t ev_ready = nullptr, ev_used = nullptr;
     bool bbox_pending = false, used_valid = false;
     double bbmin[3] = {0, 0, 0}, bbmax[3] = {0, 0, 0};
-    CloudView view() const { return CloudView{x, y, z, cat, tag, (int32_t)n, sid, n_struct, sid ? struct_size : 0}; }
+    CloudView view() const { return CloudView{x, y, z, cat, cat_hi, tag, (int32_t)n, sid, n_struct, sid ? struct_size : 0}; }
 };
 
 enum { PH_CELLS = 0, PH_ANCHORS = 1, PH_ENV = 2, PH_SWEEP = 3, PH_N = 4 };
@@ -404,7 +405,9 @@ extern "C" int lchd_ctx_set_config(lchd_ctx* c, const lchd_config* cfg) {
     CTX_GUARD(c);
     const int C = cfg->n_categories;
     if (C <= 0) return fail(LCHD_EVALUE, "The number of possible categories (primitive types) cannot be zero!");
-    if (C > 255) return fail(LCHD_EUNSUPPORTED, "at most 255 categories are supported (categories travel as u8; got %d)", C);
+    if (C > kWideCategories)
+        return fail(LCHD_EUNSUPPORTED, "at most %d categories are supported (the sweep keeps one per-lane count column per category in LDS; got %d)",
+                    kWideCategories, C);
     if (int rc = lchd_config_validate(C, C, cfg->category_weights, C)) return rc;
     if (cfg->n_weight_functions <= 0) return fail(LCHD_EVALUE, "at least one weight function is required");
     if (int rc = lchd_sd_validate(cfg->sd_kind, cfg->sd_n_params)) return rc;
@@ -529,10 +532,23 @@ static int upload_coords(lchd_ctx* c, lchd_cloud* cl, const double* xyz) {
     return LCHD_OK;
 }
 
-static std::vector<uint8_t> cats_to_u8(const int32_t* cat, int64_t n) {
-    std::vector<uint8_t> v((size_t)n);
-    for (int64_t i = 0; i < n; ++i) v[(size_t)i] = (cat[i] >= 0 && cat[i] < 255) ? (uint8_t)cat[i] : (uint8_t)255;  // 255 = not in the map
-    return v;
+// Category ids travel as one byte (255 = not in the category map) -- or, as soon as an id beyond 254 occurs (more than 255
+// categories), as two: low byte | high byte, 0xFFFF = not in the map.
+static bool cats_need_hi(const int32_t* cat, int64_t n) {
+    for (int64_t i = 0; i < n; ++i)
+        if (cat[i] >= 255 && cat[i] < 65535) return true;
+    return false;
+}
+static void cats_encode(const int32_t* cat, int64_t n, uint8_t* lo, uint8_t* hi /* or nullptr */) {
+    for (int64_t i = 0; i < n; ++i) {
+        if (hi) {
+            const uint32_t v = (cat[i] >= 0 && cat[i] < 65535) ? (uint32_t)cat[i] : 0xFFFFu;
+            lo[i] = (uint8_t)(v & 255u);
+            hi[i] = (uint8_t)(v >> 8);
+        } else {
+            lo[i] = (cat[i] >= 0 && cat[i] < 255) ? (uint8_t)cat[i] : (uint8_t)255;
+        }
+    }
 }
 
 extern "C" int lchd_cloud_create(lchd_ctx* c, const double* xyz, const int32_t* cat, const int32_t* tag, int64_t n, lchd_cloud** out) {
@@ -562,8 +578,14 @@ extern "C" int lchd_cloud_create(lchd_ctx* c, const double* xyz, const int32_t* 
         if ((e = hipMemsetAsync(cl->z, 0, sizeof(double) * m, c->stream)) != hipSuccess) return bail(e, "hipMemset(z)");
     }
     if (n) {
-        std::vector<uint8_t> c8 = cats_to_u8(cat, n);
+        const bool wide = cats_need_hi(cat, n);
+        std::vector<uint8_t> c8((size_t)n), c8h(wide ? (size_t)n : 0);
+        cats_encode(cat, n, c8.data(), wide ? c8h.data() : nullptr);
         if ((e = hipMemcpy(cl->cat, c8.data(), (size_t)n, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(cat)");
+        if (wide) {
+            if ((e = hipMalloc(&cl->cat_hi, (size_t)n)) != hipSuccess) return bail(e, "hipMalloc(cat_hi)");
+            if ((e = hipMemcpy(cl->cat_hi, c8h.data(), (size_t)n, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(cat_hi)");
+        }
         if (tag) e = hipMemcpy(cl->tag, tag, sizeof(int32_t) * n, hipMemcpyHostToDevice);
         else e = hipMemset(cl->tag, 0, sizeof(int32_t) * n);
         if (e != hipSuccess) return bail(e, "tags");
@@ -618,6 +640,7 @@ extern "C" void lchd_cloud_destroy(lchd_ctx* c, lchd_cloud* cl) {
     (void)hipFree(cl->y);
     (void)hipFree(cl->z);
     (void)hipFree(cl->cat);
+    (void)hipFree(cl->cat_hi);
     (void)hipFree(cl->tag);
     (void)hipFree(cl->sid);
     (void)hipFree(cl->d_raw);
@@ -768,7 +791,7 @@ struct PassBufs {
     size_t zero_bytes;
 };
 static void carve_pass(Arena& ar, int64_t n_a, int cells_a, int64_t envs_a, int64_t n_b, int cells_b, int64_t envs_b, int cap, int64_t n_pairs,
-                       PassBufs& pb) {
+                       PassBufs& pb, bool cat16 = false) {
     const size_t ma = (size_t)std::max<int64_t>(n_a, 1), mb = (size_t)std::max<int64_t>(n_b, 1);
     ar.off = (ar.off + 255) & ~size_t(255);
     const size_t z0 = ar.off;
@@ -794,10 +817,11 @@ static void carve_pass(Arena& ar, int64_t n_a, int cells_a, int64_t envs_a, int6
         b.uniq = ar.take<AnchorRec>(ne);
         b.scan_tmp = ar.take<uint32_t>(std::max<size_t>(m, (size_t)n_cells) / 4096 + 4);
         b.env.key = ar.take<uint64_t>(ne * (size_t)cap);
-        b.env.cat = ar.take<uint8_t>(ne * (size_t)cap);
+        b.env.cat = ar.take<uint8_t>(ne * (size_t)cap * (cat16 ? 2 : 1));
         b.env.len = ar.take<int32_t>(ne);
         b.env.stride = cap;
         b.env.cdf_keys = 0;
+        b.env.cat16 = cat16 ? 1 : 0;
         b.raw_key = cap > 16384 ? ar.take<double>(ne * (size_t)cap) : nullptr;
         b.raw_cat = cap > 16384 ? ar.take<uint8_t>(ne * (size_t)cap) : nullptr;
     }
@@ -841,7 +865,9 @@ static int prims_enqueue(lchd_ctx* c) {
     const double thr = P.thr;
     const int cap = P.cap;
     // environments of the default capacity: several per wavefront on a grid of half-threshold cells (lchd_env_group.hip)
-    const bool group = cap == kEnvGroupCap && !c->tune.no_env_group && a->n < ((int64_t)1 << 29) && b->n < ((int64_t)1 << 29);
+    // more than 255 categories: 16-bit ids in the environment store, k_env_cells<.., uint16_t> + k_sweep_wide<.., CAT16>
+    const bool cat16 = c->h_cfg.n_categories > kMaxCategories;
+    const bool group = cap == kEnvGroupCap && !c->tune.no_env_group && a->n < ((int64_t)1 << 29) && b->n < ((int64_t)1 << 29) && !cat16;
     P.group = group;
     P.group_small = false;
     const GridPlan ga = plan_grid(a, thr, group ? 2 : 1), gb = plan_grid(b, thr, group ? 2 : 1);
@@ -854,11 +880,11 @@ static int prims_enqueue(lchd_ctx* c) {
     PassBufs pb{};
     {
         Arena dry(nullptr, 0, true);
-        carve_pass(dry, a->n, ga.n_cells, max_env_a, b->n, gb.n_cells, max_env_b, cap, n_pairs, pb);
+        carve_pass(dry, a->n, ga.n_cells, max_env_a, b->n, gb.n_cells, max_env_b, cap, n_pairs, pb, cat16);
         if (int rc = ensure_ws(c, dry.off + 4096)) return rc;
     }
     Arena ar(c->ws, c->ws_cap, false);
-    carve_pass(ar, a->n, ga.n_cells, max_env_a, b->n, gb.n_cells, max_env_b, cap, n_pairs, pb);
+    carve_pass(ar, a->n, ga.n_cells, max_env_a, b->n, gb.n_cells, max_env_b, cap, n_pairs, pb, cat16);
     SideBufs &sa = pb.a, &sb = pb.b;
     sa.env.cdf_keys = sb.env.cdf_keys = (c->h_cfg.n_wf == 1 && !c->tune.no_cdf_keys) ? 1 : 0;
 
@@ -907,7 +933,8 @@ static int prims_enqueue(lchd_ctx* c) {
         if (!launch_env_group(s, c->d_cfg, tag_list, P.group_small, esa, esb, thr, apw, c->d_status))
             return fail(LCHD_EDEVICE, "the grouped environment kernel rejected its launch configuration");
     } else if (!launch_env_cells(s, cap, c->d_cfg, tag_list, esa, esb, thr, c->d_status))
-        return fail(LCHD_EUNSUPPORTED, "no environment kernel variant with capacity %d", cap);
+        return fail(LCHD_EUNSUPPORTED, cat16 ? "with more than 255 categories an environment may hold at most 8192 points (capacity %d asked for)"
+                                             : "no environment kernel variant with capacity %d", cap);
     mark(c, 3);
     SweepArgs sw{};
     fill_sweep_args(c, sw);
@@ -1023,6 +1050,7 @@ extern "C" int lchd_frames_create(lchd_ctx* c, const lchd_cloud* tmpl, int32_t c
     if (!c || !tmpl || !out || capacity_frames < 1) return fail(LCHD_EVALUE, "bad argument");
     CTX_GUARD(c);
     if (tmpl->sid) return fail(LCHD_EVALUE, "the template of a frames buffer must be a single structure");
+    if (tmpl->cat_hi) return fail(LCHD_EUNSUPPORTED, "frames buffers take structures with at most 255 categories");
     const int64_t nt = tmpl->n, total = nt * capacity_frames;
     if (nt < 1 || total > ((int64_t)1 << 30)) return fail(LCHD_EUNSUPPORTED, "frames buffer of %lld atoms is out of range", (long long)total);
     lchd_cloud* cl = new lchd_cloud();
@@ -1239,14 +1267,17 @@ static int stage_cloud(const double* xyz, const int32_t* cat, const int32_t* tag
                        lchd_cloud& cl) {
     auto take = [&](size_t bytes) { off = (off + 255) & ~size_t(255); const size_t o = off; off += bytes; return o; };
     const size_t m = (size_t)std::max<int64_t>(n, 1);
-    const size_t ox = take(8 * m), oy = take(8 * m), oz = take(8 * m), ot = take(4 * m), oc = take(m);
+    const size_t ox = take(8 * m), oy = take(8 * m), oz = take(8 * m), ot = take(4 * m), oc = take(m), och = take(m);
     cl.x = reinterpret_cast<double*>(d_base + ox);
     cl.y = reinterpret_cast<double*>(d_base + oy);
     cl.z = reinterpret_cast<double*>(d_base + oz);
     cl.tag = reinterpret_cast<int32_t*>(d_base + ot);
     cl.cat = reinterpret_cast<uint8_t*>(d_base + oc);
+    cl.cat_hi = nullptr;
     cl.n = n;
     if (!h_base) return LCHD_OK;  // sizing pass
+    const bool wide = cats_need_hi(cat, n);
+    if (wide) cl.cat_hi = reinterpret_cast<uint8_t*>(d_base + och);
     double *hx = reinterpret_cast<double*>(h_base + ox), *hy = reinterpret_cast<double*>(h_base + oy), *hz = reinterpret_cast<double*>(h_base + oz);
     int32_t* ht = reinterpret_cast<int32_t*>(h_base + ot);
     uint8_t* hc = reinterpret_cast<uint8_t*>(h_base + oc);
@@ -1257,8 +1288,8 @@ static int stage_cloud(const double* xyz, const int32_t* cat, const int32_t* tag
         hx[i] = v[0]; hy[i] = v[1]; hz[i] = v[2];
         for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], v[k]); mx[k] = std::max(mx[k], v[k]); }
         ht[i] = tag ? tag[i] : 0;
-        hc[i] = (cat[i] >= 0 && cat[i] < 255) ? (uint8_t)cat[i] : (uint8_t)255;  // 255 = not in the map
     }
+    cats_encode(cat, n, hc, wide ? reinterpret_cast<uint8_t*>(h_base + och) : nullptr);
     for (int k = 0; k < 3; ++k) { cl.bbmin[k] = n ? mn[k] : 0.0; cl.bbmax[k] = n ? mx[k] : 0.0; }
     return LCHD_OK;
 }
@@ -1672,6 +1703,9 @@ static int dense_driver(lchd_ctx* c, const lchd_config* cfg, const int32_t* seq_
     if (cols_a > 65535 || cols_b > 65535)
         return fail(LCHD_EUNSUPPORTED, "dense rows of more than 65535 points are not supported by this build (got %lld / %lld)",
                     (long long)cols_a, (long long)cols_b);
+    if (cfg->n_categories > kMaxCategories)
+        return fail(LCHD_EUNSUPPORTED, "from_coords / from_dmxs take at most %d categories in this build (from_primitives and from_anchors: %d)",
+                    kMaxCategories, kWideCategories);
     // The two structures (SoA coordinates + categories), the weight-function indices and -- for calls of up to kDirectOutPairs
     // rows -- the scores travel through the context's pinned staging block (one asynchronous copy in, none out); nothing is
     // allocated per call.
@@ -1740,6 +1774,9 @@ extern "C" int lchd_from_coords_dev(lchd_ctx* c, lchd_cloud* a, lchd_cloud* b, c
     if (a->n == 0) return LCHD_OK;
     if (!d_out) return fail(LCHD_EVALUE, "null score pointer");
     if (a->n > 65535) return fail(LCHD_EUNSUPPORTED, "dense rows of more than 65535 points are not supported by this build (got %lld)", (long long)a->n);
+    if (c->h_cfg.n_categories > kMaxCategories)
+        return fail(LCHD_EUNSUPPORTED, "from_coords takes at most %d categories in this build (from_primitives and from_anchors: %d)", kMaxCategories,
+                    kWideCategories);
     CTX_GUARD(c);
     bool retry = false;
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -1823,17 +1860,20 @@ extern "C" int lchd_from_anchors(lchd_ctx* c, const lchd_config* cfg, const int3
     const size_t na = (size_t)len_seq_a, nb = (size_t)len_seq_b;
     size_t off = 0;
     auto take = [&](size_t bytes) { off = (off + 255) & ~size_t(255); const size_t o = off; off += bytes; return o; };
-    const size_t o_ka = take(8 * na), o_kb = take(8 * nb), o_ca = take(na), o_cb = take(nb), o_la = take(4), o_lb = take(4), o_wf = take(4);
+    const bool cat16 = cfg->n_categories > kMaxCategories;  // 16-bit category ids in the two lists
+    const size_t cb_ = cat16 ? 2 : 1;
+    const size_t o_ka = take(8 * na), o_kb = take(8 * nb), o_ca = take(cb_ * na), o_cb = take(cb_ * nb), o_la = take(4), o_lb = take(4), o_wf = take(4);
     const size_t in_bytes = off;
     const size_t o_meta = take(sizeof(int4)), o_out = take(sizeof(double));
     if (int rc = grow_io(c, off)) return rc;
     auto stage = [&](size_t o_k, size_t o_c, size_t o_l, const int32_t* seq, const double* d, size_t n) {
         uint64_t* k = reinterpret_cast<uint64_t*>(c->h_io + o_k);
         uint8_t* c8 = reinterpret_cast<uint8_t*>(c->h_io + o_c);
+        uint16_t* c16 = reinterpret_cast<uint16_t*>(c->h_io + o_c);
         for (size_t i = 0; i < n; ++i) {
             const double v = d[i] + 0.0;  // -0.0 -> +0.0
             memcpy(&k[i], &v, 8);
-            c8[i] = (uint8_t)seq[i];      // inside [0, n_categories): checked above
+            if (cat16) c16[i] = (uint16_t)seq[i]; else c8[i] = (uint8_t)seq[i];  // inside [0, n_categories): checked above
         }
         const int32_t len = (int32_t)n;
         memcpy(c->h_io + o_l, &len, 4);
@@ -1846,6 +1886,7 @@ extern "C" int lchd_from_anchors(lchd_ctx* c, const lchd_config* cfg, const int3
     ea.len = reinterpret_cast<int32_t*>(c->d_io + o_la); ea.stride = len_seq_a;
     eb.key = reinterpret_cast<uint64_t*>(c->d_io + o_kb); eb.cat = reinterpret_cast<uint8_t*>(c->d_io + o_cb);
     eb.len = reinterpret_cast<int32_t*>(c->d_io + o_lb); eb.stride = len_seq_b;
+    ea.cat16 = eb.cat16 = cat16 ? 1 : 0;
     hipStream_t s = c->stream;
     if (int rc = begin_pass(c)) return rc;
     c->status_dirty = true;

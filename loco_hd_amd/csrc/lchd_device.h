@@ -6,7 +6,10 @@
 
 namespace lchd {
 
-constexpr int kMaxCategories = 255;   // categories travel as u8 on the device
+constexpr int kMaxCategories = 255;   // categories travel as u8 on the device ...
+constexpr int kWideCategories = 512;  // ... or, for 256 .. 512 categories, as u16 (CloudView::cat_hi, EnvStore::cat16): from_primitives and
+                                      // from_anchors only, through k_env_cells<.., uint16_t> and k_sweep_wide<.., CAT16> (its per-lane
+                                      // category counts, 256 bytes per category, must fit the LDS)
 #ifndef LCHD_SWEEP_EPL
 #define LCHD_SWEEP_EPL 6
 #endif
@@ -97,7 +100,8 @@ struct DevConfig {
 // SoA structure in HBM.
 struct CloudView {
     const double *x, *y, *z;
-    const uint8_t* cat;
+    const uint8_t* cat;       // low byte of the category id
+    const uint8_t* cat_hi;    // high byte (nullptr: every id fits a byte; 255 = not in the category map, with cat_hi: 0xFFFF)
     const int32_t* tag;
     int32_t n;
     const int32_t* sid;   // structure id per atom for a batch of structures (nullptr = one structure)
@@ -142,6 +146,7 @@ struct EnvStore {
     int32_t* len;
     int64_t stride;
     int32_t cdf_keys;  // 1: key = bits of F(distance) for the configuration's single weight function (sweep needs no CDF evaluation)
+    int32_t cat16;     // 1: `cat` holds 16-bit category ids (more than 255 categories): two bytes per point
 };
 
 // One structure (or batch of structures) of a from_primitives pass as the prologue sees it: the inputs, and the arrays the
@@ -186,7 +191,7 @@ struct EnvSides {
     EnvSide s[2];
 };
 bool launch_env_cells(hipStream_t s, int cap, const DevConfig* cfg, bool tag_list, const EnvSide& a, const EnvSide& b, double thr,
-                      DeviceStatus* st);
+                      DeviceStatus* st);   // (EnvStore::cat16 of the sides picks the 16-bit-category instantiation: cap <= 16384)
 // The default capacity (environments of at most kEnvGroupCap points), several environments per wavefront (lchd_env_group.hip).
 // Needs a grid whose cells are at least thr / 2 wide (the search walks the 5 x 5 x 5 neighbourhood), record arrays padded by
 // kEnvGroupRecPad records, fewer than 2^29 records per side and environment slots of at least kEnvGroupCap points.

@@ -33,6 +33,7 @@
 // filled without any inter-workgroup communication.  All arithmetic is f64 like the reference; no MFMA
 // (there is no contraction in this path).
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 
 #include "lchd_device.h"
@@ -144,6 +145,12 @@ constexpr int kBitWordsMax = (kStructAtomsMax + 31) / 32;       // anchor flags 
 // atomic per atom) of the generic path.  The structure owns cells [cell_base, cell_base + cps) and records
 // [base, base + size).  smem: hist[cps] u32 | cid[size] u16 | rank[size] u16; on return hist[] holds the first slot of
 // every cell (relative to `base`) and cid / rank are intact, so position(atom a) = base + hist[cid[a]] + rank[a].
+// category id of atom i: low byte | high byte, or -- a structure without high bytes -- the byte itself, its "not in the map" value
+// 255 widened to 0xFFFF (a configuration with more than 255 categories has a category 255)
+__device__ __forceinline__ uint32_t cat_of_atom(const CloudView& c, int64_t i) {
+    const uint32_t lo = c.cat[i];
+    return c.cat_hi ? (lo | ((uint32_t)c.cat_hi[i] << 8)) : (lo == 255u ? 0xFFFFu : lo);
+}
 template <int NT>
 __device__ __forceinline__ void cell_build_wg(const CloudView& c, const GridView& g, int cps, int64_t base, int size, int64_t cell_base,
                                               bool write_end, CellRec* __restrict__ rec, uint32_t* __restrict__ pos_of,
@@ -204,7 +211,7 @@ __device__ __forceinline__ void cell_build_wg(const CloudView& c, const GridView
             r[u].y = c.y[i];
             r[u].z = c.z[i];
             r[u].tag = (uint32_t)c.tag[i];
-            r[u].cat = c.cat[i];
+            r[u].cat = cat_of_atom(c, i);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -474,7 +481,7 @@ __global__ void k_prep_scatter(PrepSide pa, PrepSide pb, int cells_a, int cells_
             CellRec r;
             r.x = x; r.y = y; r.z = z;
             r.tag = tag;
-            r.cat = c.cat[i];
+            r.cat = cat_of_atom(c, i);
             P.rec[pos] = r;
             P.pos_of[i] = pos;
         }
@@ -571,8 +578,8 @@ int launch_prologue(hipStream_t s, const Tuning& t, const int64_t* anchors, int6
 // Equal keys may come out in any order: ties only ever produce zero-width intervals in the sweep
 // (SURVEY.md section 0), so the score does not depend on it.
 // ------------------------------------------------------------------------------------------------
-template <int NT>
-__device__ __forceinline__ void bitonic_sort_lds(uint64_t* key, uint8_t* val, int n2, int tid) {
+template <int NT, class VT = uint8_t>
+__device__ __forceinline__ void bitonic_sort_lds(uint64_t* key, VT* val, int n2, int tid) {
     for (int k = 2; k <= n2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int t = tid; t < (n2 >> 1); t += NT) {
@@ -583,7 +590,7 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t* key, uint8_t* val, in
                 if (up ? (a > b) : (a < b)) {
                     key[i] = b;
                     key[l] = a;
-                    const uint8_t va = val[i];
+                    const VT va = val[i];
                     val[i] = val[l];
                     val[l] = va;
                 }
@@ -663,7 +670,8 @@ __device__ unsigned long long g_env_stamps[8];
 #else
 #define ESTAMP(i) do { } while (0)
 #endif
-template <int NT, bool TAGLIST>  // TAGLIST: the tag rule is a pair list (binary searches); otherwise one comparison, no branch
+// VT: the category type of the LDS buffer and of the store (uint16_t: more than 255 categories, EnvStore::cat16; no O(n) bucket sort)
+template <int NT, bool TAGLIST, class VT = uint8_t>  // TAGLIST: the tag rule is a pair list (binary searches); otherwise one comparison, no branch
 #ifdef ENV_W8
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 64 ? 8 : 1, NT == 64 ? 8 : 8))) void k_env_cells(
 #else
@@ -677,10 +685,11 @@ const DevConfig* __restrict__ cfgp, EnvSides sides, double thr, int cap, DeviceS
     const GridView g = S.g;
     const AnchorRec* __restrict__ uniq = S.uniq;
     const EnvStore env = S.env;
-    // dynamic LDS: cap * 9 bytes (u64 keys, then u8 categories)
+    // dynamic LDS: cap * (8 + sizeof(VT)) bytes (u64 keys, then the categories)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* key = reinterpret_cast<uint64_t*>(smem);
-    uint8_t* val = smem + (size_t)cap * 8;
+    VT* val = reinterpret_cast<VT*>(smem + (size_t)cap * 8);
+    constexpr bool NARROW = sizeof(VT) == 1;
     __shared__ int count_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t e = (int64_t)blockIdx.x - (side ? sides.s[0].max_envs : 0);
@@ -791,7 +800,7 @@ const DevConfig* __restrict__ cfgp, EnvSides sides, double thr, int cap, DeviceS
                         const int pos = count + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                         if (pos < cap) {
                             key[pos] = d2u(d2);  // the square root is taken after compaction (a sixth of the candidates survive)
-                            val[pos] = (uint8_t)(tc >> 32);
+                            val[pos] = (VT)(tc >> 32);
                         }
                     }
                     count += __popcll(m);
@@ -827,7 +836,7 @@ const DevConfig* __restrict__ cfgp, EnvSides sides, double thr, int cap, DeviceS
                     const int pos = wbase + __popcll(m & ((1ull << lane) - 1ull));
                     if (pos < cap) {
                         key[pos] = d2u(sqrt(d2));
-                        val[pos] = (uint8_t)ccat;
+                        val[pos] = (VT)ccat;
                     }
                 }
             }
@@ -852,7 +861,7 @@ const DevConfig* __restrict__ cfgp, EnvSides sides, double thr, int cap, DeviceS
         return;
     }
     bool sorted = false;
-    if constexpr (NT == 64) {
+    if constexpr (NT == 64 && NARROW) {
         // Typical environments (<= 512 points) are sorted in O(n) by one wavefront: inside a sphere the number of points
         // grows like d^3, so bucket = floor(256 * (d / thr)^3) spreads them almost evenly over 256 buckets (any
         // monotone map is correct; it only has to be balanced to be fast).  LDS histogram with returned slots -> wave
@@ -941,13 +950,13 @@ const DevConfig* __restrict__ cfgp, EnvSides sides, double thr, int cap, DeviceS
             __syncthreads();
         }
         const int n2 = next_pow2(count);
-        for (int i = count + tid; i < n2; i += NT) { key[i] = kPadKey; val[i] = 0; }
+        for (int i = count + tid; i < n2; i += NT) { key[i] = kPadKey; val[i] = (VT)0; }
         __syncthreads();
-        bitonic_sort_lds<NT>(key, val, n2, tid);
+        bitonic_sort_lds<NT, VT>(key, val, n2, tid);
     }
     ESTAMP(2);
     uint64_t* ok_ = env.key + e * env.stride;
-    uint8_t* oc_ = env.cat + e * env.stride;
+    VT* oc_ = reinterpret_cast<VT*>(env.cat) + e * env.stride;
     // categories outside the map are reported HERE (pmf.rs:38-42 raises for a point of a used environment, which is exactly
     // what gets written below) and stored as 0: the sweep kernels do not test categories again
     bool bad = false;
@@ -972,10 +981,10 @@ const DevConfig* __restrict__ cfgp, EnvSides sides, double thr, int cap, DeviceS
                 inv |= act && f < prev;
                 carry = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(f), 63), __builtin_amdgcn_readlane(__double2loint(f), 63));
                 if (act) {
-                    const uint8_t v = val[i];
+                    const VT v = val[i];
                     bad |= (int)v >= cfg.n_categories;
                     ok_[i] = d2u(f);
-                    oc_[i] = (int)v < cfg.n_categories ? v : (uint8_t)0;
+                    oc_[i] = (int)v < cfg.n_categories ? v : (VT)0;
                 }
             }
             written = !__ballot(inv);
@@ -987,10 +996,10 @@ const DevConfig* __restrict__ cfgp, EnvSides sides, double thr, int cap, DeviceS
             else keys_to_cdf_lds<NT>(key, count, tid, cfgp);
         }
         for (int i = tid; i < count; i += NT) {
-            const uint8_t v = val[i];
+            const VT v = val[i];
             bad |= (int)v >= cfg.n_categories;
             ok_[i] = key[i];
-            oc_[i] = (int)v < cfg.n_categories ? v : (uint8_t)0;
+            oc_[i] = (int)v < cfg.n_categories ? v : (VT)0;
         }
     }
     ESTAMP(3);
@@ -1005,6 +1014,11 @@ static void launch_env_cells_nt(hipStream_t s, dim3 grid, size_t lds, bool tag_l
     EnvSides sides;
     sides.s[0] = a;
     sides.s[1] = b;
+    if (a.env.cat16) {
+        if (tag_list) k_env_cells<NT, true, uint16_t><<<grid, NT, lds, s>>>(cfg, sides, thr, cap, st);
+        else k_env_cells<NT, false, uint16_t><<<grid, NT, lds, s>>>(cfg, sides, thr, cap, st);
+        return;
+    }
     if (tag_list) k_env_cells<NT, true><<<grid, NT, lds, s>>>(cfg, sides, thr, cap, st);
     else k_env_cells<NT, false><<<grid, NT, lds, s>>>(cfg, sides, thr, cap, st);
 }
@@ -1078,8 +1092,9 @@ __global__ __launch_bounds__(1024) void k_env_collect(const DevConfig* __restric
 bool launch_env_cells(hipStream_t s, int cap, const DevConfig* cfg, bool tag_list, const EnvSide& a, const EnvSide& b, double thr,
                       DeviceStatus* st) {
     if (a.max_envs + b.max_envs <= 0) return true;
+    const bool cat16 = a.env.cat16 != 0;
     if (cap > 16384 && cap <= 65536 && !(cap & (cap - 1))) {  // collect unsorted, then the global-memory row sort
-        if (!a.raw_key || !b.raw_key) return false;
+        if (!a.raw_key || !b.raw_key || cat16) return false;
         EnvSides sides;
         sides.s[0] = a;
         sides.s[1] = b;
@@ -1095,8 +1110,9 @@ bool launch_env_cells(hipStream_t s, int cap, const DevConfig* cfg, bool tag_lis
         return true;
     }
     if (cap < 64 || cap > 16384 || (cap & (cap - 1))) return false;
+    if (cat16 && cap > 8192) return false;  // (10 bytes per point: 16384 points would need the CU's whole LDS)
     const dim3 grid((unsigned)(a.max_envs + b.max_envs));
-    const size_t lds = (size_t)cap * 9;
+    const size_t lds = (size_t)cap * (cat16 ? 10 : 9);
     if (cap <= 2048) {
         launch_env_cells_nt<64>(s, grid, lds + 16 + 257 * sizeof(uint32_t), tag_list, cfg, a, b, thr, cap, st);
     } else if (cap <= 4096) {
@@ -3020,13 +3036,14 @@ __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs arg
     }
 }
 
-constexpr int kWideMaxCat = 256;
+constexpr int kWideMaxCat = kWideCategories;  // (512: the per-lane count columns, 256 bytes per category, must fit the LDS)
 
 // Many-categories variant (32 < C <= 255): the per-lane category counts live in LDS columns instead of registers, all
 // category loops are runtime loops, and the sqrt tables are read from global memory.  Slower per pair than k_sweep,
 // but independent of the category count in registers.  WPB = anchor pairs (wavefronts) per workgroup.
-template <int MODE, int FMODE, int WPB>
+template <int MODE, int FMODE, int WPB, bool CAT16 = false>  // CAT16: 16-bit category ids in the environment store (EnvStore::cat16)
 __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
+    using CT = typename std::conditional<CAT16, uint16_t, uint8_t>::type;
     constexpr int TILE = kSweepTile;
     constexpr bool LDSTAB = false;
     constexpr bool H2 = (MODE != MODE_GEN);
@@ -3038,7 +3055,7 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
     __shared__ double w_s[kWideMaxCat], sw_s[kWideMaxCat];
     __shared__ uint32_t carry_[WPB][kWideMaxCat];  // per category: counts before the current tile (A | B << 16)
     __shared__ uint64_t sA_[WPB][TILE], sB_[WPB][TILE];
-    __shared__ uint8_t cA_[WPB][TILE], cB_[WPB][TILE];
+    __shared__ CT cA_[WPB][TILE], cB_[WPB][TILE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform => everything derived from it stays scalar
     const DevConfig* __restrict__ cfgp = args.cfg;
@@ -3058,8 +3075,8 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
     __syncthreads();
     uint64_t* sA = sA_[wv];
     uint64_t* sB = sB_[wv];
-    uint8_t* cA = cA_[wv];
-    uint8_t* cB = cB_[wv];
+    CT* cA = cA_[wv];
+    CT* cB = cB_[wv];
     uint32_t* carry = carry_[wv];
     uint32_t* cnt = reinterpret_cast<uint32_t*>(smem_dyn) + (size_t)wv * C * 64 + lane;  // this lane's column: cnt[c * 64]
 
@@ -3089,18 +3106,18 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
             nx = __builtin_amdgcn_readfirstlane(mn.x); ny = __builtin_amdgcn_readfirstlane(mn.y);
             nz = __builtin_amdgcn_readfirstlane(mn.z); nw = __builtin_amdgcn_readfirstlane(mn.w);
         };
-        const int nA = mz & 0xFFFFFF, nB = mw & 0xFFFFFF;
+        const int nA = CAT16 ? (mz & 0xFFFF) : (mz & 0xFFFFFF), nB = CAT16 ? (mw & 0xFFFF) : (mw & 0xFFFFFF);
         if (nA <= 0 || nB <= 0) {  // anchor out of range (flagged by k_mark_anchors) or overflow / empty environment (flagged by K1)
             if (lane == 0) args.out[p] = nan("");
             take_next();
             continue;
         }
         const int64_t ea = mx, eb = my;
-        const int c0a = (mz >> 24) & 255, c0b = (mw >> 24) & 255;  // categories of the two anchors
+        const int c0a = CAT16 ? ((mz >> 16) & 0xFFFF) : ((mz >> 24) & 255), c0b = CAT16 ? ((mw >> 16) & 0xFFFF) : ((mw >> 24) & 255);  // categories of the two anchors
         const uint64_t* __restrict__ kA = args.env_a.key + ea * args.env_a.stride;
         const uint64_t* __restrict__ kB = args.env_b.key + eb * args.env_b.stride;
-        const uint8_t* __restrict__ tA = args.env_a.cat + ea * args.env_a.stride;
-        const uint8_t* __restrict__ tB = args.env_b.cat + eb * args.env_b.stride;
+        const CT* __restrict__ tA = reinterpret_cast<const CT*>(args.env_a.cat) + ea * args.env_a.stride;
+        const CT* __restrict__ tB = reinterpret_cast<const CT*>(args.env_b.cat) + eb * args.env_b.stride;
         const int wfi = args.wf_index ? args.wf_index[p] : 0;
         if (args.wf_index && (wfi < 0 || wfi >= n_wf)) {
             if (lane == 0) { sweep_report(args.hst, ST_BAD_WF); args.out[p] = nan(""); }
@@ -3336,7 +3353,10 @@ static void launch_sweep_wide(hipStream_t s, int n_cat, int64_t n_pairs, int fmo
     } else {
         const unsigned grid = (unsigned)(n_pairs < 8192 ? n_pairs : 8192);
         const size_t dyn = (size_t)n_cat * 256;  // (> 64 KB from 257 categories' worth on: init_device_kernels raised the limit)
-        if (fmode == F_KEY) k_sweep_wide<MODE, F_KEY, 1><<<grid, 64, dyn, s>>>(a);
+        if (a.env_a.cat16) {  // more than 255 categories: 16-bit ids in the store
+            if (fmode == F_KEY) k_sweep_wide<MODE, F_KEY, 1, true><<<grid, 64, dyn, s>>>(a);
+            else k_sweep_wide<MODE, F_ANY, 1, true><<<grid, 64, dyn, s>>>(a);
+        } else if (fmode == F_KEY) k_sweep_wide<MODE, F_KEY, 1><<<grid, 64, dyn, s>>>(a);
         else k_sweep_wide<MODE, F_ANY, 1><<<grid, 64, dyn, s>>>(a);
     }
 }
@@ -3359,13 +3379,20 @@ __global__ void k_pair_meta(SweepArgs args) {
             nA = args.env_a.len[ea];
             nB = args.env_b.len[eb];
             if (nA > 0 && nB > 0) {
-                c0a = args.env_a.cat[ea * args.env_a.stride];
-                c0b = args.env_b.cat[eb * args.env_b.stride];
+                if (args.env_a.cat16) {
+                    c0a = reinterpret_cast<const uint16_t*>(args.env_a.cat)[ea * args.env_a.stride];
+                    c0b = reinterpret_cast<const uint16_t*>(args.env_b.cat)[eb * args.env_b.stride];
+                } else {
+                    c0a = args.env_a.cat[ea * args.env_a.stride];
+                    c0b = args.env_b.cat[eb * args.env_b.stride];
+                }
             } else {
                 nA = nB = 0;
             }
         }
-        args.meta[p] = make_int4((int)ea, (int)eb, nA | (c0a << 24), nB | (c0b << 24));
+        // (16-bit categories, k_sweep_wide only: the environment length -- at most 65535 -- in the low half, the category above it)
+        if (args.env_a.cat16) args.meta[p] = make_int4((int)ea, (int)eb, nA | (c0a << 16), nB | (c0b << 16));
+        else args.meta[p] = make_int4((int)ea, (int)eb, nA | (c0a << 24), nB | (c0b << 24));
         biggest = max(biggest, max(nA, nB));
         // pairs k_sweep_duo takes: everything that fits its tile, and the unusable ones (it writes their NaN); pairs the
         // 8-bit-count sweep takes: both environments of at most 255 points.  Both are counted whichever rule this pass uses:
@@ -3510,6 +3537,8 @@ void init_device_kernels() {
     auto raise = [](const void* fn, int bytes) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); };
     raise(reinterpret_cast<const void*>(&k_env_cells<1024, false>), 16384 * 9);
     raise(reinterpret_cast<const void*>(&k_env_cells<1024, true>), 16384 * 9);
+    raise(reinterpret_cast<const void*>(&k_env_cells<1024, false, uint16_t>), 8192 * 10);
+    raise(reinterpret_cast<const void*>(&k_env_cells<1024, true, uint16_t>), 8192 * 10);
     raise(reinterpret_cast<const void*>(&k_env_rows<1024, true>), (int)((kRowBucketsBig + 1) * sizeof(uint32_t) + 16));
     raise(reinterpret_cast<const void*>(&k_env_rows<1024, false>), 16384 * 9 + 16 + (kRowBucketsSmall + 1) * 4);
     raise(reinterpret_cast<const void*>(&k_env_rows2<1024, 16, 1>), 16384 * 9 + 16 + (kRowBucketsSmall + 1) * 4);
@@ -3525,6 +3554,12 @@ void init_device_kernels() {
     raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_H2U, F_ANY, 1>), 256 * 256);
     raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_H2W, F_KEY, 1>), 256 * 256);
     raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_H2W, F_ANY, 1>), 256 * 256);
+    raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_GEN, F_KEY, 1, true>), kWideCategories * 256);
+    raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_GEN, F_ANY, 1, true>), kWideCategories * 256);
+    raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_H2U, F_KEY, 1, true>), kWideCategories * 256);
+    raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_H2U, F_ANY, 1, true>), kWideCategories * 256);
+    raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_H2W, F_KEY, 1, true>), kWideCategories * 256);
+    raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_H2W, F_ANY, 1, true>), kWideCategories * 256);
     raise(reinterpret_cast<const void*>(&k_prologue_fused), kStructCellsMax * 4 + kStructAtomsMax * 4);  // + ~3 KB static: above 64 KB in total
     raise(reinterpret_cast<const void*>(&k_cells_struct2<1024>), kStructCellsMax * 4 + kStructAtomsMax * 4);
     raise(reinterpret_cast<const void*>(&k_cells_struct2<256>), kStructCellsMax * 4 + kStructAtomsMax * 4);

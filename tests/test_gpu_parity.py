@@ -361,9 +361,61 @@ def test_two_contexts_and_capacity_decay(lh, oracle):
     assert np.max(np.abs(big(lh, second) - want_big)) < TIGHT
 
 
-def test_too_many_categories_is_loud(lh):
+def test_three_hundred_categories(lh, oracle):
+    """The reference's category map is an arbitrary HashMap (/root/reference/src/locohd.rs:312-316).  Beyond 255 categories
+    the ids travel as 16 bits (k_env_cells<.., uint16_t>, k_sweep_wide<.., CAT16>): from_anchors and from_primitives, every
+    statistical-distance family, category weights, a weight-function dictionary, both tag rules.  from_coords / from_dmxs and
+    more than 512 categories stay loud refusals."""
+    rng = np.random.default_rng(61)
+    cats = [f"t{i}" for i in range(300)]
+    n = 500
+    sa, xa = rng.choice(cats, n).tolist(), rng.uniform(0, 22.0, (n, 3))
+    sb, xb = rng.choice(cats, n).tolist(), rng.uniform(0, 22.0, (n, 3))
+    sa[0], sb[0], sa[1], sb[1] = "t299", "t299", "t255", "t256"  # ids on both sides of the one-byte boundary among the anchors
+    tags = [f"r{i // 5}" for i in range(n)]
+    anchors = [(int(i), int(j)) for i, j in zip(rng.integers(0, n, 300), rng.integers(0, n, 300))] + [(0, 0), (1, 1), (0, 1)]
+    w = rng.uniform(0.5, 2.0, 300).tolist()
+    cases = [dict(), dict(category_weights=w), dict(rule={"accept_same": False}),
+             dict(rule={"tag_pairs": {("r1", "r2"), ("r3", "r3"), ("r10", "r40")}, "accepted_pairs": False, "ordered": False}),
+             dict(sd=("Kolmogorov-Smirnov", [])), dict(sd=("Kullback-Leibler", [1e-9])), dict(sd=("Renyi", [1.7, 1e-9])), dict(sd=("Hellinger", [3.0])),
+             dict(sd=("Hellinger", [2.0]), category_weights=w)]
+    for case in cases:
+
+        def run(mod):
+            kw = {}
+            if "category_weights" in case:
+                kw["category_weights"] = case["category_weights"]
+            if "sd" in case:
+                kw["statistical_distance"] = mod.StatisticalDistance(*case["sd"])
+            rule = mod.TagPairingRule(case["rule"]) if "rule" in case else None
+            lchd = mod.LoCoHD(cats, mod.WeightFunction("hyper_exp", [1.0, 0.15]), rule, **kw)
+            out = [np.asarray(lchd.from_primitives(prims(mod, sa, xa, tags), prims(mod, sb, xb, tags), anchors, 8.0)) for _ in range(2)]
+            da, db = np.sort(rng_d.uniform(0, 9, 40)), np.sort(rng_d.uniform(0, 9, 55))
+            da[0] = db[0] = 0.0
+            one = lchd.from_anchors(sa[:40], sb[:55], da.tolist(), db.tolist())
+            return out, one
+
+        rng_d = np.random.default_rng(7)
+        got, got1 = run(lh)
+        rng_d = np.random.default_rng(7)
+        want, want1 = run(oracle)
+        for g in got:
+            assert np.max(np.abs(g - want[0])) < TIGHT, case
+        assert abs(got1 - want1) < TIGHT, case
+    # a weight-function dictionary (the sweep evaluates the CDFs itself)
+    def run_multi(mod):
+        lchd = mod.LoCoHD(cats, {"a": mod.WeightFunction("uniform", [2.0, 8.0]), "b": mod.WeightFunction("kumaraswamy", [1.0, 9.0, 2.0, 3.0])})
+        keyed = [(i, j, "a" if (i + j) % 2 else "b") for i, j in anchors]
+        return np.asarray(lchd.from_primitives(prims(mod, sa, xa), prims(mod, sb, xb), keyed, 8.0))
+    assert np.max(np.abs(run_multi(lh) - run_multi(oracle))) < TIGHT
+    # a label outside the map is still an error; the remaining refusals are loud
+    lchd = lh.LoCoHD(cats, lh.WeightFunction("uniform", [0.0, 4.0]))
+    with pytest.raises(ValueError):
+        lchd.from_primitives(prims(lh, ["t1", "nope"], xa[:2] * 0.01), prims(lh, ["t1", "t2"], xb[:2] * 0.01), [(0, 0)], 8.0)
     with pytest.raises(NotImplementedError):
-        lh.LoCoHD([f"c{i}" for i in range(256)]).from_anchors(["c0"], ["c0"], [0.0], [0.0])
+        lchd.from_coords(sa[:10], sb[:10], xa[:10], xb[:10])
+    with pytest.raises(NotImplementedError):
+        lh.LoCoHD([f"c{i}" for i in range(513)]).from_anchors(["c0"], ["c0"], [0.0], [0.0])
 
 
 def test_error_behaviour(lh):
