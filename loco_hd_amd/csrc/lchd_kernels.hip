@@ -1988,13 +1988,13 @@ __device__ __forceinline__ uint64_t spread8(uint64_t x) {
 //   e is 1, 2, 3 or 4.  Weighted categories take pow_fast for all three.
 //   Renyi: ratio^(alpha - 1) = exp((alpha - 1) ln ratio) through the fast log / exp.
 __device__ __forceinline__ double sd_generic_fast(int kind, double p0, double p1, const double* va, const double* vb, double sa, double sb, int C,
-                                               const double* __restrict__ pow_tab) {
+                                               const double* __restrict__ pow_tab, int tab_half = 65536) {
     const double ia = 1.0 / sa, ib = 1.0 / sb;  // (one reciprocal per side: <= 1 ulp from pmf.rs:78-81's per-category divisions)
     if (kind == SD_HELLINGER) {
         const double e = p0, einv = 1.0 / e;
         const int ie = (e == 1.0 || e == 2.0 || e == 3.0 || e == 4.0) ? (int)e : 0;  // |d|^e by multiplication
         double na1 = 0.0, nb1 = 0.0;
-        if (pow_tab) { na1 = pow_tab[65536 + (int)sa]; nb1 = pow_tab[65536 + (int)sb]; }
+        if (pow_tab) { na1 = pow_tab[tab_half + (int)sa]; nb1 = pow_tab[tab_half + (int)sb]; }
         double dist = 0.0;
 #pragma unroll 1
         for (int c = 0; c < C; ++c) {
@@ -2143,6 +2143,10 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? (CMAX <= LCHD
     constexpr int NT = LDSTAB ? (CNT8 ? 256 + 8 : kSqrtTab + 8) : 1;  // sqrt(k), 1/sqrt(k) for k <= 512 (255) in LDS; otherwise read from the global tables
     __shared__ double t_sqrt[NT], t_rsqrt[NT];
     __shared__ double w_s[32], sw_s[32];
+    // MODE_GEN, Hellinger with a general exponent, environments of at most kSqrtTab points: k^(1/e) and k^(-1/e) for k <= 512 in
+    // LDS (the two look-ups per category and event went to the 1 MB tables in global memory: latency-bound at 2 waves per SIMD)
+    constexpr int kGenTab = kSqrtTab + 8;
+    __shared__ double t_pow[(MODE == MODE_GEN) ? 2 * kGenTab : 1];
     __shared__ uint64_t sA_[WPB][LT], sB_[WPB][LT];
     __shared__ uint8_t cA_[WPB][LT], cB_[WPB][LT];
     // per-lane category counts of the event loop: [side][word][lane] u64 of four 16-bit fields (a lane only ever touches its own)
@@ -2179,6 +2183,15 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? (CMAX <= LCHD
         const double wv_ = tid < C ? cfgp->cat_w[tid] : 0.0;
         w_s[tid] = wv_;
         sw_s[tid] = sqrt(wv_);
+    }
+    bool gen_lds = false;
+    if constexpr (MODE == MODE_GEN) {
+        gen_lds = args.gen_tab && cfgp->pow_tab && args.env_a.stride <= kSqrtTab && args.env_b.stride <= kSqrtTab;  // (wave-uniform)
+        if (gen_lds)
+            for (int k = tid; k < kGenTab; k += 64 * WPB) {
+                t_pow[k] = cfgp->pow_tab[k];
+                t_pow[kGenTab + k] = cfgp->pow_tab[65536 + k];
+            }
     }
     __syncthreads();
     uint64_t* sA = sA_[wv];
@@ -2481,12 +2494,32 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? (CMAX <= LCHD
                     }
                     return dist;
                 }
+                if constexpr (MODE == MODE_GEN) {
+                    // Hellinger with exponent 1, 2, 3 or 4, unit weights, environments inside the LDS power tables: k^(1/e) from
+                    // the tables, |x - y|^e by multiplication -- no transcendental per category, so the per-category code is a dozen
+                    // instructions and can be unrolled over the slots straight from the registers (the runtime-loop form below
+                    // goes through a scratch copy of the counts)
+                    if (gen_lds && kind == SD_HELLINGER && (prm0 == 1.0 || prm0 == 2.0 || prm0 == 3.0 || prm0 == 4.0)) {
+                        const int ie = (int)prm0;
+                        const double na1 = t_pow[kGenTab + (int)sa_], nb1 = t_pow[kGenTab + (int)sb_];
+                        double dist = 0.0;
+#pragma unroll
+                        for (int c = 0; c < CMAX; ++c) {
+                            const double d = fabs(t_pow[(int)va[c]] * na1 - t_pow[(int)vb[c]] * nb1);  // (padded slots: |0 - 0|)
+                            dist += ie == 1 ? d : (ie == 2 ? d * d : (ie == 3 ? d * d * d : (d * d) * (d * d)));
+                        }
+                        return pow_fast(dist / 2.0, 1.0 / prm0);
+                    }
+                }
                 // Hellinger with a general exponent, Renyi: runtime loops over a scratch copy of the weighted counts (unrolled per
                 // category slot these branches tripled the kernel's size; as an out-of-line call the register saves cost more
                 // than the arithmetic)
                 double ca_[CMAX], cb_[CMAX];
 #pragma unroll
                 for (int c = 0; c < CMAX; ++c) { ca_[c] = va[c]; cb_[c] = vb[c]; }
+                if constexpr (MODE == MODE_GEN) {
+                    if (gen_lds) return sd_generic_fast(kind, prm0, prm1, ca_, cb_, sa_, sb_, C, t_pow, kGenTab);
+                }
                 return sd_generic_fast(kind, prm0, prm1, ca_, cb_, sa_, sb_, C, args.gen_tab ? cfgp->pow_tab : nullptr);
             }
         };
