@@ -161,6 +161,7 @@ struct lchd_ctx {
     // configuration
     bool cfg_set = false;
     bool hellinger2 = false, unit_weights = false, wf_pow = false;  // which sweep kernel variant applies
+    int sd_fast = 0;  // Kullback-Leibler (1) / Renyi (2) with parameters the O(1)-per-event sweep handles (lchd_sweep_inc.hip)
     DevConfig h_cfg{};
     DevConfig* d_cfg = nullptr;
     char* d_blob = nullptr;
@@ -273,6 +274,7 @@ static Tuning tuning_from_env() {  // the ONLY place that reads LCHD_* hooks (te
     t.no_env_group = getenv("LCHD_NO_ENV_GROUP") != nullptr;
     t.env_apw = env_int("LCHD_ENV_APW", 0);
     t.sweep_grid = env_int("LCHD_SWEEP_GRID", 0);
+    t.no_sd_inc = getenv("LCHD_NO_SD_INC") != nullptr;
     t.force_cmax = env_int("LCHD_FORCE_CMAX", 0);
     t.cap_hint = env_int("LCHD_CAP_HINT", 0);
     return t;
@@ -499,6 +501,19 @@ extern "C" int lchd_ctx_set_config(lchd_ctx* c, const lchd_config* cfg) {
     c->h_cfg = h;
     c->hellinger2 = (cfg->sd_kind == LCHD_SD_HELLINGER && cfg->sd_params[0] == 2.0);
     c->unit_weights = std::all_of(cfg->category_weights, cfg->category_weights + C, [](double v) { return v == 1.0; });
+    // k_sweep_inc drops terms of second order in eps * (largest count): eps <= 1e-9 keeps them below 3e-13.  Renyi: a moderate order
+    // (the tables hold k^alpha for k <= 512) and a finite eps^(1 - alpha); alpha = 1 is the Kullback-Leibler form (:36-38).
+    c->sd_fast = 0;
+    if (c->unit_weights) {
+        if (cfg->sd_kind == LCHD_SD_KULLBACK_LEIBLER && cfg->sd_params[0] > 0.0 && cfg->sd_params[0] <= 1e-9) c->sd_fast = 1;
+        if (cfg->sd_kind == LCHD_SD_RENYI && cfg->sd_params[1] > 0.0 && cfg->sd_params[1] <= 1e-9) {
+            const double al = cfg->sd_params[0];
+            if (al == 1.0) c->sd_fast = 1;
+            else if (al >= 0.01 && al <= 20.0 && std::isfinite(std::pow(cfg->sd_params[1], 1.0 - al)) && std::pow(cfg->sd_params[1], 1.0 - al) < 1e250 &&
+                     cfg->sd_params[1] * 512.0 * std::max(1.0, std::fabs(al - 1.0)) <= 1e-6)
+                c->sd_fast = 2;
+        }
+    }
     c->wf_pow = false;
     for (int i = 0; i < cfg->n_weight_functions; ++i)
         c->wf_pow = c->wf_pow || cfg->weight_functions[i].kind == LCHD_WF_DAGUM || cfg->weight_functions[i].kind == LCHD_WF_KUMARASWAMY ||
@@ -852,6 +867,7 @@ static void fill_sweep_args(lchd_ctx* c, SweepArgs& sw) {
     sw.st = c->d_status;
     sw.hst = c->h_status;
     sw.seq = c->seq;
+    sw.sd_fast = c->tune.no_sd_inc ? 0 : c->sd_fast;
     sw.sqrt_tab = c->d_tabs;
     sw.rsqrt_tab = c->d_tabs + 65536;
     sw.done = c->d_done;

@@ -70,6 +70,7 @@ struct Tuning {
     bool no_count8 = false;         // LCHD_NO_COUNT8: never the 8-bit-count sweep
     bool no_tables = false;         // LCHD_NO_SD_TABLES: generic distances without the per-launch power / log tables
     bool no_env_group = false;      // LCHD_NO_ENV_GROUP: environments of the default capacity through k_env_cells (one per wavefront) too
+    bool no_sd_inc = false;         // LCHD_NO_SD_INC: Kullback-Leibler / Renyi through the generic sweep even where k_sweep_inc applies
     int sweep_grid = 0;             // LCHD_SWEEP_GRID: most workgroups of a sweep launch (0: 8192)
     int env_apw = 0;                // LCHD_ENV_APW: anchors per wavefront of k_env_group (0: chosen from the number of anchors)
     int force_cmax = 0;             // LCHD_FORCE_CMAX: at least this many category slots
@@ -254,6 +255,7 @@ struct SweepArgs {
                               // environments <= 255 points, the 8-bit-count k_sweep); the indirect k_sweep takes the others
     int32_t gen_tab;          // set by launch_sweep: MODE_GEN may use power tables (Hellinger with a general exponent, unit category weights)
     int32_t forced;           // set by launch_sweep: the host picked the sweep kernels (hint from the previous pass): no device-side decision
+    int32_t sd_fast;          // the configuration qualifies for k_sweep_inc (lchd_sweep_inc.hip): 0 no, 1 Kullback-Leibler form, 2 Renyi form
 };
 // sweep_hint: 0 = unknown (launch every candidate kernel, the device decides from the pair records); otherwise what
 // k_pair_meta counted in the previous pass of this configuration: 4 | 1 (pairs of at most 224 merged events were the
@@ -264,6 +266,9 @@ struct SweepArgs {
 // launch was left out: the caller must check this pass's counts, HostStatus::n_duo / n_c8 against the number of pairs).
 int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinger2, bool unit_weights, bool wf_pow, int sweep_hint,
                  const SweepArgs& a);
+// Kullback-Leibler / Renyi in O(1) per event (lchd_sweep_inc.hip): unit weights, CDF-keyed environments of at most 512 points, tiny eps;
+// reads the pair records of k_pair_meta.  kind: SweepArgs::sd_fast.
+void launch_sweep_inc(hipStream_t s, int kind, int cmax, const SweepArgs& a);
 // trajectory frames: replicate the template's labels / unpack [frames][atoms][3] into SoA + bounding box keys
 void launch_frames_labels(hipStream_t s, const uint8_t* tcat, const int32_t* ttag, int64_t n_tmpl, int32_t n_frames, uint8_t* cat,
                           int32_t* tag, int32_t* sid);

@@ -3553,8 +3553,10 @@ int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinge
             if (hint == 1) return info;
         }
     }
-    if (!hellinger2) launch_sweep_f<MODE_GEN, false>(s, cmax, grid, fmode, a);
-    else if (unit_weights) {
+    if (!hellinger2) {
+        if (a.sd_fast && unit_weights && small && fmode == F_KEY && !a.wf_index && cmax <= 32) launch_sweep_inc(s, a.sd_fast, cmax, a);
+        else launch_sweep_f<MODE_GEN, false>(s, cmax, grid, fmode, a);
+    } else if (unit_weights) {
         if (small) launch_sweep_f<MODE_H2U, true>(s, cmax, grid, fmode, a);
         else launch_sweep_f<MODE_H2U, false>(s, cmax, grid, fmode, a);
     } else {
