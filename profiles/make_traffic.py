@@ -11,7 +11,9 @@ import csv
 import json
 import sys
 
-DOMINANT = {"c2a": "k_sweep<12", "c5": "k_sweep<28", "c4": "k_env_cells<64", "c3": "k_sweep_duo<8>", "c2b": "k_env_rows2<1024, 10"}
+# (c4: since round 3 the sweep is the longer phase; `c4_env`, `c5_env` describe the environment kernel of those workloads)
+DOMINANT = {"c2a": "k_sweep<12", "c5": "k_sweep<28", "c4": "k_sweep_duo<8>", "c3": "k_sweep_duo<8>", "c2b": "k_env_rows2<1024, 10",
+            "c4_env": "k_env_group<false, 320", "c5_env": "k_env_group<false, 320"}
 
 
 def main(workload, summary, stats):

@@ -96,9 +96,13 @@ configs = {
     "hellinger2_category_weights": dict(category_weights=list(np.linspace(0.5, 2.0, w["C"]))),
     "two_weight_functions": dict(w_func={"a": lh.WeightFunction("hyper_exp", [1.0, 0.1]), "b": lh.WeightFunction("uniform", [3.0, 10.0])}),
     "kolmogorov_smirnov": dict(statistical_distance=lh.StatisticalDistance("Kolmogorov-Smirnov", [])),
-    "kullback_leibler": dict(statistical_distance=lh.StatisticalDistance("Kullback-Leibler", [1e-10])),
+    "kullback_leibler": dict(statistical_distance=lh.StatisticalDistance("Kullback-Leibler", [1e-10])),  # eps <= 1e-9: k_sweep_inc, O(1) per event
     "renyi_2.4": dict(statistical_distance=lh.StatisticalDistance("Renyi", [2.4, 1e-10])),
+    "renyi_0.5": dict(statistical_distance=lh.StatisticalDistance("Renyi", [0.5, 1e-10])),
+    "kullback_leibler_eps_1e-3": dict(statistical_distance=lh.StatisticalDistance("Kullback-Leibler", [1e-3])),  # the generic per-category sweep
+    "renyi_2.4_eps_1e-3": dict(statistical_distance=lh.StatisticalDistance("Renyi", [2.4, 1e-3])),
     "hellinger_exponent_3": dict(statistical_distance=lh.StatisticalDistance("Hellinger", [3.0])),
+    "hellinger_exponent_2.5": dict(statistical_distance=lh.StatisticalDistance("Hellinger", [2.5])),
 }
 res["c2a_variants_sweep_ms"] = {}
 for k, kw in configs.items():
