@@ -273,6 +273,7 @@ static Tuning tuning_from_env() {  // the ONLY place that reads LCHD_* hooks (te
     t.no_tables = getenv("LCHD_NO_SD_TABLES") != nullptr;
     t.no_env_group = getenv("LCHD_NO_ENV_GROUP") != nullptr;
     t.env_apw = env_int("LCHD_ENV_APW", 0);
+    t.env_small = env_int("LCHD_ENV_GROUP_SMALL", -1);
     t.sweep_grid = env_int("LCHD_SWEEP_GRID", 0);
     t.no_sd_inc = getenv("LCHD_NO_SD_INC") != nullptr;
     t.force_cmax = env_int("LCHD_FORCE_CMAX", 0);
@@ -945,7 +946,7 @@ static int prims_enqueue(lchd_ctx* c) {
         const int by_size = c->last_biggest > 0 && c->last_biggest <= 140 ? 4 : (c->last_biggest > kEnvGroupSmallUpTo ? 1 : 2);
         const int apw = c->tune.env_apw > 0 ? c->tune.env_apw
                                             : (int)std::max<int64_t>(1, std::min<int64_t>(by_size, (max_env_a + max_env_b) / 8192));
-        P.group_small = c->group_small;
+        P.group_small = c->tune.env_small >= 0 ? (c->tune.env_small != 0 && c->last_biggest <= kEnvGroupCapSmall) : c->group_small;
         if (!launch_env_group(s, c->d_cfg, tag_list, P.group_small, esa, esb, thr, apw, c->d_status))
             return fail(LCHD_EDEVICE, "the grouped environment kernel rejected its launch configuration");
     } else if (!launch_env_cells(s, cap, c->d_cfg, tag_list, esa, esb, thr, c->d_status))

@@ -72,6 +72,7 @@ struct Tuning {
     bool no_env_group = false;      // LCHD_NO_ENV_GROUP: environments of the default capacity through k_env_cells (one per wavefront) too
     bool no_sd_inc = false;         // LCHD_NO_SD_INC: Kullback-Leibler / Renyi through the generic sweep even where k_sweep_inc applies
     int sweep_grid = 0;             // LCHD_SWEEP_GRID: most workgroups of a sweep launch (0: 8192)
+    int env_small = -1;             // LCHD_ENV_GROUP_SMALL: 0 / 1 forces the regular / the small instantiation of k_env_group (-1: from the previous pass)
     int env_apw = 0;                // LCHD_ENV_APW: anchors per wavefront of k_env_group (0: chosen from the number of anchors)
     int force_cmax = 0;             // LCHD_FORCE_CMAX: at least this many category slots
     int cap_hint = 0;               // LCHD_CAP_HINT: first environment capacity to try

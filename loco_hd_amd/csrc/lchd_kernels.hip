@@ -2111,6 +2111,9 @@ __device__ unsigned long long g_sweep_stamps[8];
 // tile and to keep per lane, and 3 KB less LDS per wavefront, which lets the many-slot variants run at 3 waves per SIMD
 // instead of 2.  Pairs with a larger environment are left to the INDIRECT instantiation of the 16-bit kernel.
 template <int CMAX, int MODE, int FMODE, bool LDSTAB, bool INDIRECT = false, bool INLINE_META = false, bool CNT8 = false>
+#ifndef LCHD_DENSE_PARTTAB
+#define LCHD_DENSE_PARTTAB 1024   // entries of the partial sqrt table of the sweeps without full LDS tables (0: none)
+#endif
 #ifndef LCHD_EXACT_H2_LOOP
 #define LCHD_EXACT_H2_LOOP 1
 #endif
@@ -2142,6 +2145,9 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? (CMAX <= LCHD
     constexpr int NV = H2 ? 1 : CMAX;     // only the generic path keeps per-category values in registers
     constexpr int NT = LDSTAB ? (CNT8 ? 256 + 8 : kSqrtTab + 8) : 1;  // sqrt(k), 1/sqrt(k) for k <= 512 (255) in LDS; otherwise read from the global tables
     __shared__ double t_sqrt[NT], t_rsqrt[NT];
+    constexpr bool PARTTAB = !LDSTAB && H2_ && (LCHD_DENSE_PARTTAB != 0);
+    constexpr int kPartTab = LCHD_DENSE_PARTTAB > 0 ? LCHD_DENSE_PARTTAB : 1;
+    __shared__ double t_part[PARTTAB ? kPartTab : 1];
     __shared__ double w_s[32], sw_s[32];
     // MODE_GEN, Hellinger with a general exponent, environments of at most kSqrtTab points: k^(1/e) and k^(-1/e) for k <= 512 in
     // LDS (the two look-ups per category and event went to the 1 MB tables in global memory: latency-bound at 2 waves per SIMD)
@@ -2179,6 +2185,8 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? (CMAX <= LCHD
             t_sqrt[k] = g_sqrt[k];
             t_rsqrt[k] = g_rsqrt[k];
         }
+    if constexpr (PARTTAB)
+        for (int k = tid; k < kPartTab; k += 64 * WPB) t_part[k] = g_sqrt[k];
     if (tid < 32) {
         const double wv_ = tid < C ? cfgp->cat_w[tid] : 0.0;
         w_s[tid] = wv_;
@@ -2204,7 +2212,13 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? (CMAX <= LCHD
 #if LCHD_BIG_SQRT_COMPUTE
     // environments beyond the LDS tables: sqrt(count) is computed (rsq seed + Goldschmidt, <= 1 ulp from the table value)
     // instead of being fetched from the 65536-entry global tables -- four dependent L2 round trips per event otherwise
-    auto sqrt_cnt = [&](int cnt) -> double { if constexpr (LDSTAB) return t_sqrt[cnt]; else return sqrt_unit((double)cnt); };
+    // (dense rows: counts below kPartTab -- per-category counts of a 10^4-point row with ten categories stay there until the row's
+    //  last tiles -- come from a partial LDS table, larger ones are computed; a per-lane branch, both arms only near a row's end)
+    auto sqrt_cnt = [&](int cnt) -> double {
+        if constexpr (LDSTAB) return t_sqrt[cnt];
+        else if constexpr (PARTTAB) { if (cnt < kPartTab) return t_part[cnt]; else return sqrt_unit((double)cnt); }
+        else return sqrt_unit((double)cnt);
+    };
     auto rsqrt_cnt = [&](int cnt) -> double {
         if constexpr (LDSTAB) return t_rsqrt[cnt];
         else {
