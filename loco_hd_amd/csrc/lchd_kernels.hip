@@ -1843,6 +1843,9 @@ enum { F_KEY = 0, F_FAST = 1, F_ANY = 2 };
 #ifndef LCHD_HEADS_REREAD
 #define LCHD_HEADS_REREAD 1   // k_sweep: both list heads are re-read from LDS after every event
 #endif
+#ifndef LCHD_CAT_HEADS
+#define LCHD_CAT_HEADS 1      // k_sweep / k_sweep_duo: the categories of both list heads are read together with their keys
+#endif
 #ifndef LCHD_BRANCHFREE_HEADS
 #define LCHD_BRANCHFREE_HEADS 1
 #endif
@@ -2671,6 +2674,9 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? (CMAX <= LCHD
             int i = i0, j = j0;
 #if LCHD_HEADS_REREAD
             uint64_t ka = sA[i], kb = sB[j];  // both heads are re-read after every event; run ends are tested on the indices
+#if LCHD_CAT_HEADS
+            int cta = cA[i], ctb = cB[j];     // ... and so are their categories: the event's category is a select, not an LDS round trip behind takeA
+#endif
 #else
             uint64_t ka = (i < i1) ? sA[i] : kPadKey, kb = (j < j1) ? sB[j] : kPadKey;
 #endif
@@ -2684,11 +2690,19 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? (CMAX <= LCHD
                     // the selects that steer a single refill into the right head register (the kernel is VALU-issue bound).
                     const bool takeA = (i < i1) & ((j >= j1) | (ka <= kb));
                     const uint64_t key = takeA ? ka : kb;
+#if LCHD_CAT_HEADS
+                    const int ct = takeA ? cta : ctb;
+#else
                     const int ct = (takeA ? cA : cB)[takeA ? i : j];
+#endif
                     i += takeA ? 1 : 0;
                     j += takeA ? 0 : 1;
                     ka = sA[i];  // (one past the run's end at most: inside the tile buffers, never used)
                     kb = sB[j];
+#if LCHD_CAT_HEADS
+                    cta = cA[i];
+                    ctb = cB[j];
+#endif
 #else
                     const bool takeA = (ka <= kb);  // an exhausted list shows the pad key (> every real key)
                     const uint64_t key = takeA ? ka : kb;
@@ -2850,44 +2864,58 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? (CMAX <= LCHD
 // host launches this kernel AND k_sweep; k_pair_meta counts the qualifying pairs (DeviceStatus::n_small): when they are
 // the majority this kernel sweeps them and k_sweep only the rest, otherwise this kernel returns at once.
 // ------------------------------------------------------------------------------------------------
-constexpr int kDuoTile = 224;  // merged events per pair: 32 lanes x 7 (two teams x four waves + the tables = 40 704 B: 4 workgroups/CU)
-__device__ __forceinline__ uint32_t half_incl_scan_u32(uint32_t x) {  // inclusive scan inside each 32-lane half
+constexpr int kDuoTile = 224;  // merged events per pair: 16 lanes x 14
+#ifndef LCHD_DUO_TL
+#define LCHD_DUO_TL 16   // lanes per pair of k_sweep_duo (32: two pairs per wavefront, the round-1 form; 16: four)
+#endif
+// inclusive scan / sum inside each team of TL consecutive lanes (TL = 16: one DPP row; 32: two rows joined by row_bcast:15)
+template <int TL>
+__device__ __forceinline__ uint32_t team_incl_scan_u32(uint32_t x) {
     int v = (int)x;
     v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
     v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
     v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
     v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    if constexpr (TL == 32) v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
     return (uint32_t)v;
 }
-__device__ __forceinline__ uint64_t half_incl_scan_fields(uint64_t x) {
-    const uint32_t lo = half_incl_scan_u32((uint32_t)x), hi = half_incl_scan_u32((uint32_t)(x >> 32));
+template <int TL>
+__device__ __forceinline__ uint64_t team_incl_scan_fields(uint64_t x) {
+    const uint32_t lo = team_incl_scan_u32<TL>((uint32_t)x), hi = team_incl_scan_u32<TL>((uint32_t)(x >> 32));
     return ((uint64_t)hi << 32) | lo;
 }
-__device__ __forceinline__ double half_sum_f64(double v) {  // lanes 31 and 63 end up with the sum of their half
+template <int TL>
+__device__ __forceinline__ double team_sum_f64(double v) {  // the last lane of every team ends up with the team's sum
     v += dpp_mov_f64_or_zero<0x111, 0xf>(v);
     v += dpp_mov_f64_or_zero<0x112, 0xf>(v);
     v += dpp_mov_f64_or_zero<0x114, 0xf>(v);
     v += dpp_mov_f64_or_zero<0x118, 0xf>(v);
-    v += dpp_mov_f64_or_zero<0x142, 0xa>(v);
+    if constexpr (TL == 32) v += dpp_mov_f64_or_zero<0x142, 0xa>(v);
     return v;
 }
 
-template <int CMAX>
+// (the name is historic: round 1 swept TWO pairs per wavefront; with TL = 16 a wavefront sweeps FOUR -- the per-tile prologue, which
+// is two thirds of this kernel's instructions at ~150 events per pair, is shared by twice as many pairs, the event loop costs the
+// same per pair: C3 459 -> see DESIGN section 4)
+template <int CMAX, int TL = LCHD_DUO_TL>
 __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs args) {
-    constexpr int EPL = kDuoTile / 32, TILE = kDuoTile, WPB = kSweepWaves;
+    static_assert(TL == 16 || TL == 32, "a team is one or two DPP rows");
+    constexpr int TEAMS = 64 / TL, EPL = kDuoTile / TL, TILE = kDuoTile, WPB = kSweepWaves;
     // category counts as 8-bit fields: a pair of this kernel has at most kDuoTile = 224 merged events, so no count exceeds 225
     // (one word per side up to 8 category slots, two up to 16: half the scans and no word select for the common 8-slot case)
     constexpr int FPW = 8, FB = 8;
     constexpr int NW = (CMAX + FPW - 1) / FPW;  // u64 words of count fields per side (CMAX <= 16: one word of 4-bit chunk fields)
     static_assert(kDuoTile + 1 < 256, "8-bit count fields");
-    static_assert(kDuoTile == kDuoTileFwd && EPL <= 15, "4-bit chunk-local counters");
+    static_assert(kDuoTile == kDuoTileFwd && EPL * TL == kDuoTile && EPL <= 15, "4-bit chunk-local counters");
     constexpr int NT = 256 + 8;  // (no count and no total of this kernel's pairs exceeds 226)
+    // 4-bit chunk-local fields, one per category slot: 32 bits hold them up to 8 slots (half the selects and adds of a 64-bit word)
+    using H4 = typename std::conditional<(CMAX <= 8), uint32_t, uint64_t>::type;
     __shared__ double t_sqrt[NT], t_rsqrt[NT];
-    __shared__ uint64_t sA_[WPB][2][TILE], sB_[WPB][2][TILE];
-    __shared__ uint8_t cA_[WPB][2][TILE], cB_[WPB][2][TILE];
+    // one buffer per team: list A's points, then list B's (at most TILE together; + the spare entries the head re-reads may touch)
+    __shared__ uint64_t s_[WPB][TEAMS][TILE + 2];
+    __shared__ uint8_t c_[WPB][TEAMS][TILE + 8];
     if (!args.forced && 2 * args.st->n_small < (unsigned long long)args.n_pairs) return;  // mostly larger pairs: k_sweep sweeps everything
-    const int tid = threadIdx.x, lane = tid & 63, tl = lane & 31, team = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, tl = lane & (TL - 1), team = lane / TL;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const DevConfig* __restrict__ cfgp = args.cfg;
     const double Finf0 = cfgp->wf_finf[0];
@@ -2896,14 +2924,12 @@ __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs arg
         t_rsqrt[k] = args.rsqrt_tab[k];
     }
     __syncthreads();
-    uint64_t* sA = sA_[wv][team];
-    uint64_t* sB = sB_[wv][team];
-    uint8_t* cA = cA_[wv][team];
-    uint8_t* cB = cB_[wv][team];
+    uint64_t* sA = s_[wv][team];
+    uint8_t* cA = c_[wv][team];
     auto field = [&](const uint64_t (&ex)[NW], int c) -> int { return (int)((ex[c / FPW] >> ((c % FPW) * FB)) & 0xFFull); };
 
-    const int64_t pstride = (int64_t)gridDim.x * WPB * 2;
-    for (int64_t pb = ((int64_t)blockIdx.x * WPB + wv) * 2; pb < args.n_pairs; pb += pstride) {
+    const int64_t pstride = (int64_t)gridDim.x * WPB * TEAMS;
+    for (int64_t pb = ((int64_t)blockIdx.x * WPB + wv) * TEAMS; pb < args.n_pairs; pb += pstride) {
         const int64_t p = pb + team;
         const bool live = p < args.n_pairs;
         const int4 m = args.meta[live ? p : pb];
@@ -2918,38 +2944,39 @@ __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs arg
         const uint8_t* __restrict__ tB = args.env_b.cat + (int64_t)m.y * args.env_b.stride;
         const double F0 = valid ? u2d(kA[0]) : 0.0;            // F(0): both anchors sit at distance 0
         const double H0 = (c0a == c0b) ? 0.0 : 1.0;            // two point masses
+        uint64_t* sB = sA + mA;
+        uint8_t* cB = cA + mA;
 
         wave_sync_lds();  // the previous pairs' tiles are fully consumed
-        {
-            uint64_t rkA[EPL], rkB[EPL];
-            uint8_t rcA[EPL], rcB[EPL];
+        {   // stage [A's points | B's points]: entry t of the buffer is A[1 + t] or B[1 + t - mA]; all loads before the first LDS write.
+            // One predicate for the whole team (the pair is swept here), none per entry: an entry beyond T re-reads the pair's last
+            // point (index clamped: inside the row) and lands in the buffer's unused tail (t < TILE).
+            uint64_t rk[EPL];
+            uint8_t rc[EPL];
+            const uint64_t* kBs = kB - mA;
+            const uint8_t* tBs = tB - mA;
 #pragma unroll
-            for (int u = 0; u < EPL; ++u) {
-                const int t = tl + 32 * u;
-                rkA[u] = t < mA ? kA[1 + t] : 0ull;
-                rcA[u] = t < mA ? tA[1 + t] : (uint8_t)0;
+            for (int u = 0; u < EPL; ++u) { rk[u] = 0ull; rc[u] = 0; }
+            if (valid) {
+#pragma unroll
+                for (int u = 0; u < EPL; ++u) {
+                    const int t = min(tl + TL * u, T - 1);  // (T = 0: entry 0 of list A's row, the anchor)
+                    const bool isA = t < mA;
+                    rk[u] = (isA ? kA : kBs)[1 + t];
+                    rc[u] = (isA ? tA : tBs)[1 + t];
+                }
             }
 #pragma unroll
             for (int u = 0; u < EPL; ++u) {
-                const int t = tl + 32 * u;
-                rkB[u] = t < mB ? kB[1 + t] : 0ull;
-                rcB[u] = t < mB ? tB[1 + t] : (uint8_t)0;
-            }
-#pragma unroll
-            for (int u = 0; u < EPL; ++u) {
-                const int t = tl + 32 * u;
-                if (t < mA) { sA[t] = rkA[u]; cA[t] = rcA[u]; }
-            }
-#pragma unroll
-            for (int u = 0; u < EPL; ++u) {
-                const int t = tl + 32 * u;
-                if (t < mB) { sB[t] = rkB[u]; cB[t] = rcB[u]; }
+                const int t = tl + TL * u;
+                sA[t] = rk[u];
+                cA[t] = rc[u];
             }
         }
         wave_sync_lds();
 
         // lane tl of a team owns merged events [d0, d1) of its pair
-        const int epl = (T + 31) >> 5;  // <= EPL
+        const int epl = (T + TL - 1) / TL;  // <= EPL
         const int d0 = min(tl * epl, T), d1 = min(d0 + epl, T);
         const int i1 = merge_path(sA, mA, sB, mB, d1);
         int i0 = __builtin_amdgcn_update_dpp(i1, i1, 0x138, 0xf, 0xf, false);  // wave_shr:1
@@ -2957,21 +2984,21 @@ __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs arg
         const int j0 = d0 - i0, j1 = d1 - i1;
 
         // pass 1: 4-bit-per-category histogram of the lane's chunk
-        uint64_t hA = 0, hB = 0;
+        H4 hA = 0, hB = 0;
 #if LCHD_PASS1_FUSED
         {   // one fixed-trip loop over the chunk's points, A's run first (see k_sweep)
             const int nAl = i1 - i0, nl = d1 - d0;
             const uint8_t* pa_ = cA + i0;
             const uint8_t* pb_ = cB + (j0 - nAl);
-            uint64_t hT = 0;
+            H4 hT = 0;
 #pragma unroll
             for (int m = 0; m < EPL; ++m) {
-                if (m < epl) {  // wave-uniform? no: epl differs between the two teams -- the test is per lane, the reads stay in range
+                if (m < epl) {  // wave-uniform? no: epl differs between the teams -- the test is per lane, the reads stay in range
                     const bool isA = m < nAl;
                     const int ct = (isA ? pa_ : pb_)[m < nl ? m : 0];
-                    const uint64_t inc = (m < nl) ? (1ull << ((ct & 15) * 4)) : 0ull;
+                    const H4 inc = (m < nl) ? ((H4)1 << ((ct & 15) * 4)) : (H4)0;
                     hT += inc;
-                    hA += isA ? inc : 0ull;
+                    hA += isA ? inc : (H4)0;
                 }
             }
             hB = hT - hA;
@@ -2979,19 +3006,19 @@ __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs arg
 #else
         for (int i = i0; i < i1; ++i) {
             const int ct = cA[i];
-            hA += 1ull << ((ct & 15) * 4);
+            hA += (H4)1 << ((ct & 15) * 4);
         }
         for (int j = j0; j < j1; ++j) {
             const int ct = cB[j];
-            hB += 1ull << ((ct & 15) * 4);
+            hB += (H4)1 << ((ct & 15) * 4);
         }
 #endif
         // packed counts at the start of the chunk: the anchors + an exclusive scan over the team's lanes
         uint64_t exA[NW], exB[NW];
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
-            const uint64_t va_ = spread8(hA >> (32 * k)), vb_ = spread8(hB >> (32 * k));
-            const uint64_t sa_ = half_incl_scan_fields(va_), sb_ = half_incl_scan_fields(vb_);
+            const uint64_t va_ = spread8((uint64_t)hA >> (32 * k)), vb_ = spread8((uint64_t)hB >> (32 * k));
+            const uint64_t sa_ = team_incl_scan_fields<TL>(va_), sb_ = team_incl_scan_fields<TL>(vb_);
             exA[k] = (((c0a / FPW) == k) ? (1ull << ((c0a % FPW) * FB)) : 0ull) + sa_ - va_;
             exB[k] = (((c0b / FPW) == k) ? (1ull << ((c0b % FPW) * FB)) : 0ull) + sb_ - vb_;
         }
@@ -3010,12 +3037,31 @@ __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs arg
 
         // pass 2 (same scheme as k_sweep): both list heads in registers, chunk-local additions in 4-bit fields
         int i = i0, j = j0;
+#if LCHD_CAT_HEADS
+        uint64_t ka = sA[i], kb = sB[j];
+        int cta = cA[i], ctb = cB[j];
+#else
         uint64_t ka = (i < i1) ? sA[i] : kPadKey, kb = (j < j1) ? sB[j] : kPadKey;
-        uint64_t dA = 0, dB = 0;
+#endif
+        H4 dA = 0, dB = 0;
         double Fp = 0.0, Hp = 0.0, firstF = 0.0, local = 0.0;
-        const int epl_w = max(__builtin_amdgcn_readlane(epl, 0), __builtin_amdgcn_readlane(epl, 32));  // wave-uniform trip count
+        int epl_w = __builtin_amdgcn_readlane(epl, 0);  // wave-uniform trip count: the longest of the teams' chunks
+#pragma unroll
+        for (int k = 1; k < TEAMS; ++k) epl_w = max(epl_w, __builtin_amdgcn_readlane(epl, k * TL));
         for (int e = 0; e < epl_w; ++e) {
             if (d0 + e < d1) {
+#if LCHD_CAT_HEADS
+                // both heads and their categories are re-read after every event (see k_sweep); run ends are tested on the indices
+                const bool takeA = (i < i1) & ((j >= j1) | (ka <= kb));
+                const uint64_t key = takeA ? ka : kb;
+                const int ct = takeA ? cta : ctb;
+                i += takeA ? 1 : 0;
+                j += takeA ? 0 : 1;
+                ka = sA[i];  // (one past the run's end at most: the buffers have spare entries)
+                kb = sB[j];
+                cta = cA[i];
+                ctb = cB[j];
+#else
                 const bool takeA = (ka <= kb);
                 const uint64_t key = takeA ? ka : kb;
                 const int ct = (takeA ? cA : cB)[takeA ? i : j];
@@ -3023,11 +3069,12 @@ __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs arg
                 j += takeA ? 0 : 1;
                 {
                     const int nidx = takeA ? i : j, nend = takeA ? i1 : j1;
-                    const uint64_t nk = (takeA ? sA : sB)[min(nidx, TILE - 1)];
+                    const uint64_t nk = (takeA ? sA : sB)[nidx];
                     const uint64_t nh = nidx < nend ? nk : kPadKey;
                     ka = takeA ? nh : ka;
                     kb = takeA ? kb : nh;
                 }
+#endif
                 const double F = u2d(key);
                 if (e == 0) firstF = F; else local += (F - Fp) * Hp;
                 totA += takeA ? 1 : 0;
@@ -3040,13 +3087,13 @@ __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs arg
                     wA = hit ? exA[k] : wA;
                     wB = hit ? exB[k] : wB;
                 }
-                const int cntA_ = (int)((wA >> sh) & 0xFFull) + (int)((dA >> sh4) & 15ull);  // before the update
-                const int cntB_ = (int)((wB >> sh) & 0xFFull) + (int)((dB >> sh4) & 15ull);
-                const uint64_t inc4 = 1ull << sh4;
-                dA += takeA ? inc4 : 0ull;
-                dB += takeA ? 0ull : inc4;
-                const int mine = takeA ? cntA_ : cntB_, other = takeA ? cntB_ : cntA_;
-                D += (t_sqrt[mine + 1] - t_sqrt[mine]) * t_sqrt[other];
+                const int cntA_ = (int)((wA >> sh) & 0xFFull) + (int)((dA >> sh4) & (H4)15);  // before the update
+                const int cntB_ = (int)((wB >> sh) & 0xFFull) + (int)((dB >> sh4) & (H4)15);
+                const H4 inc4 = (H4)1 << sh4;
+                dA += takeA ? inc4 : (H4)0;
+                dB += takeA ? (H4)0 : inc4;
+                const int mine_ = takeA ? cntA_ : cntB_, other = takeA ? cntB_ : cntA_;
+                D += (t_sqrt[mine_ + 1] - t_sqrt[mine_]) * t_sqrt[other];
                 ra = t_rsqrt[totA];
                 rb = t_rsqrt[totB];
                 double h2 = 1.0 - (ra * rb) * D;
@@ -3058,8 +3105,8 @@ __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs arg
                         for (int f = 0; f < FPW; ++f) {
                             const int c = FPW * k + f;
                             if (c < CMAX) {
-                                const int ca = field(exA, c) + (int)((dA >> (c * 4)) & 15ull);
-                                const int cb = field(exB, c) + (int)((dB >> (c * 4)) & 15ull);
+                                const int ca = field(exA, c) + (int)((dA >> (c * 4)) & (H4)15);
+                                const int cb = field(exB, c) + (int)((dB >> (c * 4)) & (H4)15);
                                 const double dd = t_sqrt[ca] * ra - t_sqrt[cb] * rb;
                                 acc2 = fma(dd, dd, acc2);
                             }
@@ -3076,10 +3123,11 @@ __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs arg
         double prevF = wave_shr1_f64(Fp), prevH = wave_shr1_f64(Hp);
         if (tl == 0) { prevF = F0; prevH = H0; }
         if (d0 < d1) local += (firstF - prevF) * prevH;
-        const int last = T > 0 ? (T - 1) / epl : 0;  // the team lane that holds the last event (lane 0 if there is none)
-        if (tl == last) local += (T > 0) ? (Finf0 - Fp) * Hp : (Finf0 - F0) * H0;
-        const double acc = half_sum_f64(local);
-        if (tl == 31 && live && mine) args.out[p] = valid ? acc : nan("");  // (categories were checked when the environments were built)
+        // the team lane that holds the last event (its chunk is not empty and ends at T; lane 0 if there is no event at all)
+        const bool is_last = T > 0 ? (d0 < d1 && d1 == T) : (tl == 0);
+        if (is_last) local += (T > 0) ? (Finf0 - Fp) * Hp : (Finf0 - F0) * H0;
+        const double acc = team_sum_f64<TL>(local);
+        if (tl == TL - 1 && live && mine) args.out[p] = valid ? acc : nan("");  // (categories were checked when the environments were built)
     }
 }
 
@@ -3550,7 +3598,8 @@ int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinge
             const unsigned bgrid = grid < 1024 ? grid : 1024;  // the listed (larger) pairs are a minority whenever this launch does anything
             constexpr int NTH = 64 * kSweepWaves;
             if (use_duo) {
-                const int64_t dblocks = (a.n_pairs + 2 * kSweepWaves - 1) / (2 * kSweepWaves);
+                constexpr int kTeamPairs = (64 / LCHD_DUO_TL) * kSweepWaves;  // pairs per workgroup and round
+                const int64_t dblocks = (a.n_pairs + kTeamPairs - 1) / kTeamPairs;
                 const unsigned dgrid = (unsigned)(dblocks < gcap ? dblocks : gcap);
                 if (cmax <= 8) { k_sweep_duo<8><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<8, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
                 else if (cmax <= 12) { k_sweep_duo<12><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<12, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
