@@ -269,6 +269,7 @@ static Tuning tuning_from_env() {  // the ONLY place that reads LCHD_* hooks (te
     t.no_sweep_hint = getenv("LCHD_NO_SWEEP_HINT") != nullptr;
     t.no_inline_meta = getenv("LCHD_NO_INLINE_META") != nullptr;
     t.no_count8 = getenv("LCHD_NO_COUNT8") != nullptr;
+    t.no_c8_team = getenv("LCHD_NO_C8_TEAM") != nullptr;
     t.old_rows = getenv("LCHD_OLD_ROWS") != nullptr;
     t.no_tables = getenv("LCHD_NO_SD_TABLES") != nullptr;
     t.no_env_group = getenv("LCHD_NO_ENV_GROUP") != nullptr;

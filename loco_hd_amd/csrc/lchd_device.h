@@ -38,7 +38,8 @@ struct DeviceStatus {
     uint32_t max_env;        // largest environment seen (for the overflow retry)
     uint32_t n_unique[2];    // unique anchors per side
     uint32_t pad[2];
-    unsigned long long n_small;     // pairs with at most kDuoTile merged events (k_pair_meta): who sweeps them is decided on the device
+    unsigned long long n_small;     // pairs under the pass's first-choice small rule (k_pair_meta): who sweeps them is decided on the device
+    unsigned long long n_c8;        // pairs under SweepArgs::c8_rule (the second choice of a pass without a hint)
 };
 // Host-mapped (pinned, device-visible) mirror: written with plain stores only -- the snapshot by one thread of k_pair_meta,
 // the error words by whichever sweep wavefront meets the (rare) condition; every writer of a word stores the same value.
@@ -68,6 +69,7 @@ struct Tuning {
     bool no_inline_meta = false;    // LCHD_NO_INLINE_META: small calls also run k_pair_meta + the regular sweep kernels
     bool old_rows = false;          // LCHD_OLD_ROWS: dense rows through k_env_rows (three distance passes) for every length
     bool no_count8 = false;         // LCHD_NO_COUNT8: never the 8-bit-count sweep
+    bool no_c8_team = false;        // LCHD_NO_C8_TEAM: the 8-bit-count sweep always one pair per wavefront (k_sweep<.., CNT8>)
     bool no_tables = false;         // LCHD_NO_SD_TABLES: generic distances without the per-launch power / log tables
     bool no_env_group = false;      // LCHD_NO_ENV_GROUP: environments of the default capacity through k_env_cells (one per wavefront) too
     bool no_sd_inc = false;         // LCHD_NO_SD_INC: Kullback-Leibler / Renyi through the generic sweep even where k_sweep_inc applies
@@ -253,7 +255,10 @@ struct SweepArgs {
     uint32_t seq;             // pass counter echoed into HostStatus::snapshot_seq
     int32_t duo_enabled;      // set by launch_sweep: k_sweep_duo was launched too and sweeps the small pairs when they are the majority
     int32_t small_rule;       // set by launch_sweep: which pairs count as "small" (0: <= kDuoTile merged events, k_sweep_duo; 1: both
-                              // environments <= 255 points, the 8-bit-count k_sweep); the indirect k_sweep takes the others
+                              // environments <= 255 points, the 8-bit-count k_sweep; 2: ... and at most 480 merged events, its
+                              // two-pairs-per-wavefront form); the indirect k_sweep takes the others
+    int32_t c8_rule;          // set by launch_sweep: the rule (1 or 2) HostStatus::n_c8 is counted under
+    int32_t second_rule;      // set by launch_sweep: 0, or the rule of the second small-pair kernel a pass without a hint launched
     int32_t gen_tab;          // set by launch_sweep: MODE_GEN may use power tables (Hellinger with a general exponent, unit category weights)
     int32_t forced;           // set by launch_sweep: the host picked the sweep kernels (hint from the previous pass): no device-side decision
     int32_t sd_fast;          // the configuration qualifies for k_sweep_inc (lchd_sweep_inc.hip): 0 no, 1 Kullback-Leibler form, 2 Renyi form

@@ -1884,6 +1884,24 @@ enum { F_KEY = 0, F_FAST = 1, F_ANY = 2 };
 #endif
 constexpr int kDuoTileFwd = 224;  // = kDuoTile (k_sweep_duo, below)
 constexpr int kCount8MaxEnv = 255;        // the 8-bit-count sweep takes pairs whose environments both have at most this many points
+constexpr int kTeam8Tile = 480;           // ... and its two-pairs-per-wavefront form (k_sweep_duo<CMAX, 32, 480>) those of at most 32 x 15 merged events
+// which pairs the small-pair kernel of a launch sweeps (SweepArgs::small_rule); nA, nB: environment sizes incl. the anchor, both > 0
+__device__ __forceinline__ bool pair_is_small(int rule, int nA, int nB) {
+    if (rule == 0) return nA + nB - 2 <= kDuoTileFwd;
+    const bool c8 = max(nA, nB) <= kCount8MaxEnv;
+    return rule == 1 ? c8 : (c8 && nA + nB - 2 <= kTeam8Tile);
+}
+// The small rule in force in this pass, or -1 (the plain sweep takes every pair).  With a hint the host launched exactly the
+// kernels that have to run (forced); without one every candidate kernel is launched and all of them decide here, from the
+// counts of k_pair_meta: the first-choice rule if its pairs are the majority, else the second-choice rule if ITS pairs are --
+// the same function of the pair list the host evaluates for the next pass's hint.
+__device__ __forceinline__ int rule_in_force(const SweepArgs& args) {
+    if (args.forced) return args.small_rule;
+    const unsigned long long P = (unsigned long long)args.n_pairs;
+    if (2 * args.st->n_small >= P) return args.small_rule;
+    if (args.second_rule && 2 * args.st->n_c8 >= P) return args.second_rule;
+    return -1;
+}
 #ifndef LCHD_INLINE_META_PAIRS
 #define LCHD_INLINE_META_PAIRS 4096
 #endif
@@ -2172,10 +2190,11 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? (CMAX <= LCHD
     // When pairs with at most kDuoTile merged events are the majority of a launch, k_sweep_duo sweeps them two per wavefront
     // and the INDIRECT instantiation of this kernel picks the remaining ones out of the pair records; otherwise the plain
     // instantiation sweeps everything.  All three decide from the same word (k_pair_meta: DeviceStatus::n_small).
+    const int small_rule = (INDIRECT || CNT8 || !args.forced) ? rule_in_force(args) : -1;
     if (!args.forced) {  // (forced: the host launched exactly the kernels that have to run)
-        const bool duo_active = 2 * args.st->n_small >= (unsigned long long)args.n_pairs;
-        if constexpr (INDIRECT || CNT8) { if (!duo_active) return; }  // (the small-pair kernels and their companion: only when small pairs are the majority)
-        else { if (args.duo_enabled && duo_active) return; }
+        if constexpr (CNT8) { if (small_rule != 1) return; }          // (the small-pair kernels and their companion: only when
+        else if constexpr (INDIRECT) { if (small_rule < 0) return; }  //  the pairs of their rule are the majority)
+        else { if (args.duo_enabled && small_rule >= 0) return; }
     }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform => everything derived from it stays scalar
@@ -2304,7 +2323,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? (CMAX <= LCHD
             // the pairs the small-pair kernel of this launch leaves over: more than kDuoTile merged events (k_sweep_duo), or an
             // environment of more than 255 points (the 8-bit-count k_sweep)
             const int za = mm.z & 0xFFFFFF, zb = mm.w & 0xFFFFFF;
-            todo = __ballot(za > 0 && (args.small_rule ? max(za, zb) > kCount8MaxEnv : za + zb - 2 > kDuoTileFwd));
+            todo = __ballot(za > 0 && !pair_is_small(small_rule, za, zb));
             p_cur = blk * 64;
             blk += pstride;
         }
@@ -2897,24 +2916,30 @@ __device__ __forceinline__ double team_sum_f64(double v) {  // the last lane of 
 // (the name is historic: round 1 swept TWO pairs per wavefront; with TL = 16 a wavefront sweeps FOUR -- the per-tile prologue, which
 // is two thirds of this kernel's instructions at ~150 events per pair, is shared by twice as many pairs, the event loop costs the
 // same per pair: C3 459 -> see DESIGN section 4)
-template <int CMAX, int TL = LCHD_DUO_TL>
+// TILE_ = 224: pairs of at most 224 merged events (small_rule 0); TILE_ = 480 (TL = 32): pairs whose environments both have at most
+// 255 points and that have at most 480 merged events (small_rule 2) -- the 8-bit-count k_sweep's pairs, two per wavefront (C2a: ~343
+// events per pair)
+template <int CMAX, int TL = LCHD_DUO_TL, int TILE_ = kDuoTile>
 __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs args) {
     static_assert(TL == 16 || TL == 32, "a team is one or two DPP rows");
-    constexpr int TEAMS = 64 / TL, EPL = kDuoTile / TL, TILE = kDuoTile, WPB = kSweepWaves;
-    // category counts as 8-bit fields: a pair of this kernel has at most kDuoTile = 224 merged events, so no count exceeds 225
-    // (one word per side up to 8 category slots, two up to 16: half the scans and no word select for the common 8-slot case)
+    constexpr int TEAMS = 64 / TL, EPL = TILE_ / TL, TILE = TILE_, WPB = kSweepWaves;
+    constexpr int RULE = TILE_ == kDuoTile ? 0 : 2;
+    // category counts as 8-bit fields: no count of a pair of this kernel exceeds 255 (TILE 224: at most 225 points in all; TILE 480:
+    // environments of at most 255 points) -- one word per side up to 8 category slots, two up to 16: half the scans and no word select
+    // for the common 8-slot case
     constexpr int FPW = 8, FB = 8;
     constexpr int NW = (CMAX + FPW - 1) / FPW;  // u64 words of count fields per side (CMAX <= 16: one word of 4-bit chunk fields)
-    static_assert(kDuoTile + 1 < 256, "8-bit count fields");
-    static_assert(kDuoTile == kDuoTileFwd && EPL * TL == kDuoTile && EPL <= 15, "4-bit chunk-local counters");
-    constexpr int NT = 256 + 8;  // (no count and no total of this kernel's pairs exceeds 226)
+    static_assert(TILE_ == kDuoTile || TILE_ == kTeam8Tile, "the two rules of pair_is_small");
+    static_assert(kDuoTile + 1 < 256 && kCount8MaxEnv < 256, "8-bit count fields");
+    static_assert(kDuoTile == kDuoTileFwd && EPL * TL == TILE_ && EPL <= 15, "4-bit chunk-local counters");
+    constexpr int NT = 256 + 8;  // (no count and no total of this kernel's pairs exceeds 256)
     // 4-bit chunk-local fields, one per category slot: 32 bits hold them up to 8 slots (half the selects and adds of a 64-bit word)
     using H4 = typename std::conditional<(CMAX <= 8), uint32_t, uint64_t>::type;
     __shared__ double t_sqrt[NT], t_rsqrt[NT];
     // one buffer per team: list A's points, then list B's (at most TILE together; + the spare entries the head re-reads may touch)
     __shared__ uint64_t s_[WPB][TEAMS][TILE + 2];
     __shared__ uint8_t c_[WPB][TEAMS][TILE + 8];
-    if (!args.forced && 2 * args.st->n_small < (unsigned long long)args.n_pairs) return;  // mostly larger pairs: k_sweep sweeps everything
+    if (!args.forced && rule_in_force(args) != RULE) return;  // another rule's pairs are the majority, or none's: k_sweep sweeps everything
     const int tid = threadIdx.x, lane = tid & 63, tl = lane & (TL - 1), team = lane / TL;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const DevConfig* __restrict__ cfgp = args.cfg;
@@ -2934,7 +2959,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs arg
         const bool live = p < args.n_pairs;
         const int4 m = args.meta[live ? p : pb];
         const bool usable = live && (m.z & 0xFFFFFF) > 0 && (m.w & 0xFFFFFF) > 0;
-        const bool mine = !usable || (m.z & 0xFFFFFF) + (m.w & 0xFFFFFF) - 2 <= TILE;  // larger pairs belong to k_sweep
+        const bool mine = !usable || pair_is_small(RULE, m.z & 0xFFFFFF, m.w & 0xFFFFFF);  // larger pairs belong to k_sweep
         const bool valid = usable && mine;
         const int mA = valid ? (m.z & 0xFFFFFF) - 1 : 0, mB = valid ? (m.w & 0xFFFFFF) - 1 : 0, T = mA + mB;  // non-anchor events
         const int c0a = (m.z >> 24) & 255, c0b = (m.w >> 24) & 255;
@@ -3493,7 +3518,7 @@ __global__ void k_pair_meta(SweepArgs args) {
         // 8-bit-count sweep takes: both environments of at most 255 points.  Both are counted whichever rule this pass uses:
         // the host picks the next pass's kernels from them.
         n_duo += (nA + nB - 2 <= kDuoTileFwd) ? 1 : 0;
-        n_c8 += (max(nA, nB) <= kCount8MaxEnv) ? 1 : 0;
+        n_c8 += pair_is_small(args.c8_rule, nA, nB) ? 1 : 0;
     }
     // pairs that fit one 32-lane tile: if they are the majority, k_sweep_duo sweeps them and k_sweep only the rest.  One
     // partial count per workgroup; the workgroup that finishes LAST folds them, publishes what the host wants to know into
@@ -3519,7 +3544,8 @@ __global__ void k_pair_meta(SweepArgs args) {
         const unsigned long long duo = v & 0xFFFFFFFFull, c8 = v >> 32;
         args.hst->n_duo = duo;
         args.hst->n_c8 = c8;
-        publish_status(args, args.small_rule ? c8 : duo, mx);
+        args.st->n_c8 = c8;
+        publish_status(args, args.small_rule ? c8 : duo, mx);  // (small_rule 1 or 2 == c8_rule whenever it is not 0)
     }
 }
 
@@ -3569,7 +3595,12 @@ int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinge
     const bool c8_small_slots = fast_cfg && cmax <= 16 && !t.no_count8 && known && !(duo_major && !t.no_duo) && c8_major;
     const bool use_duo = fast_cfg && cmax <= 16 && !t.no_duo && !c8_small_slots;
     const bool use_c8 = fast_cfg && !t.no_count8 && (cmax > 16 || c8_small_slots);
-    a.small_rule = use_c8 ? 1 : 0;
+    // up to 16 slots the 8-bit-count pairs are swept two per wavefront (rule 2: and at most 480 merged events)
+    const bool c8_team = use_c8 && cmax <= 16 && !t.no_c8_team;
+    a.c8_rule = (cmax <= 16 && !t.no_c8_team) ? 2 : 1;  // (what k_pair_meta counts as n_c8 -- whichever small-pair kernel this pass uses)
+    a.small_rule = use_c8 ? a.c8_rule : 0;
+    // no hint and up to 16 slots: k_sweep_duo's rule first, the two-pairs-per-wavefront 8-bit-count rule second
+    a.second_rule = (!known && use_duo && fast_cfg && !t.no_count8 && !t.no_c8_team) ? 2 : 0;
     const int hint = !known ? 0 : ((use_c8 ? c8_major : duo_major) ? 1 : 2);
     // ... | 8 (EVERY pair of the previous pass had at most 224 events) | 16 (... both environments <= 255 points): the companion
     // launch for the larger pairs would find nothing to do and is left out; the host checks the counts of THIS pass afterwards
@@ -3604,6 +3635,20 @@ int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinge
                 if (cmax <= 8) { k_sweep_duo<8><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<8, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
                 else if (cmax <= 12) { k_sweep_duo<12><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<12, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
                 else { k_sweep_duo<16><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<16, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+                if (a.second_rule) {
+                    const int64_t tblocks = (a.n_pairs + 2 * kSweepWaves - 1) / (2 * kSweepWaves);
+                    const unsigned tgrid = (unsigned)(tblocks < gcap ? tblocks : gcap);
+                    if (cmax <= 8) k_sweep_duo<8, 32, kTeam8Tile><<<tgrid, NTH, 0, s>>>(a);
+                    else if (cmax <= 12) k_sweep_duo<12, 32, kTeam8Tile><<<tgrid, NTH, 0, s>>>(a);
+                    else k_sweep_duo<16, 32, kTeam8Tile><<<tgrid, NTH, 0, s>>>(a);
+                }
+            } else if (c8_team) {
+                constexpr int kTeamPairs = 2 * kSweepWaves;
+                const int64_t dblocks = (a.n_pairs + kTeamPairs - 1) / kTeamPairs;
+                const unsigned dgrid = (unsigned)(dblocks < gcap ? dblocks : gcap);
+                if (cmax <= 8) { k_sweep_duo<8, 32, kTeam8Tile><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<8, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+                else if (cmax <= 12) { k_sweep_duo<12, 32, kTeam8Tile><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<12, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+                else { k_sweep_duo<16, 32, kTeam8Tile><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<16, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
             } else {
                 if (cmax <= 8) { k_sweep<8, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); if (!no_others) k_sweep<8, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
                 else if (cmax <= 12) { k_sweep<12, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); if (!no_others) k_sweep<12, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }

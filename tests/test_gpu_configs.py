@@ -449,6 +449,55 @@ def test_sweep_hint_follows_the_workload(lh, oracle, monkeypatch, ncat):
     sess.close()
 
 
+@pytest.mark.parametrize("ncat,density", [(7, 0.060), (7, 0.065), (8, 0.0575), (11, 0.0575), (12, 0.061), (15, 0.0575), (16, 0.060)])
+def test_two_pairs_per_wavefront_eight_bit_sweep_around_its_limits(lh, oracle, monkeypatch, ncat, density):
+    """Up to 16 category slots the pairs whose environments both have <= 255 points AND that have <= 480 merged events are swept
+    two per wavefront (k_sweep_duo<CMAX, 32, 480>); the others go to the INDIRECT 16-bit k_sweep.  Environments of ~212 ... ~244
+    points put pairs on both sides of both limits in one call (at 0.065 atoms/A^3 the qualifying pairs are a minority: the plain
+    k_sweep takes everything).  Against the oracle; the first pass of a context (no hint: every
+    candidate kernel is launched, the device decides) and the second (the host launches what the first pass counted) must agree
+    BIT FOR BIT -- both evaluate the same function of the pair list; and against the one-pair-per-wavefront 8-bit sweep."""
+    import torch
+    from loco_hd_amd.device import DeviceSession
+
+    monkeypatch.setenv("LCHD_NO_INLINE_META", "1")
+    rng = np.random.default_rng(int(density * 1e4) + ncat)
+    n = 3000
+    side = (n / density) ** (1 / 3)
+    # (periodic images would be needed for every environment to reach the bulk size: the rim gives the smaller pairs)
+    xa, xb = rng.uniform(0, side, (n, 3)), rng.uniform(0, side, (n, 3))
+    ca, cb = rng.integers(0, ncat, n).astype(np.int32), rng.integers(0, ncat, n).astype(np.int32)
+    cats = [f"c{i}" for i in range(ncat)]
+    centre = np.argsort(np.linalg.norm(xa - side / 2, axis=1))[: n // 2]  # anchors away from the rim: bulk-sized environments
+    centre_b = np.argsort(np.linalg.norm(xb - side / 2, axis=1))[: n // 2]
+    pairs = np.stack([rng.choice(centre, 6000), rng.choice(centre_b, 6000)], 1).astype(np.int64)
+    tag = np.zeros(n, dtype=np.int32)
+    wf = ("hyper_exp", [1.0, 0.2])
+    lo = oracle.LoCoHD(cats, oracle.WeightFunction(*wf), n_of_threads=8)
+    want, sizes = lo.from_arrays(xa, ca, tag, xb, cb, tag, pairs, 10.0, return_env_sizes=True)
+    want, sizes = np.asarray(want), np.asarray(sizes)
+    c8 = sizes.max(axis=1) <= 255
+    team = c8 & (sizes.sum(axis=1) - 2 <= 480)
+    assert 0.02 < np.mean(team) < 0.98 and np.mean(c8 & ~team) > 0.01 and np.mean(~c8) > 0.01, (np.mean(team), np.mean(c8))
+    outs = {}
+    for mode in ("team", "single"):
+        if mode == "single":
+            monkeypatch.setenv("LCHD_NO_C8_TEAM", "1")
+        sess = DeviceSession(lh.LoCoHD(cats, lh.WeightFunction(*wf)))
+        a, b, d_pairs = sess.upload(xa, ca), sess.upload(xb, cb), torch.from_numpy(pairs).cuda()
+        first = sess.from_primitives(a, b, d_pairs, 10.0).cpu().numpy()
+        second = sess.from_primitives(a, b, d_pairs, 10.0).cpu().numpy()
+        third = sess.from_primitives(a, b, d_pairs, 10.0).cpu().numpy()
+        sess.close()
+        assert np.max(np.abs(first - want)) < TIGHT, (mode, np.mean(team))
+        if mode == "team":
+            assert np.array_equal(first, second) and np.array_equal(second, third)
+        else:  # (the hook leaves the first pass to the plain 16-bit sweep, whose tiles cut long pairs differently: last-bit differences)
+            assert np.max(np.abs(first - second)) < 1e-13 and np.array_equal(second, third)
+        outs[mode] = first
+    assert np.max(np.abs(outs["team"] - outs["single"])) < 1e-13
+
+
 def test_regular_batch_of_large_structures_uses_the_per_structure_cell_build(lh, oracle):
     """64 frames of an 11 000-atom structure: the one-workgroup-per-structure cell list at (almost) its LDS limit, against
     the oracle on a sample of frames and against the generic cell-list path."""

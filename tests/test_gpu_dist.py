@@ -140,7 +140,9 @@ def test_device_group_of_the_c_abi(setup, oracle):
         bad[37, 1] = s["n"] + 5
         with pytest.raises(lh.PanicException):
             grp.from_packed(pa, pb, bad, 10.0)
-        assert np.array_equal(grp.from_packed(pa, pb, s["pairs"][:1000], 10.0), ref[:1000])  # and the group keeps working
+        # ... and the group keeps working (a call this small takes the one-launch sweep, one pair per wavefront: its lanes cut a pair
+        # into other chunks than the two-pairs-per-wavefront kernel of the large call -- last-bit differences)
+        assert np.max(np.abs(grp.from_packed(pa, pb, s["pairs"][:1000], 10.0) - ref[:1000])) < 1e-13
     assert np.max(np.abs(ref - s["want"])) < TIGHT
     # the reference's call shape with lists of PrimitiveAtoms and a dictionary of weight functions (per-pair keys travel too)
     multi = {"near": lh.WeightFunction("uniform", [0.0, 6.0]), "far": lh.WeightFunction("hyper_exp", [1.0, 0.1])}
