@@ -270,6 +270,7 @@ static Tuning tuning_from_env() {  // the ONLY place that reads LCHD_* hooks (te
     t.no_inline_meta = getenv("LCHD_NO_INLINE_META") != nullptr;
     t.no_count8 = getenv("LCHD_NO_COUNT8") != nullptr;
     t.no_c8_team = getenv("LCHD_NO_C8_TEAM") != nullptr;
+    if (const char* v = getenv("LCHD_C8_TEAM_MAX")) t.c8_team_max = atoi(v);
     t.old_rows = getenv("LCHD_OLD_ROWS") != nullptr;
     t.no_tables = getenv("LCHD_NO_SD_TABLES") != nullptr;
     t.no_env_group = getenv("LCHD_NO_ENV_GROUP") != nullptr;

@@ -70,6 +70,7 @@ struct Tuning {
     bool old_rows = false;          // LCHD_OLD_ROWS: dense rows through k_env_rows (three distance passes) for every length
     bool no_count8 = false;         // LCHD_NO_COUNT8: never the 8-bit-count sweep
     bool no_c8_team = false;        // LCHD_NO_C8_TEAM: the 8-bit-count sweep always one pair per wavefront (k_sweep<.., CNT8>)
+    int c8_team_max = 0;            // LCHD_C8_TEAM_MAX: ... above this many category slots (0: the two-pairs form up to 32)
     bool no_tables = false;         // LCHD_NO_SD_TABLES: generic distances without the per-launch power / log tables
     bool no_env_group = false;      // LCHD_NO_ENV_GROUP: environments of the default capacity through k_env_cells (one per wavefront) too
     bool no_sd_inc = false;         // LCHD_NO_SD_INC: Kullback-Leibler / Renyi through the generic sweep even where k_sweep_inc applies

@@ -2884,6 +2884,9 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? (CMAX <= LCHD
 // the majority this kernel sweeps them and k_sweep only the rest, otherwise this kernel returns at once.
 // ------------------------------------------------------------------------------------------------
 constexpr int kDuoTile = 224;  // merged events per pair: 16 lanes x 14
+#ifndef LCHD_TEAM_BIG_WAVES
+#define LCHD_TEAM_BIG_WAVES 3   // waves per SIMD k_sweep_duo is compiled for with more than 16 category slots
+#endif
 #ifndef LCHD_DUO_TL
 #define LCHD_DUO_TL 16   // lanes per pair of k_sweep_duo (32: two pairs per wavefront, the round-1 form; 16: four)
 #endif
@@ -2920,7 +2923,7 @@ __device__ __forceinline__ double team_sum_f64(double v) {  // the last lane of 
 // 255 points and that have at most 480 merged events (small_rule 2) -- the 8-bit-count k_sweep's pairs, two per wavefront (C2a: ~343
 // events per pair)
 template <int CMAX, int TL = LCHD_DUO_TL, int TILE_ = kDuoTile>
-__global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs args) {
+__global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_WAVES)) void k_sweep_duo(SweepArgs args) {
     static_assert(TL == 16 || TL == 32, "a team is one or two DPP rows");
     constexpr int TEAMS = 64 / TL, EPL = TILE_ / TL, TILE = TILE_, WPB = kSweepWaves;
     constexpr int RULE = TILE_ == kDuoTile ? 0 : 2;
@@ -2928,7 +2931,9 @@ __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs arg
     // environments of at most 255 points) -- one word per side up to 8 category slots, two up to 16: half the scans and no word select
     // for the common 8-slot case
     constexpr int FPW = 8, FB = 8;
-    constexpr int NW = (CMAX + FPW - 1) / FPW;  // u64 words of count fields per side (CMAX <= 16: one word of 4-bit chunk fields)
+    constexpr int NW = (CMAX + FPW - 1) / FPW;  // u64 words of count fields per side
+    constexpr int NH = (CMAX + 15) / 16;        // words of 4-bit chunk fields per side (two from 17 category slots on)
+    static_assert(CMAX <= 32, "two words of 4-bit chunk fields");
     static_assert(TILE_ == kDuoTile || TILE_ == kTeam8Tile, "the two rules of pair_is_small");
     static_assert(kDuoTile + 1 < 256 && kCount8MaxEnv < 256, "8-bit count fields");
     static_assert(kDuoTile == kDuoTileFwd && EPL * TL == TILE_ && EPL <= 15, "4-bit chunk-local counters");
@@ -3009,40 +3014,42 @@ __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs arg
         const int j0 = d0 - i0, j1 = d1 - i1;
 
         // pass 1: 4-bit-per-category histogram of the lane's chunk
-        H4 hA = 0, hB = 0;
-#if LCHD_PASS1_FUSED
+        H4 hA[NH], hB[NH];
+#pragma unroll
+        for (int w = 0; w < NH; ++w) hA[w] = hB[w] = 0;
         {   // one fixed-trip loop over the chunk's points, A's run first (see k_sweep)
             const int nAl = i1 - i0, nl = d1 - d0;
             const uint8_t* pa_ = cA + i0;
             const uint8_t* pb_ = cB + (j0 - nAl);
-            H4 hT = 0;
+            H4 hT[NH];
+#pragma unroll
+            for (int w = 0; w < NH; ++w) hT[w] = 0;
 #pragma unroll
             for (int m = 0; m < EPL; ++m) {
                 if (m < epl) {  // wave-uniform? no: epl differs between the teams -- the test is per lane, the reads stay in range
                     const bool isA = m < nAl;
                     const int ct = (isA ? pa_ : pb_)[m < nl ? m : 0];
                     const H4 inc = (m < nl) ? ((H4)1 << ((ct & 15) * 4)) : (H4)0;
-                    hT += inc;
-                    hA += isA ? inc : (H4)0;
+                    if constexpr (NH == 1) {
+                        hT[0] += inc;
+                        hA[0] += isA ? inc : (H4)0;
+                    } else {
+                        const bool hi = (ct & 16) != 0;
+                        hT[0] += hi ? (H4)0 : inc;
+                        hT[1] += hi ? inc : (H4)0;
+                        hA[0] += (isA && !hi) ? inc : (H4)0;
+                        hA[1] += (isA && hi) ? inc : (H4)0;
+                    }
                 }
             }
-            hB = hT - hA;
+#pragma unroll
+            for (int w = 0; w < NH; ++w) hB[w] = hT[w] - hA[w];
         }
-#else
-        for (int i = i0; i < i1; ++i) {
-            const int ct = cA[i];
-            hA += (H4)1 << ((ct & 15) * 4);
-        }
-        for (int j = j0; j < j1; ++j) {
-            const int ct = cB[j];
-            hB += (H4)1 << ((ct & 15) * 4);
-        }
-#endif
         // packed counts at the start of the chunk: the anchors + an exclusive scan over the team's lanes
         uint64_t exA[NW], exB[NW];
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
-            const uint64_t va_ = spread8((uint64_t)hA >> (32 * k)), vb_ = spread8((uint64_t)hB >> (32 * k));
+            const uint64_t va_ = spread8((uint64_t)hA[(k * 8) / 16] >> (((k * 8) % 16) * 4)), vb_ = spread8((uint64_t)hB[(k * 8) / 16] >> (((k * 8) % 16) * 4));
             const uint64_t sa_ = team_incl_scan_fields<TL>(va_), sb_ = team_incl_scan_fields<TL>(vb_);
             exA[k] = (((c0a / FPW) == k) ? (1ull << ((c0a % FPW) * FB)) : 0ull) + sa_ - va_;
             exB[k] = (((c0b / FPW) == k) ? (1ull << ((c0b % FPW) * FB)) : 0ull) + sb_ - vb_;
@@ -3068,7 +3075,9 @@ __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs arg
 #else
         uint64_t ka = (i < i1) ? sA[i] : kPadKey, kb = (j < j1) ? sB[j] : kPadKey;
 #endif
-        H4 dA = 0, dB = 0;
+        H4 dA[NH], dB[NH];
+#pragma unroll
+        for (int w = 0; w < NH; ++w) dA[w] = dB[w] = 0;
         double Fp = 0.0, Hp = 0.0, firstF = 0.0, local = 0.0;
         int epl_w = __builtin_amdgcn_readlane(epl, 0);  // wave-uniform trip count: the longest of the teams' chunks
 #pragma unroll
@@ -3112,11 +3121,21 @@ __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs arg
                     wA = hit ? exA[k] : wA;
                     wB = hit ? exB[k] : wB;
                 }
-                const int cntA_ = (int)((wA >> sh) & 0xFFull) + (int)((dA >> sh4) & (H4)15);  // before the update
-                const int cntB_ = (int)((wB >> sh) & 0xFFull) + (int)((dB >> sh4) & (H4)15);
+                H4 qA = dA[0], qB = dB[0];
+                if constexpr (NH == 2) { qA = (ct & 16) ? dA[1] : qA; qB = (ct & 16) ? dB[1] : qB; }
+                const int cntA_ = (int)((wA >> sh) & 0xFFull) + (int)((qA >> sh4) & (H4)15);  // before the update
+                const int cntB_ = (int)((wB >> sh) & 0xFFull) + (int)((qB >> sh4) & (H4)15);
                 const H4 inc4 = (H4)1 << sh4;
-                dA += takeA ? inc4 : (H4)0;
-                dB += takeA ? (H4)0 : inc4;
+                if constexpr (NH == 2) {
+                    const bool hi = (ct & 16) != 0;
+                    dA[0] += (takeA && !hi) ? inc4 : (H4)0;
+                    dA[1] += (takeA && hi) ? inc4 : (H4)0;
+                    dB[0] += (!takeA && !hi) ? inc4 : (H4)0;
+                    dB[1] += (!takeA && hi) ? inc4 : (H4)0;
+                } else {
+                    dA[0] += takeA ? inc4 : (H4)0;
+                    dB[0] += takeA ? (H4)0 : inc4;
+                }
                 const int mine_ = takeA ? cntA_ : cntB_, other = takeA ? cntB_ : cntA_;
                 D += (t_sqrt[mine_ + 1] - t_sqrt[mine_]) * t_sqrt[other];
                 ra = t_rsqrt[totA];
@@ -3124,18 +3143,32 @@ __global__ __launch_bounds__(64 * kSweepWaves, 4) void k_sweep_duo(SweepArgs arg
                 double h2 = 1.0 - (ra * rb) * D;
                 if (h2 < kExactH2Below) {  // literal difference-of-roots form where the cancellation form loses accuracy (k_sweep::exact_h2)
                     double acc2 = 0.0;
+                    if constexpr (NH == 1) {
 #pragma unroll
-                    for (int k = 0; k < NW; ++k) {
+                        for (int k = 0; k < NW; ++k) {
 #pragma unroll
-                        for (int f = 0; f < FPW; ++f) {
-                            const int c = FPW * k + f;
-                            if (c < CMAX) {
-                                const int ca = field(exA, c) + (int)((dA >> (c * 4)) & (H4)15);
-                                const int cb = field(exB, c) + (int)((dB >> (c * 4)) & (H4)15);
-                                const double dd = t_sqrt[ca] * ra - t_sqrt[cb] * rb;
-                                acc2 = fma(dd, dd, acc2);
+                            for (int f = 0; f < FPW; ++f) {
+                                const int c = FPW * k + f;
+                                if (c < CMAX) {
+                                    const int ca = field(exA, c) + (int)((dA[0] >> (c * 4)) & (H4)15);
+                                    const int cb = field(exB, c) + (int)((dB[0] >> (c * 4)) & (H4)15);
+                                    const double dd = t_sqrt[ca] * ra - t_sqrt[cb] * rb;
+                                    acc2 = fma(dd, dd, acc2);
+                                }
+                                if ((f & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                             }
-                            if ((f & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                        }
+                    } else {  // (rare path, many slots: a rolled loop -- no unrolled copy of 28 look-up pairs competing for registers)
+#pragma unroll 1
+                        for (int c = 0; c < CMAX; ++c) {
+                            uint64_t wA = exA[0], wB = exB[0];
+#pragma unroll
+                            for (int k = 1; k < NW; ++k) { wA = (c / FPW == k) ? exA[k] : wA; wB = (c / FPW == k) ? exB[k] : wB; }
+                            const H4 qA = (c & 16) ? dA[NH - 1] : dA[0], qB = (c & 16) ? dB[NH - 1] : dB[0];
+                            const int ca = (int)((wA >> ((c % FPW) * FB)) & 0xFFull) + (int)((qA >> ((c & 15) * 4)) & (H4)15);
+                            const int cb = (int)((wB >> ((c % FPW) * FB)) & 0xFFull) + (int)((qB >> ((c & 15) * 4)) & (H4)15);
+                            const double dd = t_sqrt[ca] * ra - t_sqrt[cb] * rb;
+                            acc2 = fma(dd, dd, acc2);
                         }
                     }
                     h2 = 0.5 * acc2;
@@ -3596,8 +3629,9 @@ int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinge
     const bool use_duo = fast_cfg && cmax <= 16 && !t.no_duo && !c8_small_slots;
     const bool use_c8 = fast_cfg && !t.no_count8 && (cmax > 16 || c8_small_slots);
     // up to 16 slots the 8-bit-count pairs are swept two per wavefront (rule 2: and at most 480 merged events)
-    const bool c8_team = use_c8 && cmax <= 16 && !t.no_c8_team;
-    a.c8_rule = (cmax <= 16 && !t.no_c8_team) ? 2 : 1;  // (what k_pair_meta counts as n_c8 -- whichever small-pair kernel this pass uses)
+    const bool team_ok = !t.no_c8_team && cmax <= (t.c8_team_max > 0 ? t.c8_team_max : 32);
+    const bool c8_team = use_c8 && team_ok;
+    a.c8_rule = team_ok ? 2 : 1;  // (what k_pair_meta counts as n_c8 -- whichever small-pair kernel this pass uses)
     a.small_rule = use_c8 ? a.c8_rule : 0;
     // no hint and up to 16 slots: k_sweep_duo's rule first, the two-pairs-per-wavefront 8-bit-count rule second
     a.second_rule = (!known && use_duo && fast_cfg && !t.no_count8 && !t.no_c8_team) ? 2 : 0;
@@ -3648,7 +3682,11 @@ int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinge
                 const unsigned dgrid = (unsigned)(dblocks < gcap ? dblocks : gcap);
                 if (cmax <= 8) { k_sweep_duo<8, 32, kTeam8Tile><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<8, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
                 else if (cmax <= 12) { k_sweep_duo<12, 32, kTeam8Tile><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<12, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
-                else { k_sweep_duo<16, 32, kTeam8Tile><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<16, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+                else if (cmax <= 16) { k_sweep_duo<16, 32, kTeam8Tile><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<16, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+                else if (cmax <= 20) { k_sweep_duo<20, 32, kTeam8Tile><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<20, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+                else if (cmax <= 24) { k_sweep_duo<24, 32, kTeam8Tile><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<24, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+                else if (cmax <= 28) { k_sweep_duo<28, 32, kTeam8Tile><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<28, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+                else { k_sweep_duo<32, 32, kTeam8Tile><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<32, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
             } else {
                 if (cmax <= 8) { k_sweep<8, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); if (!no_others) k_sweep<8, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
                 else if (cmax <= 12) { k_sweep<12, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); if (!no_others) k_sweep<12, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }

@@ -449,10 +449,11 @@ def test_sweep_hint_follows_the_workload(lh, oracle, monkeypatch, ncat):
     sess.close()
 
 
-@pytest.mark.parametrize("ncat,density", [(7, 0.060), (7, 0.065), (8, 0.0575), (11, 0.0575), (12, 0.061), (15, 0.0575), (16, 0.060)])
+@pytest.mark.parametrize("ncat,density", [(7, 0.060), (7, 0.065), (8, 0.0575), (11, 0.0575), (12, 0.061), (15, 0.0575), (16, 0.060),
+                                          (17, 0.0575), (20, 0.060), (23, 0.0575), (25, 0.061), (28, 0.0575), (29, 0.060), (32, 0.0575)])
 def test_two_pairs_per_wavefront_eight_bit_sweep_around_its_limits(lh, oracle, monkeypatch, ncat, density):
-    """Up to 16 category slots the pairs whose environments both have <= 255 points AND that have <= 480 merged events are swept
-    two per wavefront (k_sweep_duo<CMAX, 32, 480>); the others go to the INDIRECT 16-bit k_sweep.  Environments of ~212 ... ~244
+    """Pairs whose environments both have <= 255 points AND that have <= 480 merged events are swept two per wavefront
+    (k_sweep_duo<CMAX, 32, 480>, CMAX = 8 ... 32: one or two words of 4-bit chunk fields, one to four words of 8-bit counts); the others go to the INDIRECT 16-bit k_sweep.  Environments of ~212 ... ~244
     points put pairs on both sides of both limits in one call (at 0.065 atoms/A^3 the qualifying pairs are a minority: the plain
     k_sweep takes everything).  Against the oracle; the first pass of a context (no hint: every
     candidate kernel is launched, the device decides) and the second (the host launches what the first pass counted) must agree
