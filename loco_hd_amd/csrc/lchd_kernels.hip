@@ -2887,6 +2887,12 @@ constexpr int kDuoTile = 224;  // merged events per pair: 16 lanes x 14
 #ifndef LCHD_TEAM_BIG_WAVES
 #define LCHD_TEAM_BIG_WAVES 3   // waves per SIMD k_sweep_duo is compiled for with more than 16 category slots
 #endif
+#ifndef LCHD_TEAM_EXACT_UNROLL_MAX
+#define LCHD_TEAM_EXACT_UNROLL_MAX 8    // category slots up to which the (rare) literal Hellinger form of k_sweep_duo is unrolled (above: a rolled loop -- the unrolled look-ups of 12+ slots cost registers in the event loop)
+#endif
+#ifndef LCHD_TEAM_LOOP_UNROLL
+#define LCHD_TEAM_LOOP_UNROLL 1
+#endif
 #ifndef LCHD_DUO_TL
 #define LCHD_DUO_TL 16   // lanes per pair of k_sweep_duo (32: two pairs per wavefront, the round-1 form; 16: four)
 #endif
@@ -2977,6 +2983,12 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_W
         uint64_t* sB = sA + mA;
         uint8_t* cB = cA + mA;
 
+        // lane tl of a team owns merged events [d0, d1) of its pair
+        const int epl = (T + TL - 1) / TL;  // <= EPL
+        int epl_w = __builtin_amdgcn_readlane(epl, 0);  // wave-uniform trip count: the longest of the teams' chunks
+#pragma unroll
+        for (int k = 1; k < TEAMS; ++k) epl_w = max(epl_w, __builtin_amdgcn_readlane(epl, k * TL));
+
         wave_sync_lds();  // the previous pairs' tiles are fully consumed
         {   // stage [A's points | B's points]: entry t of the buffer is A[1 + t] or B[1 + t - mA]; all loads before the first LDS write.
             // One predicate for the whole team (the pair is swept here), none per entry: an entry beyond T re-reads the pair's last
@@ -2990,23 +3002,25 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_W
             if (valid) {
 #pragma unroll
                 for (int u = 0; u < EPL; ++u) {
-                    const int t = min(tl + TL * u, T - 1);  // (T = 0: entry 0 of list A's row, the anchor)
-                    const bool isA = t < mA;
-                    rk[u] = (isA ? kA : kBs)[1 + t];
-                    rc[u] = (isA ? tA : tBs)[1 + t];
+                    if (u < epl_w) {  // (wave-uniform: rounds no team of this wavefront needs are skipped)
+                        const int t = min(tl + TL * u, T - 1);  // (T = 0: entry 0 of list A's row, the anchor)
+                        const bool isA = t < mA;
+                        rk[u] = (isA ? kA : kBs)[1 + t];
+                        rc[u] = (isA ? tA : tBs)[1 + t];
+                    }
                 }
             }
 #pragma unroll
             for (int u = 0; u < EPL; ++u) {
-                const int t = tl + TL * u;
-                sA[t] = rk[u];
-                cA[t] = rc[u];
+                if (u < epl_w) {
+                    const int t = tl + TL * u;
+                    sA[t] = rk[u];
+                    cA[t] = rc[u];
+                }
             }
         }
         wave_sync_lds();
 
-        // lane tl of a team owns merged events [d0, d1) of its pair
-        const int epl = (T + TL - 1) / TL;  // <= EPL
         const int d0 = min(tl * epl, T), d1 = min(d0 + epl, T);
         const int i1 = merge_path(sA, mA, sB, mB, d1);
         int i0 = __builtin_amdgcn_update_dpp(i1, i1, 0x138, 0xf, 0xf, false);  // wave_shr:1
@@ -3078,10 +3092,15 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_W
         H4 dA[NH], dB[NH];
 #pragma unroll
         for (int w = 0; w < NH; ++w) dA[w] = dB[w] = 0;
-        double Fp = 0.0, Hp = 0.0, firstF = 0.0, local = 0.0;
-        int epl_w = __builtin_amdgcn_readlane(epl, 0);  // wave-uniform trip count: the longest of the teams' chunks
-#pragma unroll
-        for (int k = 1; k < TEAMS; ++k) epl_w = max(epl_w, __builtin_amdgcn_readlane(epl, k * TL));
+        double Fp = 0.0, Hp = 0.0, local = 0.0;
+#if LCHD_CAT_HEADS
+        // F of the chunk's first event, for the stitching below: known from the heads.  Inside the loop the first event adds
+        // (F - 0) * 0 = 0 like any other -- no "first event" selects per event.
+        const double firstF = u2d(((i < i1) & ((j >= j1) | (ka <= kb))) ? ka : kb);
+#else
+        double firstF = 0.0;
+#endif
+#pragma unroll LCHD_TEAM_LOOP_UNROLL
         for (int e = 0; e < epl_w; ++e) {
             if (d0 + e < d1) {
 #if LCHD_CAT_HEADS
@@ -3110,7 +3129,11 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_W
                 }
 #endif
                 const double F = u2d(key);
+#if LCHD_CAT_HEADS
+                local += (F - Fp) * Hp;
+#else
                 if (e == 0) firstF = F; else local += (F - Fp) * Hp;
+#endif
                 totA += takeA ? 1 : 0;
                 totB += takeA ? 0 : 1;
                 const int sh = (ct % FPW) * FB, sh4 = (ct & 15) * 4;
@@ -3143,7 +3166,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_W
                 double h2 = 1.0 - (ra * rb) * D;
                 if (h2 < kExactH2Below) {  // literal difference-of-roots form where the cancellation form loses accuracy (k_sweep::exact_h2)
                     double acc2 = 0.0;
-                    if constexpr (NH == 1) {
+                    if constexpr (CMAX <= LCHD_TEAM_EXACT_UNROLL_MAX) {
 #pragma unroll
                         for (int k = 0; k < NW; ++k) {
 #pragma unroll
