@@ -1658,17 +1658,21 @@ static int dense_pass(lchd_ctx* c, const lchd_cloud& a, const lchd_cloud& b, con
                       const int32_t* d_len_b = nullptr) {
     retry = false;
     const int cap_a = next_pow2_host(cols_a), cap_b = next_pow2_host(cols_b);
+    // more than 255 categories: 16-bit ids in the environment store, k_env_rows<.., uint16_t> + k_sweep_wide<.., CAT16>
+    const bool cat16 = c->h_cfg.n_categories > kMaxCategories;
+    const size_t cat_bytes = cat16 ? 2 : 1;
     EnvStore ea{}, eb{};
     double *w_ma = nullptr, *w_mb = nullptr;
     int4* d_meta = nullptr;
     for (int dry = 1; dry >= 0; --dry) {
         Arena ar(dry ? nullptr : c->ws, dry ? 0 : c->ws_cap, dry != 0);
         ea.key = ar.take<uint64_t>((size_t)rows * cap_a);
-        ea.cat = ar.take<uint8_t>((size_t)rows * cap_a);
+        ea.cat = ar.take<uint8_t>((size_t)rows * cap_a * cat_bytes);
         ea.len = ar.take<int32_t>((size_t)rows);
         ea.stride = cap_a;
+        ea.cat16 = eb.cat16 = cat16 ? 1 : 0;
         eb.key = ar.take<uint64_t>((size_t)rows * cap_b);
-        eb.cat = ar.take<uint8_t>((size_t)rows * cap_b);
+        eb.cat = ar.take<uint8_t>((size_t)rows * cap_b * cat_bytes);
         eb.len = ar.take<int32_t>((size_t)rows);
         eb.stride = cap_b;
         ea.cdf_keys = eb.cdf_keys = (c->h_cfg.n_wf == 1 && !c->tune.no_cdf_keys) ? 1 : 0;
@@ -1693,7 +1697,7 @@ static int dense_pass(lchd_ctx* c, const lchd_cloud& a, const lchd_cloud& b, con
         return s2 * (1.0 + 1e-9) + 1e-300;
     };
     const RowSide rsa{a.view(), d_ma, cols_a, cols_a, diag2(a), ea, d_len_a}, rsb{b.view(), d_mb, cols_b, cols_b, diag2(b), eb, d_len_b};
-    if (old_rows || !launch_env_rows2(s, c->d_cfg, rsa, rsb, rows, c->d_status)) {  // (rows beyond 20480 points: keys sorted in global memory)
+    if (old_rows || cat16 || !launch_env_rows2(s, c->d_cfg, rsa, rsb, rows, c->d_status)) {  // (rows beyond 20480 points: keys sorted in global memory)
         const RowExtras exa{nullptr, d_len_a, nullptr}, exb{nullptr, d_len_b, nullptr};
         if (!launch_env_rows(s, cap_a, c->d_cfg, a.view(), d_ma, cols_a, rows, cols_a, diag2(a), ea, c->d_status, exa) ||
             !launch_env_rows(s, cap_b, c->d_cfg, b.view(), d_mb, cols_b, rows, cols_b, diag2(b), eb, c->d_status, exb))
@@ -1722,9 +1726,6 @@ static int dense_driver(lchd_ctx* c, const lchd_config* cfg, const int32_t* seq_
     if (cols_a > 65535 || cols_b > 65535)
         return fail(LCHD_EUNSUPPORTED, "dense rows of more than 65535 points are not supported by this build (got %lld / %lld)",
                     (long long)cols_a, (long long)cols_b);
-    if (cfg->n_categories > kMaxCategories)
-        return fail(LCHD_EUNSUPPORTED, "from_coords / from_dmxs take at most %d categories in this build (from_primitives and from_anchors: %d)",
-                    kMaxCategories, kWideCategories);
     // The two structures (SoA coordinates + categories), the weight-function indices and -- for calls of up to kDirectOutPairs
     // rows -- the scores travel through the context's pinned staging block (one asynchronous copy in, none out); nothing is
     // allocated per call.
@@ -1793,9 +1794,6 @@ extern "C" int lchd_from_coords_dev(lchd_ctx* c, lchd_cloud* a, lchd_cloud* b, c
     if (a->n == 0) return LCHD_OK;
     if (!d_out) return fail(LCHD_EVALUE, "null score pointer");
     if (a->n > 65535) return fail(LCHD_EUNSUPPORTED, "dense rows of more than 65535 points are not supported by this build (got %lld)", (long long)a->n);
-    if (c->h_cfg.n_categories > kMaxCategories)
-        return fail(LCHD_EUNSUPPORTED, "from_coords takes at most %d categories in this build (from_primitives and from_anchors: %d)", kMaxCategories,
-                    kWideCategories);
     CTX_GUARD(c);
     bool retry = false;
     for (int attempt = 0; attempt < 2; ++attempt) {

@@ -1134,7 +1134,7 @@ constexpr int kRowBucketsBig = 16384;    // ... for rows of up to 65535 points (
 constexpr int kRowCoarse = 256;       // uniform bins of the row's empirical distance CDF
 constexpr int kRowBucketLimit = 64;   // a fuller bucket sends the row to the bitonic network instead
 
-template <int NT, bool GLOBALKV>
+template <int NT, bool GLOBALKV, class VT = uint8_t>  // VT uint16_t: more than 255 categories (EnvStore::cat16, CloudView::cat_hi)
 __global__ __launch_bounds__(NT) void k_env_rows(const DevConfig* __restrict__ cfgp, CloudView c, const double* __restrict__ dmx,
                                                  int64_t ld, int64_t row_len, int n2, int n_buckets, double image_bound, EnvStore env,
                                                  DeviceStatus* st, RowExtras ex) {
@@ -1153,9 +1153,10 @@ __global__ __launch_bounds__(NT) void k_env_rows(const DevConfig* __restrict__ c
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int64_t r_ = blockIdx.x;
     uint64_t* key = GLOBALKV ? env.key + r_ * env.stride : reinterpret_cast<uint64_t*>(smem);
-    uint8_t* val = GLOBALKV ? env.cat + r_ * env.stride : smem + (size_t)n2 * 8;
+    VT* val = GLOBALKV ? reinterpret_cast<VT*>(env.cat) + r_ * env.stride : reinterpret_cast<VT*>(smem + (size_t)n2 * 8);
+    constexpr size_t kPer = 8 + sizeof(VT);
     uint32_t* hist = GLOBALKV ? reinterpret_cast<uint32_t*>(smem)
-                              : reinterpret_cast<uint32_t*>(smem + (size_t)n2 * 9 + ((16 - (((size_t)n2 * 9) & 15)) & 15));  // [n_buckets + 1]
+                              : reinterpret_cast<uint32_t*>(smem + (size_t)n2 * kPer + ((16 - (((size_t)n2 * kPer) & 15)) & 15));  // [n_buckets + 1]
     const int kRowBuckets = n_buckets;
     __shared__ double red_max[16];
     __shared__ uint32_t red_cnt[16];
@@ -1167,6 +1168,10 @@ __global__ __launch_bounds__(NT) void k_env_rows(const DevConfig* __restrict__ c
     if (n <= 0) return;  // (an environment its collector flagged as empty or too large)
     const double* __restrict__ row = dmx ? dmx + r * ld : nullptr;
     const uint8_t* __restrict__ cats = ex.row_cat ? ex.row_cat + r * ld : c.cat;
+    auto cat_at = [&](int i) -> VT {  // (two-byte ids: the structure's own planes; the collected rows of k_env_collect are one-byte only)
+        if constexpr (sizeof(VT) == 2) return (VT)cat_of_atom(c, i);
+        else return cats[i];
+    };
     double ax = 0.0, ay = 0.0, az = 0.0;
     if (!dmx) { ax = c.x[r]; ay = c.y[r]; az = c.z[r]; }
     // The bucketing phases work on a MONOTONE image of the distance -- the squared distance for coordinates (no square root
@@ -1242,10 +1247,10 @@ __global__ __launch_bounds__(NT) void k_env_rows(const DevConfig* __restrict__ c
     if (biggest > (uint32_t)kRowBucketLimit) {
         for (int i = tid; i < n2; i += NT) {
             key[i] = i < n ? d2u(dist_of(i, bad)) : kPadKey;
-            val[i] = i < n ? cats[i] : (uint8_t)0;
+            val[i] = i < n ? cat_at(i) : (VT)0;
         }
         __syncthreads();
-        bitonic_sort_lds<NT>(key, val, n2, tid);
+        bitonic_sort_lds<NT, VT>(key, val, n2, tid);
     } else {
         // 4. exclusive scan: hist[b] = first slot of bucket b
         for (int base = 0; base < kRowBuckets; base += NT) {
@@ -1267,7 +1272,7 @@ __global__ __launch_bounds__(NT) void k_env_rows(const DevConfig* __restrict__ c
             const double m = image_of(i, bad);
             const uint32_t pos = atomicAdd(&hist[bucket_of(m)], 1u);
             key[pos] = d2u(dist_from_image(m));
-            val[pos] = cats[i];
+            val[pos] = cat_at(i);
         }
         __syncthreads();
         // 6. finish every bucket with an insertion sort on the exact keys
@@ -1275,7 +1280,7 @@ __global__ __launch_bounds__(NT) void k_env_rows(const DevConfig* __restrict__ c
             const int lo = b ? (int)hist[b - 1] : 0, hi = (int)hist[b];
             for (int i = lo + 1; i < hi; ++i) {
                 const uint64_t k = key[i];
-                const uint8_t v = val[i];
+                const VT v = val[i];
                 int j = i - 1;
                 while (j >= lo && key[j] > k) { key[j + 1] = key[j]; val[j + 1] = val[j]; --j; }
                 key[j + 1] = k;
@@ -1295,16 +1300,16 @@ __global__ __launch_bounds__(NT) void k_env_rows(const DevConfig* __restrict__ c
         bool bad_c = false;
         if constexpr (!GLOBALKV) {
             uint64_t* ok_ = env.key + r * env.stride;
-            uint8_t* oc_ = env.cat + r * env.stride;
+            VT* oc_ = reinterpret_cast<VT*>(env.cat) + r * env.stride;
             for (int i = tid; i < n; i += NT) {
-                const uint8_t v = val[i];
+                const VT v = val[i];
                 bad_c |= (int)v >= C;
                 ok_[i] = key[i];
-                oc_[i] = (int)v < C ? v : (uint8_t)0;
+                oc_[i] = (int)v < C ? v : (VT)0;
             }
         } else {
             for (int i = tid; i < n; i += NT) {
-                const uint8_t v = val[i];
+                const VT v = val[i];
                 if ((int)v >= C) { bad_c = true; val[i] = 0; }
             }
         }
@@ -1793,6 +1798,18 @@ bool launch_env_rows(hipStream_t s, int cap, const DevConfig* cfg, const CloudVi
     if (n_rows <= 0) return true;
     if (cap > 65536 || row_len > cap || row_len > 65535) return false;
     const dim3 grid((unsigned)n_rows);
+    if (env.cat16) {  // more than 255 categories: two bytes per point (rows of up to 8192 points in LDS, longer ones in the store)
+        if (ex.row_cat) return false;
+        if (cap > 8192) {
+            const size_t lds = (size_t)(kRowBucketsBig + 1) * sizeof(uint32_t) + 16;
+            k_env_rows<1024, true, uint16_t><<<grid, 1024, lds, s>>>(cfg, c, dmx, ld, row_len, cap, kRowBucketsBig, image_bound, env, st, ex);
+        } else {
+            const size_t lds = (size_t)cap * 10 + 16 + (size_t)(kRowBucketsSmall + 1) * sizeof(uint32_t);
+            if (cap <= 1024) k_env_rows<64, false, uint16_t><<<grid, 64, lds, s>>>(cfg, c, dmx, ld, row_len, cap, kRowBucketsSmall, image_bound, env, st, ex);
+            else k_env_rows<1024, false, uint16_t><<<grid, 1024, lds, s>>>(cfg, c, dmx, ld, row_len, cap, kRowBucketsSmall, image_bound, env, st, ex);
+        }
+        return true;
+    }
     if (cap > 16384) {  // keys in global memory, 64 KB histogram in LDS
         const size_t lds = (size_t)(kRowBucketsBig + 1) * sizeof(uint32_t) + 16;
         k_env_rows<1024, true><<<grid, 1024, lds, s>>>(cfg, c, dmx, ld, row_len, cap, kRowBucketsBig, image_bound, env, st, ex);
@@ -3745,6 +3762,8 @@ void init_device_kernels() {
     raise(reinterpret_cast<const void*>(&k_env_cells<1024, true, uint16_t>), 8192 * 10);
     raise(reinterpret_cast<const void*>(&k_env_rows<1024, true>), (int)((kRowBucketsBig + 1) * sizeof(uint32_t) + 16));
     raise(reinterpret_cast<const void*>(&k_env_rows<1024, false>), 16384 * 9 + 16 + (kRowBucketsSmall + 1) * 4);
+    raise(reinterpret_cast<const void*>(&k_env_rows<1024, true, uint16_t>), (int)((kRowBucketsBig + 1) * sizeof(uint32_t) + 16));
+    raise(reinterpret_cast<const void*>(&k_env_rows<1024, false, uint16_t>), 8192 * 10 + 16 + (kRowBucketsSmall + 1) * 4);
     raise(reinterpret_cast<const void*>(&k_env_rows2<1024, 16, 1>), 16384 * 9 + 16 + (kRowBucketsSmall + 1) * 4);
     raise(reinterpret_cast<const void*>(&k_env_rows2<1024, 10, 1>), 16384 * 9 + 16 + (kRowBucketsSmall + 1) * 4);
 #ifdef LCHD_ROWS_NT512

@@ -364,8 +364,8 @@ def test_two_contexts_and_capacity_decay(lh, oracle):
 def test_three_hundred_categories(lh, oracle):
     """The reference's category map is an arbitrary HashMap (/root/reference/src/locohd.rs:312-316).  Beyond 255 categories
     the ids travel as 16 bits (k_env_cells<.., uint16_t>, k_sweep_wide<.., CAT16>): from_anchors and from_primitives, every
-    statistical-distance family, category weights, a weight-function dictionary, both tag rules.  from_coords / from_dmxs and
-    more than 512 categories stay loud refusals."""
+    statistical-distance family, category weights, a weight-function dictionary, both tag rules; from_coords / from_dmxs in
+    test_three_hundred_categories_dense below.  More than 512 categories stay a loud refusal."""
     rng = np.random.default_rng(61)
     cats = [f"t{i}" for i in range(300)]
     n = 500
@@ -413,9 +413,57 @@ def test_three_hundred_categories(lh, oracle):
     with pytest.raises(ValueError):
         lchd.from_primitives(prims(lh, ["t1", "nope"], xa[:2] * 0.01), prims(lh, ["t1", "t2"], xb[:2] * 0.01), [(0, 0)], 8.0)
     with pytest.raises(NotImplementedError):
-        lchd.from_coords(sa[:10], sb[:10], xa[:10], xb[:10])
-    with pytest.raises(NotImplementedError):
         lh.LoCoHD([f"c{i}" for i in range(513)]).from_anchors(["c0"], ["c0"], [0.0], [0.0])
+    with pytest.raises(NotImplementedError):
+        lh.LoCoHD([f"c{i}" for i in range(513)]).from_coords(["c0"], ["c0"], [[0.0, 0.0, 0.0]], [[0.0, 0.0, 0.0]])
+
+
+@pytest.mark.parametrize("n", [1, 7, 300, 1100, 9000])
+def test_three_hundred_categories_dense(lh, oracle, n):
+    """from_coords / from_dmxs (square and ragged) with 300 categories: k_env_rows<.., uint16_t> (rows of up to 8192 points sorted
+    in LDS, longer ones in the environment store) + k_sweep_wide<.., CAT16>.  Against the oracle (sampled rows at 9000)."""
+    rng = np.random.default_rng(300 + n)
+    cats = [f"t{i}" for i in range(300)]
+    sa, sb = rng.choice(cats, n).tolist(), rng.choice(cats, n).tolist()
+    if n > 2:
+        sa[0], sb[0], sa[1], sb[1] = "t299", "t254", "t255", "t256"  # ids on both sides of the one-byte boundary
+    side = (n / 0.05) ** (1 / 3) + 1.0
+    xa, xb = rng.uniform(0, side, (n, 3)), rng.uniform(0, side, (n, 3))
+    wf = ("hyper_exp", [1.0, 0.2])
+    g, o = lh.LoCoHD(cats, lh.WeightFunction(*wf)), oracle.LoCoHD(cats, oracle.WeightFunction(*wf), n_of_threads=8)
+    got = np.asarray(g.from_coords(sa, sb, xa, xb))
+    if n <= 1100:
+        want = np.asarray(o.from_coords(sa, sb, xa, xb))
+        assert np.max(np.abs(got - want)) < TIGHT
+    else:  # the oracle on a sample of rows: from_anchors on the row's own sorted distances
+        for r in rng.integers(0, n, 12):
+            da, db = np.linalg.norm(xa - xa[r], axis=1), np.linalg.norm(xb - xb[r], axis=1)
+            ia, ib = np.argsort(da, kind="stable"), np.argsort(db, kind="stable")
+            want = o.from_anchors([sa[i] for i in ia], [sb[i] for i in ib], da[ia].tolist(), db[ib].tolist())
+            assert abs(got[r] - want) < 1e-11, r
+    if n > 1100:
+        return
+    # given distance matrices, other distance families, category weights
+    dma = np.linalg.norm(xa[:, None] - xa[None], axis=2)
+    dmb = np.linalg.norm(xb[:, None] - xb[None], axis=2)
+    w = rng.uniform(0.5, 2.0, 300).tolist()
+    for kw in (dict(), dict(category_weights=w), dict(sd=("Kolmogorov-Smirnov", [])), dict(sd=("Renyi", [1.7, 1e-9]))):
+        def make(mod):
+            k = {key: val for key, val in kw.items() if key != "sd"}
+            if "sd" in kw:
+                k["statistical_distance"] = mod.StatisticalDistance(*kw["sd"])
+            return mod.LoCoHD(cats, mod.WeightFunction(*wf), **k)
+        got = np.asarray(make(lh).from_dmxs(sa, sb, dma.tolist(), dmb.tolist()))
+        want = np.asarray(make(oracle).from_dmxs(sa, sb, dma.tolist(), dmb.tolist()))
+        assert np.max(np.abs(got - want)) < TIGHT, kw
+    if n >= 7:  # ragged rows: row r is sorted with a prefix of seq (utils.rs:25-39)
+        ra = [sorted(rng.uniform(0, 9, int(k)).tolist()) for k in rng.integers(1, n + 1, n)]
+        rb = [sorted(rng.uniform(0, 9, int(k)).tolist()) for k in rng.integers(1, n + 1, n)]
+        for row in ra + rb:
+            row[0] = 0.0
+        got = np.asarray(g.from_dmxs(sa, sb, ra, rb))
+        want = np.asarray([o.from_anchors(sa[: len(x)], sb[: len(y)], x, y) for x, y in zip(ra, rb)])  # (the rows are ascending already)
+        assert np.max(np.abs(got - want)) < TIGHT
 
 
 def test_error_behaviour(lh):
