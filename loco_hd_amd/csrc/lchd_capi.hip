@@ -1851,7 +1851,9 @@ extern "C" int lchd_from_anchors(lchd_ctx* c, const lchd_config* cfg, const int3
     if (len_seq_a != len_dists_a || len_seq_b != len_dists_b) return fail(LCHD_EVALUE, "Lists seq and dists must have equal lengths!");
     if (len_seq_a == 0 || len_seq_b == 0) return fail(LCHD_EPANIC, "index out of bounds: the len is 0 but the index is 0");
     if (dists_a[0] != 0.0 || dists_b[0] != 0.0) return fail(LCHD_EVALUE, "The dists list must start with a distance of 0!");
-    if (len_seq_a > 65535 || len_seq_b > 65535) return fail(LCHD_EUNSUPPORTED, "environments of more than 65535 points are not supported");
+    // environments of more than 65 535 points: the 64-bit-count form of the wide sweep (8-bit category ids, 24-bit lengths)
+    if ((len_seq_a > 65535 || len_seq_b > 65535) && (cfg->n_categories > kMaxCategories || len_seq_a >= (1 << 24) || len_seq_b >= (1 << 24)))
+        return fail(LCHD_EUNSUPPORTED, "environments of more than 65535 points are supported with at most %d categories and fewer than 2^24 points", kMaxCategories);
     for (int side = 0; side < 2; ++side) {
         const double* d = side ? dists_b : dists_a;
         const int64_t n = side ? len_dists_b : len_dists_a;

@@ -3234,9 +3234,15 @@ constexpr int kWideMaxCat = kWideCategories;  // (512: the per-lane count column
 // Many-categories variant (32 < C <= 255): the per-lane category counts live in LDS columns instead of registers, all
 // category loops are runtime loops, and the sqrt tables are read from global memory.  Slower per pair than k_sweep,
 // but independent of the category count in registers.  WPB = anchor pairs (wavefronts) per workgroup.
-template <int MODE, int FMODE, int WPB, bool CAT16 = false>  // CAT16: 16-bit category ids in the environment store (EnvStore::cat16)
+// BIG: environments of more than 65 535 points (the reference sorts and sweeps any length, utils.rs:25-39): the two counts of a
+// category are the halves of a 64-bit word instead of a 32-bit one, square roots beyond the 65 536-entry tables are computed.
+template <int MODE, int FMODE, int WPB, bool CAT16 = false, bool BIG = false>  // CAT16: 16-bit category ids in the environment store (EnvStore::cat16)
 __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
+    static_assert(!(BIG && CAT16), "the pair record holds a 24-bit length next to an 8-bit category");
     using CT = typename std::conditional<CAT16, uint16_t, uint8_t>::type;
+    using W = typename std::conditional<BIG, uint64_t, uint32_t>::type;  // count of side A | count of side B << SH
+    constexpr int SH = BIG ? 32 : 16;
+    constexpr W kOneA = (W)1, kOneB = (W)1 << SH, kMaskA = kOneB - 1;
     constexpr int TILE = kSweepTile;
     constexpr bool LDSTAB = false;
     constexpr bool H2 = (MODE != MODE_GEN);
@@ -3246,7 +3252,7 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
     __shared__ double t_sqrt[NT], t_rsqrt[NT];
     __shared__ double w_s[kWideMaxCat], sw_s[kWideMaxCat];
-    __shared__ uint32_t carry_[WPB][kWideMaxCat];  // per category: counts before the current tile (A | B << 16)
+    __shared__ W carry_[WPB][BIG ? 256 : kWideMaxCat];  // per category: counts before the current tile (A | B << SH)
     __shared__ uint64_t sA_[WPB][TILE], sB_[WPB][TILE];
     __shared__ CT cA_[WPB][TILE], cB_[WPB][TILE];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -3270,11 +3276,23 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
     uint64_t* sB = sB_[wv];
     CT* cA = cA_[wv];
     CT* cB = cB_[wv];
-    uint32_t* carry = carry_[wv];
-    uint32_t* cnt = reinterpret_cast<uint32_t*>(smem_dyn) + (size_t)wv * C * 64 + lane;  // this lane's column: cnt[c * 64]
+    W* carry = carry_[wv];
+    W* cnt = reinterpret_cast<W*>(smem_dyn) + (size_t)wv * C * 64 + lane;  // this lane's column: cnt[c * 64]
 
-    auto sqrt_cnt = [&](int k) -> double { if constexpr (LDSTAB) return t_sqrt[k]; else return g_sqrt[k]; };
-    auto rsqrt_cnt = [&](int k) -> double { if constexpr (LDSTAB) return t_rsqrt[k]; else return g_rsqrt[k]; };
+    auto sqrt_cnt = [&](int k) -> double {
+        if constexpr (LDSTAB) return t_sqrt[k];
+        else if constexpr (BIG) return k < 65536 ? g_sqrt[k] : sqrt((double)k);  // (k_fill_sqrt_tables: the same expressions)
+        else return g_sqrt[k];
+    };
+    auto rsqrt_cnt = [&](int k) -> double {
+        if constexpr (LDSTAB) return t_rsqrt[k];
+        else if constexpr (BIG) return k < 65536 ? g_rsqrt[k] : 1.0 / sqrt((double)k);
+        else return g_rsqrt[k];
+    };
+    auto scan_counts = [&](W x) -> W {  // inclusive wave scan of both halves at once (no half overflows: counts stay below 2^SH)
+        if constexpr (BIG) return (W)wave_incl_scan_u32((uint32_t)x) | ((W)wave_incl_scan_u32((uint32_t)(x >> 32)) << 32);
+        else return wave_incl_scan_u32(x);
+    };
 
     // One 16-byte record per pair (k_pair_meta) replaces the dependent chain anchors -> slot -> len -> first category; the
     // record of the wave's NEXT pair is requested before the current pair is processed.
@@ -3344,8 +3362,8 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
         auto exact_h2 = [&]() -> double {
             double acc2 = 0.0;
             for (int c = 0; c < C; ++c) {
-                const uint32_t v = cnt[c * 64];
-                double xa = sqrt_cnt((int)(v & 0xFFFFu)), xb = sqrt_cnt((int)(v >> 16));
+                const W v = cnt[c * 64];
+                double xa = sqrt_cnt((int)(v & kMaskA)), xb = sqrt_cnt((int)(v >> SH));
                 if constexpr (MODE == MODE_H2W) { xa *= sw_s[c]; xb *= sw_s[c]; }
                 const double d = xa * ra - xb * rb;  // equal inputs cancel exactly
                 acc2 = fma(d, d, acc2);
@@ -3364,9 +3382,9 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
                 double pn[kWideMaxCat], qn[kWideMaxCat];
                 double sa_ = 0.0, sb_ = 0.0;  // pmf.rs:67-68: fresh sums
                 for (int c = 0; c < C; ++c) {
-                    const uint32_t v = cnt[c * 64];
-                    pn[c] = w_s[c] * (double)(v & 0xFFFFu);
-                    qn[c] = w_s[c] * (double)(v >> 16);
+                    const W v = cnt[c * 64];
+                    pn[c] = w_s[c] * (double)(v & kMaskA);
+                    qn[c] = w_s[c] * (double)(v >> SH);
                     sa_ += pn[c];
                     sb_ += qn[c];
                 }
@@ -3380,8 +3398,8 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
         // seed with the two anchors (:82-84): carry row and every lane's column
         if (c0a >= C || c0b >= C) bad_cat = true;
         wave_sync_lds();
-        for (int c = lane; c < C; c += 64) carry[c] = (c == c0a ? 1u : 0u) | (c == c0b ? 0x10000u : 0u);
-        for (int c = 0; c < C; ++c) cnt[c * 64] = (c == c0a ? 1u : 0u) | (c == c0b ? 0x10000u : 0u);
+        for (int c = lane; c < C; c += 64) carry[c] = (c == c0a ? kOneA : (W)0) | (c == c0b ? kOneB : (W)0);
+        for (int c = 0; c < C; ++c) cnt[c * 64] = (c == c0a ? kOneA : (W)0) | (c == c0b ? kOneB : (W)0);
         if constexpr (H2) {
             if (c0a == c0b && !bad_cat) D = (MODE == MODE_H2W) ? w_s[c0a & (kWideMaxCat - 1)] : 1.0;
             if constexpr (MODE == MODE_H2W) {
@@ -3415,14 +3433,14 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
             const int j0 = d0 - i0, j1 = d1 - i1;
 
             // pass 1: histogram of this lane's chunk into its LDS column
-            for (int c = 0; c < C; ++c) cnt[c * 64] = 0u;
+            for (int c = 0; c < C; ++c) cnt[c * 64] = (W)0;
             for (int i = i0; i < i1; ++i) {
                 const int ct = cA[i];
-                if (ct >= C) bad_cat = true; else cnt[ct * 64] += 1u;
+                if (ct >= C) bad_cat = true; else cnt[ct * 64] += kOneA;
             }
             for (int j = j0; j < j1; ++j) {
                 const int ct = cB[j];
-                if (ct >= C) bad_cat = true; else cnt[ct * 64] += 0x10000u;
+                if (ct >= C) bad_cat = true; else cnt[ct * 64] += kOneB;
             }
             // per category: wave64 inclusive scan (the carry of earlier tiles enters through lane 0); the exclusive
             // prefix = counts at this lane's first event.  Both 16-bit halves scan at once (every count < 65536).
@@ -3431,13 +3449,13 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
             if constexpr (H2) D = 0.0;
             if constexpr (MODE == MODE_H2W) na = nb = 0.0;
             for (int c = 0; c < C; ++c) {
-                const uint32_t own = cnt[c * 64];
-                const uint32_t incl = wave_incl_scan_u32(own + (lane == 0 ? carry[c] : 0u));
-                const uint32_t excl = incl - own;
+                const W own = cnt[c * 64];
+                const W incl = scan_counts(own + (lane == 0 ? carry[c] : (W)0));
+                const W excl = incl - own;
                 cnt[c * 64] = excl;
                 if (lane == 63) carry[c] = incl;
                 if constexpr (H2) {
-                    const int ca = (int)(excl & 0xFFFFu), cb = (int)(excl >> 16);
+                    const int ca = (int)(excl & kMaskA), cb = (int)(excl >> SH);
                     if constexpr (MODE == MODE_H2W) {
                         D += w_s[c] * (sqrt_cnt(ca) * sqrt_cnt(cb));
                         na += w_s[c] * (double)ca;
@@ -3464,12 +3482,12 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
                 // pmf.rs:47-63: one more point of category ct on one side
                 const bool okc = ct < C;
                 const int cs = okc ? ct : 0;
-                const uint32_t old = cnt[cs * 64];
-                cnt[cs * 64] = old + (okc ? (takeA ? 1u : 0x10000u) : 0u);
+                const W old = cnt[cs * 64];
+                cnt[cs * 64] = old + (okc ? (takeA ? kOneA : kOneB) : (W)0);
                 totA += takeA ? 1 : 0;
                 totB += takeA ? 0 : 1;
                 if constexpr (H2) {
-                    const int cntA_ = (int)(old & 0xFFFFu), cntB_ = (int)(old >> 16);
+                    const int cntA_ = (int)(old & kMaskA), cntB_ = (int)(old >> SH);
                     const int mine = takeA ? cntA_ : cntB_, other = takeA ? cntB_ : cntA_;
                     double delta = (sqrt_cnt(mine + 1) - sqrt_cnt(mine)) * sqrt_cnt(other);
                     if constexpr (MODE == MODE_H2W) {
@@ -3537,7 +3555,12 @@ static void launch_sweep_f(hipStream_t s, int cmax, unsigned grid, int fmode, co
 template <int MODE>
 static void launch_sweep_wide(hipStream_t s, int n_cat, int64_t n_pairs, int fmode, const SweepArgs& a) {
     // dynamic LDS = WPB * C * 64 * 4 bytes of per-lane count columns
-    if (n_cat <= 64) {
+    if (a.env_a.stride > 65535 || a.env_b.stride > 65535) {  // environments of more than 65 535 points: 64-bit count words (<= 255 categories: the host checks)
+        const unsigned grid = (unsigned)(n_pairs < 8192 ? n_pairs : 8192);
+        const size_t dyn = (size_t)n_cat * 512;
+        if (fmode == F_KEY) k_sweep_wide<MODE, F_KEY, 1, false, true><<<grid, 64, dyn, s>>>(a);
+        else k_sweep_wide<MODE, F_ANY, 1, false, true><<<grid, 64, dyn, s>>>(a);
+    } else if (n_cat <= 64) {
         const int64_t blocks = (n_pairs + 3) / 4;
         const unsigned grid = (unsigned)(blocks < 4096 ? blocks : 4096);
         const size_t dyn = (size_t)4 * n_cat * 256;
@@ -3645,7 +3668,7 @@ int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinge
         else k_sweep<32, MODE_H2U, F_KEY, true, false, true><<<g, NTH, 0, s>>>(a);
         return 0;
     }
-    const bool wide = n_categories > 32 || t.force_wide;
+    const bool wide = n_categories > 32 || t.force_wide || a.env_a.stride > 65535 || a.env_b.stride > 65535;  // (long environments: the 64-bit-count form of the wide sweep)
     const int64_t blocks = (a.n_pairs + kSweepWaves - 1) / kSweepWaves;
     // grid-stride: LDS tables are built once per block.  8192 workgroups = 8 rounds of the 1024 that are resident at a time: finer
     // than that the table loads show, coarser the last round's imbalance does (measured on C2a: 4096 +2.8 %, 16384 +0.5 %)
@@ -3777,6 +3800,12 @@ void init_device_kernels() {
     raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_H2U, F_ANY, 1>), 256 * 256);
     raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_H2W, F_KEY, 1>), 256 * 256);
     raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_H2W, F_ANY, 1>), 256 * 256);
+    raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_GEN, F_KEY, 1, false, true>), 256 * 512);
+    raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_GEN, F_ANY, 1, false, true>), 256 * 512);
+    raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_H2U, F_KEY, 1, false, true>), 256 * 512);
+    raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_H2U, F_ANY, 1, false, true>), 256 * 512);
+    raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_H2W, F_KEY, 1, false, true>), 256 * 512);
+    raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_H2W, F_ANY, 1, false, true>), 256 * 512);
     raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_GEN, F_KEY, 1, true>), kWideCategories * 256);
     raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_GEN, F_ANY, 1, true>), kWideCategories * 256);
     raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_H2U, F_KEY, 1, true>), kWideCategories * 256);

@@ -466,6 +466,40 @@ def test_three_hundred_categories_dense(lh, oracle, n):
         assert np.max(np.abs(got - want)) < TIGHT
 
 
+@pytest.mark.parametrize("ncat", [5, 40, 200])
+def test_from_anchors_beyond_65535_points(lh, oracle, ncat):
+    """The reference sweeps lists of any length (/root/reference/src/locohd.rs:61-226).  Beyond 65 535 points the counts of a category
+    no longer fit the 16-bit fields of the regular sweeps: the 64-bit-count form of the wide sweep (k_sweep_wide<.., BIG>) takes over,
+    with square roots beyond the 65 536-entry tables computed.  One dominant category makes a single count pass 65 535."""
+    rng = np.random.default_rng(65 + ncat)
+    cats = [f"c{i}" for i in range(ncat)]
+    w = rng.uniform(0.5, 2.0, ncat).tolist()
+    for na, nb in ((70_000, 300), (66_000, 131_500), (65_536, 65_535)):
+        pa = np.full(ncat, 0.1 / max(ncat - 1, 1)); pa[0] = 0.9  # ~90 % of side A in one category
+        sa = [cats[i] for i in rng.choice(ncat, na, p=pa / pa.sum())]
+        sb = [cats[i] for i in rng.integers(0, ncat, nb)]
+        da, db = np.sort(rng.uniform(0, 30, na)), np.sort(rng.uniform(0, 30, nb))
+        da[0] = db[0] = 0.0
+        da[5:9] = da[5]  # ties inside a list and across the lists
+        db[3] = da[5]
+        db = np.sort(db)
+        for kw in (dict(), dict(category_weights=w), dict(sd=("Kolmogorov-Smirnov", [])), dict(sd=("Hellinger", [3.0]))):
+            def make(mod):
+                k = {key: val for key, val in kw.items() if key != "sd"}
+                if "sd" in kw:
+                    k["statistical_distance"] = mod.StatisticalDistance(*kw["sd"])
+                return mod.LoCoHD(cats, mod.WeightFunction("hyper_exp", [1.0, 0.2]), **k)
+            got = make(lh).from_anchors(sa, sb, da.tolist(), db.tolist())
+            want = make(oracle).from_anchors(sa, sb, da.tolist(), db.tolist())
+            assert abs(got - want) < 1e-11, (na, nb, kw)
+        if ncat == 5:  # a weight-function dictionary (the sweep evaluates the CDF itself)
+            mk = lambda mod: mod.LoCoHD(cats, {"u": mod.WeightFunction("uniform", [3.0, 20.0]), "k": mod.WeightFunction("kumaraswamy", [1.0, 28.0, 2.0, 3.0])})
+            assert abs(mk(lh).from_anchors(sa, sb, da.tolist(), db.tolist(), "k") - mk(oracle).from_anchors(sa, sb, da.tolist(), db.tolist(), "k")) < 1e-11
+    with pytest.raises(NotImplementedError):  # more than 255 categories AND more than 65 535 points: still refused, loudly
+        many = [f"c{i}" for i in range(300)]
+        lh.LoCoHD(many).from_anchors(["c0"] * 70_000, ["c1"], [0.0] * 70_000, [0.0])
+
+
 def test_error_behaviour(lh):
     lchd = lh.LoCoHD(["A", "B"], lh.WeightFunction("uniform", [0.0, 4.0]))
     with pytest.raises(ValueError):  # src/locohd.rs:70-73
