@@ -1015,9 +1015,9 @@ extern "C" int lchd_ctx_finish(lchd_ctx* c) {
         if (f & ST_BAD_ANCHOR) return status_to_rc(f, DRV_PRIMS);
         const int64_t biggest = c->h_status->max_env;  // largest environment of the pass (k_pair_meta), or what overflowed
         if (f & ST_ENV_OVERFLOW) {  // an environment did not fit the kernel variant's LDS capacity: run the pass again, larger
-            if (biggest > 65535)
-                return fail(LCHD_EUNSUPPORTED, "an environment holds %lld points; this build handles at most 65535 per environment "
-                                               "(the category counts of the sweep are 16-bit fields)", (long long)biggest);
+            if (biggest > 65535 && (c->h_cfg.n_categories > kMaxCategories || biggest > (1 << 23)))
+                return fail(LCHD_EUNSUPPORTED, "an environment holds %lld points; beyond 65535 per environment this build handles at most %d "
+                                               "categories and 2^23 points (the 64-bit-count sweep)", (long long)biggest, kMaxCategories);
             if (P.group && P.group_small && biggest <= kEnvGroupCap) {
                 c->group_small = false;  // the small instantiation of k_env_group overflowed: the same capacity with the regular one
             } else {
@@ -1723,9 +1723,9 @@ static int dense_driver(lchd_ctx* c, const lchd_config* cfg, const int32_t* seq_
     // utils.rs:25-39: the sort mask has row-length entries and indexes seq => a row longer than seq panics
     if (cols_a > len_seq_a || cols_b > len_seq_b) return fail(LCHD_EPANIC, "index out of bounds: a distance row is longer than its seq");
     if (cols_a == 0 || cols_b == 0) return fail(LCHD_EPANIC, "index out of bounds: empty distance row (src/locohd.rs:74)");
-    if (cols_a > 65535 || cols_b > 65535)
-        return fail(LCHD_EUNSUPPORTED, "dense rows of more than 65535 points are not supported by this build (got %lld / %lld)",
-                    (long long)cols_a, (long long)cols_b);
+    if ((cols_a > 65535 || cols_b > 65535) && (cfg->n_categories > kMaxCategories || cols_a > (1 << 23) || cols_b > (1 << 23)))
+        return fail(LCHD_EUNSUPPORTED, "dense rows of more than 65535 points are supported with at most %d categories and 2^23 points (got %lld / %lld)",
+                    kMaxCategories, (long long)cols_a, (long long)cols_b);
     // The two structures (SoA coordinates + categories), the weight-function indices and -- for calls of up to kDirectOutPairs
     // rows -- the scores travel through the context's pinned staging block (one asynchronous copy in, none out); nothing is
     // allocated per call.
@@ -1793,7 +1793,9 @@ extern "C" int lchd_from_coords_dev(lchd_ctx* c, lchd_cloud* a, lchd_cloud* b, c
     c->last_valid = false;
     if (a->n == 0) return LCHD_OK;
     if (!d_out) return fail(LCHD_EVALUE, "null score pointer");
-    if (a->n > 65535) return fail(LCHD_EUNSUPPORTED, "dense rows of more than 65535 points are not supported by this build (got %lld)", (long long)a->n);
+    if (a->n > 65535 && (c->h_cfg.n_categories > kMaxCategories || a->n > (1 << 23)))
+        return fail(LCHD_EUNSUPPORTED, "dense rows of more than 65535 points are supported with at most %d categories and 2^23 points (got %lld)",
+                    kMaxCategories, (long long)a->n);
     CTX_GUARD(c);
     bool retry = false;
     for (int attempt = 0; attempt < 2; ++attempt) {

@@ -1026,7 +1026,7 @@ static void launch_env_cells_nt(hipStream_t s, dim3 grid, size_t lds, bool tag_l
 // Thresholded environments of more than 16384 points (a threshold that swallows most of a large structure): too many keys for
 // LDS.  One 1024-thread workgroup per unique anchor walks the neighbour cells like k_env_cells and appends the survivors --
 // distance and category -- UNSORTED to the environment's scratch row in global memory; k_env_rows then sorts each scratch row
-// into the environment store in global memory (rows of up to 65535 points), exactly as it does for given distance rows.
+// into the environment store in global memory, exactly as it does for given distance rows.
 template <bool TAGLIST>
 __global__ __launch_bounds__(1024) void k_env_collect(const DevConfig* __restrict__ cfgp, EnvSides sides, double thr, int cap, DeviceStatus* st) {
     const int side = (int64_t)blockIdx.x >= sides.s[0].max_envs ? 1 : 0;
@@ -1093,7 +1093,7 @@ bool launch_env_cells(hipStream_t s, int cap, const DevConfig* cfg, bool tag_lis
                       DeviceStatus* st) {
     if (a.max_envs + b.max_envs <= 0) return true;
     const bool cat16 = a.env.cat16 != 0;
-    if (cap > 16384 && cap <= 65536 && !(cap & (cap - 1))) {  // collect unsorted, then the global-memory row sort
+    if (cap > 16384 && cap <= (1 << 23) && !(cap & (cap - 1))) {  // collect unsorted, then the global-memory row sort (beyond 65536: swept by k_sweep_wide<.., BIG>)
         if (!a.raw_key || !b.raw_key || cat16) return false;
         EnvSides sides;
         sides.s[0] = a;
@@ -1131,6 +1131,7 @@ bool launch_env_cells(hipStream_t s, int cap, const DevConfig* cfg, bool tag_lis
 constexpr int kRowBucketsSmall = 2048;   // distance buckets of the dense-row sort (rows <= 16384 points)
 constexpr int kRowBucketsMax = 8192;     // ... of k_env_rows2 when the row leaves room for them
 constexpr int kRowBucketsBig = 16384;    // ... for rows of up to 65535 points (keys stay in global memory)
+constexpr int kRowBucketsHuge = 32768;   // ... for longer rows
 constexpr int kRowCoarse = 256;       // uniform bins of the row's empirical distance CDF
 constexpr int kRowBucketLimit = 64;   // a fuller bucket sends the row to the bitonic network instead
 
@@ -1796,8 +1797,14 @@ bool launch_env_rows(hipStream_t s, int cap, const DevConfig* cfg, const CloudVi
                      int64_t n_rows, int64_t row_len, double image_bound, EnvStore env, DeviceStatus* st, const RowExtras& ex) {
     if (dmx) image_bound = 0.0;  // given rows: the kernel finds the largest finite entry itself
     if (n_rows <= 0) return true;
-    if (cap > 65536 || row_len > cap || row_len > 65535) return false;
+    if (row_len > cap || cap > (1 << 23)) return false;
     const dim3 grid((unsigned)n_rows);
+    if (cap > 65536) {  // rows of more than 65 535 points (swept by k_sweep_wide<.., BIG>): keys in the store, 32768 buckets (128 KB of LDS)
+        if (env.cat16) return false;
+        const size_t lds = (size_t)(kRowBucketsHuge + 1) * sizeof(uint32_t) + 16;
+        k_env_rows<1024, true><<<grid, 1024, lds, s>>>(cfg, c, dmx, ld, row_len, cap, kRowBucketsHuge, image_bound, env, st, ex);
+        return true;
+    }
     if (env.cat16) {  // more than 255 categories: two bytes per point (rows of up to 8192 points in LDS, longer ones in the store)
         if (ex.row_cat) return false;
         if (cap > 8192) {
@@ -3783,7 +3790,7 @@ void init_device_kernels() {
     raise(reinterpret_cast<const void*>(&k_env_cells<1024, true>), 16384 * 9);
     raise(reinterpret_cast<const void*>(&k_env_cells<1024, false, uint16_t>), 8192 * 10);
     raise(reinterpret_cast<const void*>(&k_env_cells<1024, true, uint16_t>), 8192 * 10);
-    raise(reinterpret_cast<const void*>(&k_env_rows<1024, true>), (int)((kRowBucketsBig + 1) * sizeof(uint32_t) + 16));
+    raise(reinterpret_cast<const void*>(&k_env_rows<1024, true>), (int)((kRowBucketsHuge + 1) * sizeof(uint32_t) + 16));
     raise(reinterpret_cast<const void*>(&k_env_rows<1024, false>), 16384 * 9 + 16 + (kRowBucketsSmall + 1) * 4);
     raise(reinterpret_cast<const void*>(&k_env_rows<1024, true, uint16_t>), (int)((kRowBucketsBig + 1) * sizeof(uint32_t) + 16));
     raise(reinterpret_cast<const void*>(&k_env_rows<1024, false, uint16_t>), 8192 * 10 + 16 + (kRowBucketsSmall + 1) * 4);

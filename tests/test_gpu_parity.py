@@ -500,6 +500,65 @@ def test_from_anchors_beyond_65535_points(lh, oracle, ncat):
         lh.LoCoHD(many).from_anchors(["c0"] * 70_000, ["c1"], [0.0] * 70_000, [0.0])
 
 
+def test_from_dmxs_rows_beyond_65535_points(lh, oracle):
+    """Distance rows of more than 65 535 entries (the reference co-sorts any length, utils.rs:25-39): sorted in the environment store
+    by k_env_rows<1024, GLOBALKV> with 32 768 buckets, swept by k_sweep_wide<.., BIG>.  Square and ragged, three rows each (from_coords
+    takes the same path, but its n x n rows at this size need > 100 GB of store: not a test)."""
+    rng = np.random.default_rng(6553)
+    cats = [f"c{i}" for i in range(12)]
+    na, nb = 70_000, 90_000
+    pa = np.full(12, 0.01); pa[3] = 0.89
+    sa = [cats[i] for i in rng.choice(12, na, p=pa / pa.sum())]
+    sb = [cats[i] for i in rng.integers(0, 12, nb)]
+    rows = 3
+    ma = rng.gamma(3.0, 4.0, (rows, na))  # (a skewed distance distribution: uneven buckets)
+    mb = rng.uniform(0, 40, (rows, nb))
+    ma[:, 7] = 0.0
+    mb[:, 11] = 0.0
+    ma[1, 100:4100] = ma[1, 100]  # thousands of equal distances in one row: the fuller-bucket path
+    g = lh.LoCoHD(cats, lh.WeightFunction("hyper_exp", [1.0, 0.1]))
+    o = oracle.LoCoHD(cats, oracle.WeightFunction("hyper_exp", [1.0, 0.1]))
+    got = np.asarray(g.from_dmxs(sa, sb, ma, mb))
+    for r in range(rows):
+        ia, ib = np.argsort(ma[r], kind="stable"), np.argsort(mb[r], kind="stable")
+        want = o.from_anchors([sa[i] for i in ia], [sb[i] for i in ib], ma[r][ia].tolist(), mb[r][ib].tolist())
+        assert abs(got[r] - want) < 1e-11, r
+    # ragged: row r is sorted with a prefix of seq
+    lens_a, lens_b = [na, 66_000, 10], [70_001, nb, 65_536]
+    ra = [ma[r, :k].tolist() for r, k in enumerate(lens_a)]
+    rb = [mb[r, :k].tolist() for r, k in enumerate(lens_b)]
+    ra[2][0] = 0.0
+    got = np.asarray(g.from_dmxs(sa, sb, ra, rb))
+    for r in range(rows):
+        x, y = np.asarray(ra[r]), np.asarray(rb[r])
+        ia, ib = np.argsort(x, kind="stable"), np.argsort(y, kind="stable")
+        want = o.from_anchors([sa[i] for i in ia], [sb[i] for i in ib], x[ia].tolist(), y[ib].tolist())
+        assert abs(got[r] - want) < 1e-11, r
+
+
+def test_from_primitives_environment_beyond_65535_points(lh, oracle):
+    """A threshold that swallows a 70 000-atom cloud: environments of more than 65 535 points are collected unsorted (k_env_collect),
+    sorted in the store (k_env_rows<1024, GLOBALKV>, 32 768 buckets) and swept with 64-bit count words (k_sweep_wide<.., BIG>);
+    the capacity grows 512 -> ... -> 131 072 through the overflow retries of the pass."""
+    rng = np.random.default_rng(70_000)
+    n = 70_000
+    cats = [f"c{i}" for i in range(6)]
+    v = rng.normal(size=(n, 3))
+    xa = v / np.linalg.norm(v, axis=1)[:, None] * (18.0 * rng.uniform(0, 1, n)[:, None] ** (1 / 3))
+    v = rng.normal(size=(n, 3))
+    xb = v / np.linalg.norm(v, axis=1)[:, None] * (18.0 * rng.uniform(0, 1, n)[:, None] ** (1 / 3))
+    ca, cb = rng.choice(6, n, p=[0.95, 0.01, 0.01, 0.01, 0.01, 0.01]).astype(np.int32), rng.integers(0, 6, n).astype(np.int32)
+    pairs = np.array([[0, 5], [17, 17], [n - 1, 3], [0, 3]], dtype=np.int64)
+    for rule, tag in ((None, np.zeros(n, dtype=np.int32)), ({"accept_same": False}, (np.arange(n) // 7).astype(np.int32))):
+        lo = oracle.LoCoHD(cats, oracle.WeightFunction("hyper_exp", [1.0, 0.1]), oracle.TagPairingRule(rule) if rule else None)
+        lg = lh.LoCoHD(cats, lh.WeightFunction("hyper_exp", [1.0, 0.1]), lh.TagPairingRule(rule) if rule else None)
+        want, sizes = lo.from_arrays(xa, ca, tag, xb, cb, tag, pairs, 40.0, return_env_sizes=True)
+        assert np.min(sizes) > 65_535
+        pk = lambda x, c: lh.api._Packed(x, c, tag)
+        got = lg.from_packed(pk(xa, ca), pk(xb, cb), pairs, 40.0)
+        assert np.max(np.abs(np.asarray(got) - np.asarray(want))) < 1e-11, rule
+
+
 def test_error_behaviour(lh):
     lchd = lh.LoCoHD(["A", "B"], lh.WeightFunction("uniform", [0.0, 4.0]))
     with pytest.raises(ValueError):  # src/locohd.rs:70-73
