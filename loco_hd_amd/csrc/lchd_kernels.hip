@@ -23,13 +23,14 @@
 //                           per-lane sequential sweep with a wavefront DPP prefix scan of packed category counts,
 //                           statistical distance per breakpoint, CDF differences, DPP reduction
 //                           (replaces stat_dist_integral :61-226, pmf.rs, statistical_distances.rs, cdfs.rs);
-//                           k_sweep_duo<CMAX>: two pairs per wavefront for small environments (the device decides which of the
-//                           two sweeps the small pairs); k_sweep_wide for 33..255 categories
+//                           k_sweep_duo<CMAX,TL,TILE>: the pairs that fit one tile, four (<= 224 events) or two (8-bit counts,
+//                           <= 480 events) per wavefront in teams of TL lanes -- the device or the host's hint decides which
+//                           rule is in force; k_sweep_wide for 33..512 categories and for environments beyond 65535 points
 //       trajectory frames   k_frames_labels / k_frames_unpack: SoA unpack + bounding box of a block of frames;
 //                           k_frames_centroids (+ k_bbox_finish): primitive atoms of every frame from its float32 source atoms
 //
 // One wavefront owns one environment (K1: a 64-thread workgroup) or one anchor pair (K2: four pairs per
-// 256-thread workgroup; k_sweep_duo: eight); a launch has thousands of independent wavefronts, so all 256 CUs / 8 XCDs are
+// 256-thread workgroup; k_sweep_duo: eight or sixteen); a launch has thousands of independent wavefronts, so all 256 CUs / 8 XCDs are
 // filled without any inter-workgroup communication.  All arithmetic is f64 like the reference; no MFMA
 // (there is no contraction in this path).
 #include <algorithm>
