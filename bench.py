@@ -379,7 +379,7 @@ def run_c4(args, torch, dist, dev, rank, world, use_dist):
                  f"chunks of {chunk} frames")
         result = base_result(args, world, p * world, elapsed, label, {"pairs_per_gpu": p, "mean_env_points_per_pair": env_points[0] / p,
                                                                       "sharding": "frames across ranks, no exchange step, scores stay on their rank"})
-        result["roofline"] = roofline_block("c4", {"env": "k_env_group (side A + side B)", "sweep": "k_sweep_duo<8, 16 lanes, 224 events> (four pairs per wavefront)"}[dom], algo / len(starts),
+        result["roofline"] = roofline_block("c4", {"env": "k_env_group (side A + side B)", "sweep": "k_sweep_duo<8, 16 lanes, 240 events> (four pairs per wavefront)"}[dom], algo / len(starts),
                                             phase[dom] / len(starts), len(starts), step_ms=result["ms_per_step"])
         result["kernel_ms"] = phase
         result["extras"] = {"k_frames_centroids": {"ms_per_step": phase["convert"], "algorithmic_bytes_per_step": conv_bytes,
@@ -526,7 +526,7 @@ def run_c3(args, torch, dist, dev, rank, world, use_dist):
                               "sharding": (f"tiles of the 50 x 50 decoy-pair matrix, one set per rank; a rank holds the decoys its tiles touch ({n_touched} here)"
                                            if args.scaling == "strong" else "every rank scores its own all-vs-all job"),
                               **collective_note(args, world, use_dist)})
-        result["roofline"] = roofline_block("c3", {"env": "k_env_group", "sweep": "k_sweep_duo<8, 16 lanes, 224 events> (four pairs per wavefront)"}[dom], algo, phase_ms[dom], step_ms=result["ms_per_step"])
+        result["roofline"] = roofline_block("c3", {"env": "k_env_group", "sweep": "k_sweep_duo<8, 16 lanes, 240 events> (four pairs per wavefront)"}[dom], algo, phase_ms[dom], step_ms=result["ms_per_step"])
         result["kernel_ms"] = phase_ms
         if emulated:
             emulated["single_gpu_ms"] = elapsed / args.steps * 1e3

@@ -173,7 +173,7 @@ struct lchd_ctx {
     HostStatus* h_status = nullptr;    // pinned, device-visible: the kernels publish into it with plain stores (no D2H copy)
     bool status_dirty = false;         // a pass was abandoned half-way: memset d_status before the next one
     uint32_t seq = 0;                  // pass counter (HostStatus::snapshot_seq)
-    int sweep_hint = 0;                // 0 unknown, else 4 | 1 (pairs of <= 224 events were the majority of the last pass) | 2 (pairs with both environments <= 255 points were): launch_sweep
+    int sweep_hint = 0;                // 0 unknown, else 4 | 1 (pairs of <= 240 events were the majority of the last pass) | 2 (pairs with both environments <= 255 points were): launch_sweep
     unsigned long long* d_points = nullptr;
     double* d_tabs = nullptr;  // sqrt(k) | 1/sqrt(k), 65536 entries each
     double* d_powtab = nullptr;  // k^(1/e) | k^(-1/e) for the configured Hellinger exponent (allocated when one is first configured)

@@ -265,10 +265,10 @@ struct SweepArgs {
     int32_t sd_fast;          // the configuration qualifies for k_sweep_inc (lchd_sweep_inc.hip): 0 no, 1 Kullback-Leibler form, 2 Renyi form
 };
 // sweep_hint: 0 = unknown (launch every candidate kernel, the device decides from the pair records); otherwise what
-// k_pair_meta counted in the previous pass of this configuration: 4 | 1 (pairs of at most 224 merged events were the
+// k_pair_meta counted in the previous pass of this configuration: 4 | 1 (pairs of at most 240 merged events were the
 // majority: k_sweep_duo + the indirect k_sweep) | 2 (pairs with both environments <= 255 points were: the 8-bit-count k_sweep
 // + the indirect one); neither: the plain k_sweep only.  Any choice is correct for any input; the hint only picks the launch set.
-// ... | 8 (every pair of the previous pass had at most 224 events) | 16 (... both environments <= 255 points): the companion
+// ... | 8 (every pair of the previous pass had at most 240 events) | 16 (... both environments <= 255 points): the companion
 // launch for the larger pairs is left out.  Returns 1 (the "small" rule of this pass was the 8-bit-count one) | 2 (the companion
 // launch was left out: the caller must check this pass's counts, HostStatus::n_duo / n_c8 against the number of pairs).
 int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinger2, bool unit_weights, bool wf_pow, int sweep_hint,

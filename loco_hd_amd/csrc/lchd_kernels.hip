@@ -23,7 +23,7 @@
 //                           per-lane sequential sweep with a wavefront DPP prefix scan of packed category counts,
 //                           statistical distance per breakpoint, CDF differences, DPP reduction
 //                           (replaces stat_dist_integral :61-226, pmf.rs, statistical_distances.rs, cdfs.rs);
-//                           k_sweep_duo<CMAX,TL,TILE>: the pairs that fit one tile, four (<= 224 events) or two (8-bit counts,
+//                           k_sweep_duo<CMAX,TL,TILE>: the pairs that fit one tile, four (<= 240 events) or two (8-bit counts,
 //                           <= 480 events) per wavefront in teams of TL lanes -- the device or the host's hint decides which
 //                           rule is in force; k_sweep_wide for 33..512 categories and for environments beyond 65535 points
 //       trajectory frames   k_frames_labels / k_frames_unpack: SoA unpack + bounding box of a block of frames;
@@ -1907,7 +1907,7 @@ enum { F_KEY = 0, F_FAST = 1, F_ANY = 2 };
 #ifndef LCHD_EPL_BIG
 #define LCHD_EPL_BIG 8   // merged events per lane per tile of the many-slot Hellinger-2 sweep (k_sweep<20..32>): tiles of 512
 #endif
-constexpr int kDuoTileFwd = 224;  // = kDuoTile (k_sweep_duo, below)
+constexpr int kDuoTileFwd = 240;  // = kDuoTile (k_sweep_duo, below)
 constexpr int kCount8MaxEnv = 255;        // the 8-bit-count sweep takes pairs whose environments both have at most this many points
 constexpr int kTeam8Tile = 480;           // ... and its two-pairs-per-wavefront form (k_sweep_duo<CMAX, 32, 480>) those of at most 32 x 15 merged events
 // which pairs the small-pair kernel of a launch sweeps (SweepArgs::small_rule); nA, nB: environment sizes incl. the anchor, both > 0
@@ -2908,7 +2908,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? (CMAX <= LCHD
 // host launches this kernel AND k_sweep; k_pair_meta counts the qualifying pairs (DeviceStatus::n_small): when they are
 // the majority this kernel sweeps them and k_sweep only the rest, otherwise this kernel returns at once.
 // ------------------------------------------------------------------------------------------------
-constexpr int kDuoTile = 224;  // merged events per pair: 16 lanes x 14
+constexpr int kDuoTile = 240;  // merged events per pair: 16 lanes x 15, the most the 4-bit chunk fields take (224 = 16 x 14 until late in round 3: at ~95 points per environment 8.7 % of C4's pairs were longer than that, 2.3 % are longer than 240 -- C4 sweep 3.27 -> 3.19 ms, C3 0.867 -> 0.837)
 #ifndef LCHD_TEAM_BIG_WAVES
 #define LCHD_TEAM_BIG_WAVES 3   // waves per SIMD k_sweep_duo is compiled for with more than 16 category slots
 #endif
@@ -2918,9 +2918,7 @@ constexpr int kDuoTile = 224;  // merged events per pair: 16 lanes x 14
 #ifndef LCHD_TEAM_LOOP_UNROLL
 #define LCHD_TEAM_LOOP_UNROLL 1
 #endif
-#ifndef LCHD_DUO_TL
-#define LCHD_DUO_TL 16   // lanes per pair of k_sweep_duo (32: two pairs per wavefront, the round-1 form; 16: four)
-#endif
+#define LCHD_DUO_TL 16   // lanes per pair of k_sweep_duo's <= 240-event form: four pairs per wavefront (round 1 / 2: 32 lanes, two pairs, 224 events)
 // inclusive scan / sum inside each team of TL consecutive lanes (TL = 16: one DPP row; 32: two rows joined by row_bcast:15)
 template <int TL>
 __device__ __forceinline__ uint32_t team_incl_scan_u32(uint32_t x) {
@@ -2950,7 +2948,7 @@ __device__ __forceinline__ double team_sum_f64(double v) {  // the last lane of 
 // (the name is historic: round 1 swept TWO pairs per wavefront; with TL = 16 a wavefront sweeps FOUR -- the per-tile prologue, which
 // is two thirds of this kernel's instructions at ~150 events per pair, is shared by twice as many pairs, the event loop costs the
 // same per pair: C3 459 -> see DESIGN section 4)
-// TILE_ = 224: pairs of at most 224 merged events (small_rule 0); TILE_ = 480 (TL = 32): pairs whose environments both have at most
+// TILE_ = 240: pairs of at most 240 merged events (small_rule 0); TILE_ = 480 (TL = 32): pairs whose environments both have at most
 // 255 points and that have at most 480 merged events (small_rule 2) -- the 8-bit-count k_sweep's pairs, two per wavefront (C2a: ~343
 // events per pair)
 template <int CMAX, int TL = LCHD_DUO_TL, int TILE_ = kDuoTile>
@@ -2958,7 +2956,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_W
     static_assert(TL == 16 || TL == 32, "a team is one or two DPP rows");
     constexpr int TEAMS = 64 / TL, EPL = TILE_ / TL, TILE = TILE_, WPB = kSweepWaves;
     constexpr int RULE = TILE_ == kDuoTile ? 0 : 2;
-    // category counts as 8-bit fields: no count of a pair of this kernel exceeds 255 (TILE 224: at most 225 points in all; TILE 480:
+    // category counts as 8-bit fields: no count of a pair of this kernel exceeds 255 (TILE 240: at most 242 points in all; TILE 480:
     // environments of at most 255 points) -- one word per side up to 8 category slots, two up to 16: half the scans and no word select
     // for the common 8-slot case
     constexpr int FPW = 8, FB = 8;
@@ -3686,11 +3684,11 @@ int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinge
     const bool small = a.env_a.stride <= kSqrtTab && a.env_b.stride <= kSqrtTab && !t.force_bigenv;  // every count fits the LDS tables
     const int fmode = (a.env_a.cdf_keys && a.env_b.cdf_keys) ? F_KEY : (wf_pow ? F_ANY : F_FAST);
     // Two kernels for "small" pairs exist for the default configuration (Hellinger-2, unit weights, CDF-keyed environments):
-    // k_sweep_duo (two pairs of <= 224 merged events per wavefront, <= 16 category slots) and the 8-bit-count k_sweep (both
+    // k_sweep_duo (two pairs of <= 240 merged events per wavefront, <= 16 category slots) and the 8-bit-count k_sweep (both
     // environments <= 255 points, more than 16 slots); the INDIRECT 16-bit k_sweep takes what they leave over.
     const bool fast_cfg = !wide && hellinger2 && unit_weights && small && fmode == F_KEY && !a.wf_index;
     // sweep_hint (what k_pair_meta counted in the previous pass of this configuration): 0 = nothing known, else
-    // 4 | (pairs of <= 224 events were the majority ? 1 : 0) | (pairs with both environments <= 255 points were ? 2 : 0).
+    // 4 | (pairs of <= 240 events were the majority ? 1 : 0) | (pairs with both environments <= 255 points were ? 2 : 0).
     // Up to 16 slots k_sweep_duo is the first choice and the 8-bit-count sweep the second (C2a: environments of ~170 points,
     // pairs of ~340 events -- too long for a 32-lane tile, but their counts fit 8 bits: 2 count words per side instead of 3);
     // above 16 slots only the 8-bit-count sweep exists.
@@ -3707,7 +3705,7 @@ int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinge
     // no hint and up to 16 slots: k_sweep_duo's rule first, the two-pairs-per-wavefront 8-bit-count rule second
     a.second_rule = (!known && use_duo && fast_cfg && !t.no_count8 && !t.no_c8_team) ? 2 : 0;
     const int hint = !known ? 0 : ((use_c8 ? c8_major : duo_major) ? 1 : 2);
-    // ... | 8 (EVERY pair of the previous pass had at most 224 events) | 16 (... both environments <= 255 points): the companion
+    // ... | 8 (EVERY pair of the previous pass had at most 240 events) | 16 (... both environments <= 255 points): the companion
     // launch for the larger pairs would find nothing to do and is left out; the host checks the counts of THIS pass afterwards
     // and repeats it with the full launch set if a larger pair turned up after all (the returned bit 2 says the launch was left out)
     const bool no_others = hint == 1 && (hint_bits & (use_c8 ? 16 : 8)) != 0;
