@@ -3091,8 +3091,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_W
             exA[k] = (((c0a / FPW) == k) ? (1ull << ((c0a % FPW) * FB)) : 0ull) + sa_ - va_;
             exB[k] = (((c0b / FPW) == k) ? (1ull << ((c0b % FPW) * FB)) : 0ull) + sb_ - vb_;
         }
-        int totA = 1 + i0, totB = 1 + j0;
-        double D = 0.0;
+        double D = 0.0;  // (points seen per side incl. the anchor: 1 + i and 1 + j -- the list positions ARE the totals)
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
 #pragma unroll
@@ -3102,7 +3101,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_W
                 if ((f & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
         }
-        double ra = t_rsqrt[totA], rb = t_rsqrt[totB];
+        double ra = t_rsqrt[1 + i0], rb = t_rsqrt[1 + j0];
 
         // pass 2 (same scheme as k_sweep): both list heads in registers, chunk-local additions in 4-bit fields
         int i = i0, j = j0;
@@ -3157,9 +3156,17 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_W
 #else
                 if (e == 0) firstF = F; else local += (F - Fp) * Hp;
 #endif
-                totA += takeA ? 1 : 0;
-                totB += takeA ? 0 : 1;
                 const int sh = (ct % FPW) * FB, sh4 = (ct & 15) * 4;
+                int cntA_, cntB_;  // counts of category ct before the update
+                if constexpr (NW == 1) {
+                    // one count word per side (<= 8 slots): the event is added to the word itself -- no chunk-local fields, no second
+                    // shift-and-mask pair per side
+                    cntA_ = (int)((exA[0] >> sh) & 0xFFull);
+                    cntB_ = (int)((exB[0] >> sh) & 0xFFull);
+                    const uint64_t inc8 = 1ull << sh;
+                    exA[0] += takeA ? inc8 : 0ull;
+                    exB[0] += takeA ? 0ull : inc8;
+                } else {
                 uint64_t wA = exA[0], wB = exB[0];
 #pragma unroll
                 for (int k = 1; k < NW; ++k) {
@@ -3169,8 +3176,8 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_W
                 }
                 H4 qA = dA[0], qB = dB[0];
                 if constexpr (NH == 2) { qA = (ct & 16) ? dA[1] : qA; qB = (ct & 16) ? dB[1] : qB; }
-                const int cntA_ = (int)((wA >> sh) & 0xFFull) + (int)((qA >> sh4) & (H4)15);  // before the update
-                const int cntB_ = (int)((wB >> sh) & 0xFFull) + (int)((qB >> sh4) & (H4)15);
+                cntA_ = (int)((wA >> sh) & 0xFFull) + (int)((qA >> sh4) & (H4)15);
+                cntB_ = (int)((wB >> sh) & 0xFFull) + (int)((qB >> sh4) & (H4)15);
                 const H4 inc4 = (H4)1 << sh4;
                 if constexpr (NH == 2) {
                     const bool hi = (ct & 16) != 0;
@@ -3182,10 +3189,11 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_W
                     dA[0] += takeA ? inc4 : (H4)0;
                     dB[0] += takeA ? (H4)0 : inc4;
                 }
+                }
                 const int mine_ = takeA ? cntA_ : cntB_, other = takeA ? cntB_ : cntA_;
                 D += (t_sqrt[mine_ + 1] - t_sqrt[mine_]) * t_sqrt[other];
-                ra = t_rsqrt[totA];
-                rb = t_rsqrt[totB];
+                ra = t_rsqrt[1 + i];
+                rb = t_rsqrt[1 + j];
                 double h2 = 1.0 - (ra * rb) * D;
                 if (h2 < kExactH2Below) {  // literal difference-of-roots form where the cancellation form loses accuracy (k_sweep::exact_h2)
                     double acc2 = 0.0;
@@ -3196,8 +3204,8 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_W
                             for (int f = 0; f < FPW; ++f) {
                                 const int c = FPW * k + f;
                                 if (c < CMAX) {
-                                    const int ca = field(exA, c) + (int)((dA[0] >> (c * 4)) & (H4)15);
-                                    const int cb = field(exB, c) + (int)((dB[0] >> (c * 4)) & (H4)15);
+                                    const int ca = field(exA, c) + (NW == 1 ? 0 : (int)((dA[0] >> (c * 4)) & (H4)15));
+                                    const int cb = field(exB, c) + (NW == 1 ? 0 : (int)((dB[0] >> (c * 4)) & (H4)15));
                                     const double dd = t_sqrt[ca] * ra - t_sqrt[cb] * rb;
                                     acc2 = fma(dd, dd, acc2);
                                 }
