@@ -3156,7 +3156,10 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_W
 #else
                 if (e == 0) firstF = F; else local += (F - Fp) * Hp;
 #endif
-                const int sh = (ct % FPW) * FB, sh4 = (ct & 15) * 4;
+                // (unsigned: a signed `% 8` is five instructions; with one count word the category is below 8 -- checked where the
+                // environments were built, foreign ones stored as 0)
+                const unsigned uct = (unsigned)ct;
+                const int sh = (int)((NW == 1 ? uct : (uct % FPW)) * FB), sh4 = (int)((uct & 15u) * 4u);
                 int cntA_, cntB_;  // counts of category ct before the update
                 if constexpr (NW == 1) {
                     // one count word per side (<= 8 slots): the event is added to the word itself -- no chunk-local fields, no second
@@ -3170,12 +3173,12 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_W
                 uint64_t wA = exA[0], wB = exB[0];
 #pragma unroll
                 for (int k = 1; k < NW; ++k) {
-                    const bool hit = ((ct / FPW) == k);
+                    const bool hit = ((uct / FPW) == (unsigned)k);
                     wA = hit ? exA[k] : wA;
                     wB = hit ? exB[k] : wB;
                 }
                 H4 qA = dA[0], qB = dB[0];
-                if constexpr (NH == 2) { qA = (ct & 16) ? dA[1] : qA; qB = (ct & 16) ? dB[1] : qB; }
+                if constexpr (NH == 2) { qA = (uct & 16u) ? dA[1] : qA; qB = (uct & 16u) ? dB[1] : qB; }
                 cntA_ = (int)((wA >> sh) & 0xFFull) + (int)((qA >> sh4) & (H4)15);
                 cntB_ = (int)((wB >> sh) & 0xFFull) + (int)((qB >> sh4) & (H4)15);
                 const H4 inc4 = (H4)1 << sh4;
