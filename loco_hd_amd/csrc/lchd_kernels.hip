@@ -3152,7 +3152,9 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_W
 #endif
                 const double F = u2d(key);
 #if LCHD_CAT_HEADS
-                local += (F - Fp) * Hp;
+                local = fma(F - Fp, Hp, local);  // (fused on purpose, like the two updates below: one rounding less and one instruction less per
+                                                 //  event; the translation unit's -ffp-contract=off is there for the DISTANCES, whose roundings decide
+                                                 //  ties and the strict threshold)
 #else
                 if (e == 0) firstF = F; else local += (F - Fp) * Hp;
 #endif
@@ -3194,10 +3196,10 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_W
                 }
                 }
                 const int mine_ = takeA ? cntA_ : cntB_, other = takeA ? cntB_ : cntA_;
-                D += (t_sqrt[mine_ + 1] - t_sqrt[mine_]) * t_sqrt[other];
+                D = fma(t_sqrt[mine_ + 1] - t_sqrt[mine_], t_sqrt[other], D);
                 ra = t_rsqrt[1 + i];
                 rb = t_rsqrt[1 + j];
-                double h2 = 1.0 - (ra * rb) * D;
+                double h2 = fma(-(ra * rb), D, 1.0);
                 if (h2 < kExactH2Below) {  // literal difference-of-roots form where the cancellation form loses accuracy (k_sweep::exact_h2)
                     double acc2 = 0.0;
                     if constexpr (CMAX <= LCHD_TEAM_EXACT_UNROLL_MAX) {
