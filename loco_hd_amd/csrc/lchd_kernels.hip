@@ -1685,7 +1685,6 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 2 : 4)) void k_env_rows2(const Dev
             for (int b = tl; b < NB; b += NT) hist[b] += seg_tot[b >> 6];
             if (tl == 0) hist[NB] = seg_n_s;
             __syncthreads();
-            const int seg_n = (int)seg_n_s;
             ESTAMP(3);
             // 5. scatter (no atomics): position = bucket start + slot; the exact distance replaces the image in the register
 #pragma unroll
