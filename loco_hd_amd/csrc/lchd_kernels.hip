@@ -3691,6 +3691,8 @@ int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinge
     // grid-stride: LDS tables are built once per block.  8192 workgroups = 8 rounds of the 1024 that are resident at a time: finer
     // than that the table loads show, coarser the last round's imbalance does (measured on C2a: 4096 +2.8 %, 16384 +0.5 %)
     const int64_t gcap = t.sweep_grid > 0 ? t.sweep_grid : 8192;
+    // ... the team sweeps (shorter iterations, a smaller table load per workgroup): 16384 (C2a 1.3648 -> 1.358 ms, C3 0.7835 -> 0.7769; 32768: no further gain)
+    const int64_t tcap = t.sweep_grid > 0 ? t.sweep_grid : 16384;
     const unsigned grid = (unsigned)(blocks < gcap ? blocks : gcap);
     const int cmax = std::max(n_categories, t.force_cmax);  // (force_cmax: test hook)
     const bool small = a.env_a.stride <= kSqrtTab && a.env_b.stride <= kSqrtTab && !t.force_bigenv;  // every count fits the LDS tables
@@ -3746,13 +3748,13 @@ int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinge
             if (use_duo) {
                 constexpr int kTeamPairs = (64 / LCHD_DUO_TL) * kSweepWaves;  // pairs per workgroup and round
                 const int64_t dblocks = (a.n_pairs + kTeamPairs - 1) / kTeamPairs;
-                const unsigned dgrid = (unsigned)(dblocks < gcap ? dblocks : gcap);
+                const unsigned dgrid = (unsigned)(dblocks < tcap ? dblocks : tcap);
                 if (cmax <= 8) { k_sweep_duo<8><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<8, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
                 else if (cmax <= 12) { k_sweep_duo<12><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<12, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
                 else { k_sweep_duo<16><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<16, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
                 if (a.second_rule) {
                     const int64_t tblocks = (a.n_pairs + 2 * kSweepWaves - 1) / (2 * kSweepWaves);
-                    const unsigned tgrid = (unsigned)(tblocks < gcap ? tblocks : gcap);
+                    const unsigned tgrid = (unsigned)(tblocks < tcap ? tblocks : tcap);
                     if (cmax <= 8) k_sweep_duo<8, 32, kTeam8Tile><<<tgrid, NTH, 0, s>>>(a);
                     else if (cmax <= 12) k_sweep_duo<12, 32, kTeam8Tile><<<tgrid, NTH, 0, s>>>(a);
                     else k_sweep_duo<16, 32, kTeam8Tile><<<tgrid, NTH, 0, s>>>(a);
@@ -3760,7 +3762,7 @@ int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinge
             } else if (c8_team) {
                 constexpr int kTeamPairs = 2 * kSweepWaves;
                 const int64_t dblocks = (a.n_pairs + kTeamPairs - 1) / kTeamPairs;
-                const unsigned dgrid = (unsigned)(dblocks < gcap ? dblocks : gcap);
+                const unsigned dgrid = (unsigned)(dblocks < tcap ? dblocks : tcap);
                 if (cmax <= 8) { k_sweep_duo<8, 32, kTeam8Tile><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<8, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
                 else if (cmax <= 12) { k_sweep_duo<12, 32, kTeam8Tile><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<12, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
                 else if (cmax <= 16) { k_sweep_duo<16, 32, kTeam8Tile><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<16, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
