@@ -597,29 +597,45 @@ def run_c2b(args, torch, dist, dev, rank, world, use_dist):
         result = base_result(args, world, n * world, elapsed, w["label"], {"pairs_per_gpu": n, "mean_env_points_per_pair": 2 * n,
                                                                            "sharding": "replicas only (one from_coords call per rank)"})
         result["scaling"] = "weak"
-        result["roofline"] = roofline_block("c2b" if n == 10_000 else f"c2b_{n}", {"env": "k_env_rows2 (both structures' rows in one launch)", "sweep": "k_sweep"}[dom], algo, phase_ms[dom], step_ms=result["ms_per_step"])
+        fused = sess.last_dense_fused()
+        kname = "k_dense_fused (row sort + sweep of a row pair in one workgroup)" if fused else {"env": "k_env_rows2 (both structures' rows in one launch)", "sweep": "k_sweep"}[dom]
+        result["roofline"] = roofline_block("c2b" if n == 10_000 else f"c2b_{n}", kname, algo, phase_ms[dom], step_ms=result["ms_per_step"])
+        result["config"]["dense_path"] = "fused (one launch, scores only leave the CU)" if fused else "row sort to the environment store, then sweep"
         result["kernel_ms"] = phase_ms
         if not args.no_cpu_baseline and world == 1:
             from oracle import oracle as orc  # checker / baseline only
 
             cores = usable_cores()
-            lo = orc.LoCoHD([f"c{i}" for i in range(w["C"])], orc.WeightFunction(*w["wf"]), n_of_threads=1)
             scores = out.cpu().numpy()
             names = [f"c{i}" for i in range(w["C"])]
-            sa, sb = np.asarray([names[k] for k in w["cat_a"]]), np.asarray([names[k] for k in w["cat_b"]])
-            rows = list(range(0, n, max(1, n // 48)))
-            t1, err = time.perf_counter(), 0.0
-            for i in rows:  # the reference's per-row work: distances to every atom, stable sort with the labels, sweep
-                da = np.sqrt((((w["xyz_a"][i] - w["xyz_a"]) ** 2)[:, 0] + ((w["xyz_a"][i] - w["xyz_a"]) ** 2)[:, 1]) + ((w["xyz_a"][i] - w["xyz_a"]) ** 2)[:, 2])
-                db = np.sqrt((((w["xyz_b"][i] - w["xyz_b"]) ** 2)[:, 0] + ((w["xyz_b"][i] - w["xyz_b"]) ** 2)[:, 1]) + ((w["xyz_b"][i] - w["xyz_b"]) ** 2)[:, 2])
-                oa, ob = np.argsort(da, kind="stable"), np.argsort(db, kind="stable")
-                want = lo.from_anchors(sa[oa].tolist(), sb[ob].tolist(), da[oa].tolist(), db[ob].tolist())
-                err = max(err, abs(want - scores[i]))
-            dt = time.perf_counter() - t1
-            result["cpu_baseline"] = {"value": len(rows) / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
-                                      "sample": f"{len(rows)} rows spread over the structure, {dt:.1f} s on one core: NumPy distances + stable "
-                                                f"argsort per row, then the C oracle's sweep (the reference parallelises rows over its thread pool: "
-                                                f"x{cores} cores at best on this host)"}
+            sa, sb = [names[k] for k in w["cat_a"]], [names[k] for k in w["cat_b"]]
+            # the reference's from_coords (src/locohd.rs:463-476): both distance matrices first, serially (utils.rs:10-22), then the
+            # rows -- stable sort with the labels + sweep -- over its thread pool (:434-446).  Sample: rows spread over the structure.
+            n_rows = min(n, max(48, 16 * cores))
+            rows = np.unique(np.linspace(0, n - 1, n_rows).astype(np.int64))
+
+            def dist_rows(x):  # utils.rs:1-8 order
+                d = x[rows][:, None, :] - x[None, :, :]
+                return np.sqrt((d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2])
+
+            t0 = time.perf_counter()
+            da, db = dist_rows(w["xyz_a"]), dist_rows(w["xyz_b"])
+            t_dist = time.perf_counter() - t0
+            res = {}
+            for threads in (cores, 1):
+                lo = orc.LoCoHD(names, orc.WeightFunction(*w["wf"]), n_of_threads=threads)
+                sub = slice(None) if threads > 1 else slice(0, max(8, len(rows) // cores))
+                t1 = time.perf_counter()
+                got_cpu = np.asarray(lo.from_dmxs(sa, sb, da[sub], db[sub]))
+                res[threads] = (len(got_cpu) / (time.perf_counter() - t1), got_cpu)
+            err = float(np.max(np.abs(res[cores][1] - scores[rows])))
+            rate_all = len(rows) / (len(rows) / res[cores][0] + t_dist)
+            result["cpu_baseline"] = {"value": rate_all, "unit": "pairs/s", "cores": cores, "kind": "port",
+                                      "value_1thread": res[1][0],
+                                      "sample": f"{len(rows)} rows spread over the structure: their {2 * len(rows)} distance rows by NumPy on one "
+                                                f"core ({t_dist:.2f} s: the reference builds its matrices serially, utils.rs:10-22), then the C oracle's "
+                                                f"stable row sort + sweep over {cores} threads ({len(rows) / res[cores][0]:.2f} s; one thread: "
+                                                f"{res[1][0]:.1f} rows/s)"}
             result["max_abs_err_vs_cpu"] = float(err)
             result["parity_sample_pairs"] = len(rows)
             if not (err <= 1e-6):

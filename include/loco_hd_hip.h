@@ -235,6 +235,10 @@ int lchd_ctx_enable_timing(lchd_ctx *ctx, int32_t on);
 double lchd_ctx_last_ms(lchd_ctx *ctx, const char *phase);
 /* Environment statistics of the most recent call: sum over anchor pairs of (n_A + n_B) (points incl. anchors). */
 int64_t lchd_ctx_last_env_points(lchd_ctx *ctx);
+/* 1 if the most recent from_coords / from_dmxs call of the context ran the fused sort + sweep kernel (one launch per
+ * call, nothing but the scores written: Hellinger-2, unit category weights, at most 16 categories, rows of 1 025 .. 20 480
+ * points), 0 if it ran the row sort followed by the sweep (src/locohd.rs:410-476 either way). */
+int32_t lchd_ctx_last_dense_fused(lchd_ctx *ctx);
 
 #ifdef __cplusplus
 }

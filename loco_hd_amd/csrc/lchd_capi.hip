@@ -187,6 +187,7 @@ struct lchd_ctx {
     bool group_small = false;  // the last pass had no environment beyond kEnvGroupSmallUpTo points: k_env_group's small instantiation
     int64_t last_biggest = 0;  // largest environment of the last pass (0: unknown): anchors per wavefront of k_env_group
     int shrink_votes = 0;  // consecutive passes whose largest environment would fit half of cap_hint
+    bool last_dense_fused = false;  // the most recent dense pass ran the fused sort + sweep kernel (lchd_dense_fused.hip)
     // timing
     bool timing = false;
     hipEvent_t ev[PH_N + 1] = {};
@@ -272,6 +273,7 @@ static Tuning tuning_from_env() {  // the ONLY place that reads LCHD_* hooks (te
     t.no_c8_team = getenv("LCHD_NO_C8_TEAM") != nullptr;
     if (const char* v = getenv("LCHD_C8_TEAM_MAX")) t.c8_team_max = atoi(v);
     t.old_rows = getenv("LCHD_OLD_ROWS") != nullptr;
+    t.no_dense_fused = getenv("LCHD_NO_DENSE_FUSED") != nullptr;
     t.no_tables = getenv("LCHD_NO_SD_TABLES") != nullptr;
     t.no_env_group = getenv("LCHD_NO_ENV_GROUP") != nullptr;
     t.env_apw = env_int("LCHD_ENV_APW", 0);
@@ -339,6 +341,7 @@ extern "C" int lchd_ctx_create(int32_t device, lchd_ctx** out) {
     if ((e = hipMalloc(&c->d_done, sizeof(DoneState))) != hipSuccess) return bail(e, "hipMalloc(done)");
     if ((e = hipMemset(c->d_done, 0, sizeof(DoneState))) != hipSuccess) return bail(e, "hipMemset(done)");
     init_device_kernels();  // per device, not per process
+    init_dense_fused_kernels();
     launch_fill_sqrt_tables(c->stream, c->d_tabs, c->d_tabs + 65536);
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(e, "table fill");
     for (auto& ev : c->ev)
@@ -403,6 +406,8 @@ extern "C" int64_t lchd_ctx_last_env_points(lchd_ctx* c) {
     if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
     return (int64_t)v;
 }
+
+extern "C" int32_t lchd_ctx_last_dense_fused(lchd_ctx* c) { return (c && c->last_dense_fused) ? 1 : 0; }
 
 extern "C" int lchd_ctx_set_config(lchd_ctx* c, const lchd_config* cfg) {
     if (!c || !cfg) return fail(LCHD_EVALUE, "null context/config");
@@ -1652,6 +1657,8 @@ static int sweep_rows(lchd_ctx* c, const EnvStore& ea, const EnvStore& eb, const
 // structure): row sort of both structures, sweep.  a / b: device-resident structures (coordinates used unless d_ma / d_mb,
 // DEVICE pointers to given distance rows, are set); d_wf: device weight-function indices or nullptr; d_out: device or
 // host-mapped scores.  `retry` reports that a long row defeated the segmented in-LDS sort (repeat with old_rows).
+static bool unit_weights_for_dense(const lchd_ctx* c) { return c->unit_weights; }
+
 static int dense_pass(lchd_ctx* c, const lchd_cloud& a, const lchd_cloud& b, const double* d_ma, const double* d_mb, int64_t rows,
                       int64_t cols_a, int64_t cols_b, const int32_t* d_wf, double* d_out, bool old_rows, bool& retry,
                       const double* h_ma = nullptr, const double* h_mb = nullptr, const int32_t* d_len_a = nullptr,
@@ -1661,6 +1668,56 @@ static int dense_pass(lchd_ctx* c, const lchd_cloud& a, const lchd_cloud& b, con
     // more than 255 categories: 16-bit ids in the environment store, k_env_rows<.., uint16_t> + k_sweep_wide<.., CAT16>
     const bool cat16 = c->h_cfg.n_categories > kMaxCategories;
     const size_t cat_bytes = cat16 ? 2 : 1;
+    auto diag2 = [](const lchd_cloud& cl) {  // squared diagonal of the bounding box, with a little headroom
+        double s2 = 0.0;
+        for (int k = 0; k < 3; ++k) { const double e = cl.bbmax[k] - cl.bbmin[k]; s2 += e * e; }
+        return s2 * (1.0 + 1e-9) + 1e-300;
+    };
+    c->last_dense_fused = false;
+    // The common configuration (Hellinger-2, unit category weights, <= 16 categories, rows of 1025 .. 32768 points): sort and
+    // sweep in ONE kernel per row pair, nothing but the score is written (lchd_dense_fused.hip).  No environment store.
+    if (!old_rows && !c->tune.no_dense_fused && !cat16 && c->hellinger2 && unit_weights_for_dense(c) &&
+        dense_fused_applies(c->h_cfg.n_categories, cols_a, cols_b)) {
+        double* w_ma2 = nullptr;
+        double* w_mb2 = nullptr;
+        for (int dry = 1; dry >= 0; --dry) {
+            Arena ar(dry ? nullptr : c->ws, dry ? 0 : c->ws_cap, dry != 0);
+            if (h_ma) {
+                w_ma2 = ar.take<double>((size_t)rows * cols_a);
+                w_mb2 = ar.take<double>((size_t)rows * cols_b);
+            }
+            if (dry) if (int rc2 = ensure_ws(c, ar.off + 4096)) return rc2;
+        }
+        if (h_ma) {
+            HIP_TRY(hipMemcpyAsync(w_ma2, h_ma, sizeof(double) * rows * cols_a, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(w_mb2, h_mb, sizeof(double) * rows * cols_b, hipMemcpyHostToDevice, c->stream));
+            d_ma = w_ma2;
+            d_mb = w_mb2;
+        }
+        DenseArgs da{};
+        da.cfg = c->d_cfg;
+        da.s[0] = DenseSide{a.view(), d_ma, cols_a, (int32_t)cols_a, d_len_a};
+        da.s[1] = DenseSide{b.view(), d_mb, cols_b, (int32_t)cols_b, d_len_b};
+        da.n_rows = rows;
+        da.image_bound = std::max(diag2(a), diag2(b));
+        da.wf_index = d_wf;
+        da.out = d_out;
+        da.st = c->d_status;
+        da.sqrt_tab = c->d_tabs;
+        mark(c, 2);
+        if (launch_dense_fused(c->stream, c->h_cfg.n_categories, da, c->h_status, c->seq)) {
+            mark(c, 3);
+            mark(c, 4);
+            HIP_TRY(hipGetLastError());
+            c->status_dirty = false;  // the kernel's companion launch hands the status over and resets it
+            uint32_t f = 0;
+            if (int rc2 = wait_pass(c, &f)) return rc2;
+            collect_times(c, 2, 4);
+            c->last_dense_fused = true;
+            if (f & ST_ROW_RETRY) { retry = true; return LCHD_OK; }  // a row the fused kernel gives up on: the caller repeats with the two-kernel path
+            return status_to_rc(f, DRV_DMXS);
+        }
+    }
     EnvStore ea{}, eb{};
     double *w_ma = nullptr, *w_mb = nullptr;
     int4* d_meta = nullptr;
@@ -1691,11 +1748,6 @@ static int dense_pass(lchd_ctx* c, const lchd_cloud& a, const lchd_cloud& b, con
         d_mb = w_mb;
     }
     mark(c, 2);
-    auto diag2 = [](const lchd_cloud& cl) {  // squared diagonal of the bounding box, with a little headroom
-        double s2 = 0.0;
-        for (int k = 0; k < 3; ++k) { const double e = cl.bbmax[k] - cl.bbmin[k]; s2 += e * e; }
-        return s2 * (1.0 + 1e-9) + 1e-300;
-    };
     const RowSide rsa{a.view(), d_ma, cols_a, cols_a, diag2(a), ea, d_len_a}, rsb{b.view(), d_mb, cols_b, cols_b, diag2(b), eb, d_len_b};
     if (old_rows || cat16 || !launch_env_rows2(s, c->d_cfg, rsa, rsb, rows, c->d_status)) {  // (rows beyond 20480 points: keys sorted in global memory)
         const RowExtras exa{nullptr, d_len_a, nullptr}, exb{nullptr, d_len_b, nullptr};

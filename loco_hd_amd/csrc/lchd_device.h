@@ -68,6 +68,7 @@ struct Tuning {
     bool no_sweep_hint = false;     // LCHD_NO_SWEEP_HINT: always launch all three sweep kernels and let the device decide
     bool no_inline_meta = false;    // LCHD_NO_INLINE_META: small calls also run k_pair_meta + the regular sweep kernels
     bool old_rows = false;          // LCHD_OLD_ROWS: dense rows through k_env_rows (three distance passes) for every length
+    bool no_dense_fused = false;    // LCHD_NO_DENSE_FUSED: dense rows always through the two-kernel path (row sort, then sweep)
     bool no_count8 = false;         // LCHD_NO_COUNT8: never the 8-bit-count sweep
     bool no_c8_team = false;        // LCHD_NO_C8_TEAM: the 8-bit-count sweep always one pair per wavefront (k_sweep<.., CNT8>)
     int c8_team_max = 0;            // LCHD_C8_TEAM_MAX: ... above this many category slots (0: the two-pairs form up to 32)
@@ -236,6 +237,31 @@ struct RowSides {
 };
 // rows of at most 16384 points on both sides; returns false (nothing launched) otherwise
 bool launch_env_rows2(hipStream_t s, const DevConfig* cfg, const RowSide& a, const RowSide& b, int64_t n_rows, DeviceStatus* st);
+
+// Dense rows, sort and sweep fused (lchd_dense_fused.hip): one workgroup per row pair, only the score is written.
+// Applies to Hellinger-2 with unit category weights, at most 16 categories and rows of kDenseFusedMinRow < n <= kDenseFusedMaxRow points.
+constexpr int kDenseFusedMinRow = 1024, kDenseFusedMaxRow = 20480;
+struct DenseSide {
+    CloudView c;              // categories (and coordinates when dmx == nullptr)
+    const double* dmx;        // given distance rows [n_rows][ld], or nullptr
+    int64_t ld;
+    int32_t row_len;          // points per row
+    const int32_t* row_lens;  // ragged given rows: [n_rows] points of each row (1 .. row_len), or nullptr
+};
+struct DenseArgs {
+    const DevConfig* cfg;
+    DenseSide s[2];
+    int64_t n_rows;
+    double image_bound;       // coordinates: >= the largest squared distance of either structure; ignored for given rows
+    const int32_t* wf_index;  // [n_rows] or nullptr => 0
+    double* out;
+    DeviceStatus* st;
+    const double* sqrt_tab;   // [65536] sqrt(k), context-owned
+};
+bool dense_fused_applies(int n_categories, int64_t len_a, int64_t len_b);
+// returns false (nothing launched) when the kernel does not apply; otherwise the kernel and the status hand-over are enqueued
+bool launch_dense_fused(hipStream_t s, int n_categories, const DenseArgs& a, HostStatus* hst, uint32_t seq);
+void init_dense_fused_kernels();  // per device (dynamic LDS above 64 KB), called by lchd_ctx_create
 
 struct SweepArgs {
     const DevConfig* cfg;

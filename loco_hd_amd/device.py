@@ -46,6 +46,10 @@ class DeviceSession:
     def last_env_points(self) -> int:
         return int(N.lib().lchd_ctx_last_env_points(self._ctx))
 
+    def last_dense_fused(self) -> bool:
+        """True if the most recent from_coords call ran the fused sort + sweep kernel (lchd_ctx_last_dense_fused)."""
+        return bool(N.lib().lchd_ctx_last_dense_fused(self._ctx))
+
     def upload(self, xyz: np.ndarray, cat: np.ndarray, tag: Optional[np.ndarray] = None):
         """Put one structure (xyz [n][3] f64, category ids, interned tags) into HBM; returns an opaque handle."""
         xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
