@@ -239,6 +239,10 @@ int64_t lchd_ctx_last_env_points(lchd_ctx *ctx);
  * call, nothing but the scores written: Hellinger-2, unit category weights, at most 16 categories, rows of 1 025 .. 20 480
  * points), 0 if it ran the row sort followed by the sweep (src/locohd.rs:410-476 either way). */
 int32_t lchd_ctx_last_dense_fused(lchd_ctx *ctx);
+/* from_primitives passes the context has enqueued since it was created.  A call is one pass in the steady state; a pass is
+ * repeated when an environment overflowed the capacity tried (src/locohd.rs:514-542 has no capacity) or when the sweep launch
+ * set picked from the previous call's pair statistics did not cover this call's pairs. */
+int64_t lchd_ctx_pass_count(lchd_ctx *ctx);
 
 #ifdef __cplusplus
 }

@@ -127,6 +127,8 @@ struct lchd_cloud {
     double *x = nullptr, *y = nullptr, *z = nullptr;
     uint8_t* cat = nullptr;
     uint8_t* cat_hi = nullptr;  // high byte of the category ids (allocated when an id beyond 254 occurs: more than 255 categories)
+    uint8_t* cat_narrow = nullptr;  // with cat_hi: the one-byte view for configurations of at most 255 categories (ids beyond 254 -> 255,
+                                    // "not in the category map": the narrow kernels would otherwise score id 256 as category 0)
     int32_t* tag = nullptr;
     int32_t* sid = nullptr;  // batch of structures: structure id per atom (nullptr = one structure)
     int32_t n_struct = 1;
@@ -149,7 +151,11 @@ struct lchd_cloud {
     hipEvent_t ev_ready = nullptr, ev_used = nullptr;
     bool bbox_pending = false, used_valid = false;
     double bbmin[3] = {0, 0, 0}, bbmax[3] = {0, 0, 0};
-    CloudView view() const { return CloudView{x, y, z, cat, cat_hi, tag, (int32_t)n, sid, n_struct, sid ? struct_size : 0}; }
+    // wide: the configuration has more than 255 categories (two-byte ids where the structure carries them)
+    CloudView view(bool wide) const {
+        const bool two = wide && cat_hi;
+        return CloudView{x, y, z, (!wide && cat_narrow) ? cat_narrow : cat, two ? cat_hi : nullptr, tag, (int32_t)n, sid, n_struct, sid ? struct_size : 0};
+    }
 };
 
 enum { PH_CELLS = 0, PH_ANCHORS = 1, PH_ENV = 2, PH_SWEEP = 3, PH_N = 4 };
@@ -188,6 +194,7 @@ struct lchd_ctx {
     int64_t last_biggest = 0;  // largest environment of the last pass (0: unknown): anchors per wavefront of k_env_group
     int shrink_votes = 0;  // consecutive passes whose largest environment would fit half of cap_hint
     bool last_dense_fused = false;  // the most recent dense pass ran the fused sort + sweep kernel (lchd_dense_fused.hip)
+    int64_t n_passes = 0;           // from_primitives passes enqueued so far (a call is one pass unless a capacity / launch-set retry repeats it)
     // timing
     bool timing = false;
     hipEvent_t ev[PH_N + 1] = {};
@@ -408,6 +415,7 @@ extern "C" int64_t lchd_ctx_last_env_points(lchd_ctx* c) {
 }
 
 extern "C" int32_t lchd_ctx_last_dense_fused(lchd_ctx* c) { return (c && c->last_dense_fused) ? 1 : 0; }
+extern "C" int64_t lchd_ctx_pass_count(lchd_ctx* c) { return c ? c->n_passes : -1; }
 
 extern "C" int lchd_ctx_set_config(lchd_ctx* c, const lchd_config* cfg) {
     if (!c || !cfg) return fail(LCHD_EVALUE, "null context/config");
@@ -608,6 +616,9 @@ extern "C" int lchd_cloud_create(lchd_ctx* c, const double* xyz, const int32_t* 
         if (wide) {
             if ((e = hipMalloc(&cl->cat_hi, (size_t)n)) != hipSuccess) return bail(e, "hipMalloc(cat_hi)");
             if ((e = hipMemcpy(cl->cat_hi, c8h.data(), (size_t)n, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(cat_hi)");
+            cats_encode(cat, n, c8.data(), nullptr);  // the one-byte view: ids beyond 254 are outside every map of at most 255 categories
+            if ((e = hipMalloc(&cl->cat_narrow, (size_t)n)) != hipSuccess) return bail(e, "hipMalloc(cat_narrow)");
+            if ((e = hipMemcpy(cl->cat_narrow, c8.data(), (size_t)n, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(cat_narrow)");
         }
         if (tag) e = hipMemcpy(cl->tag, tag, sizeof(int32_t) * n, hipMemcpyHostToDevice);
         else e = hipMemset(cl->tag, 0, sizeof(int32_t) * n);
@@ -664,6 +675,7 @@ extern "C" void lchd_cloud_destroy(lchd_ctx* c, lchd_cloud* cl) {
     (void)hipFree(cl->z);
     (void)hipFree(cl->cat);
     (void)hipFree(cl->cat_hi);
+    (void)hipFree(cl->cat_narrow);
     (void)hipFree(cl->tag);
     (void)hipFree(cl->sid);
     (void)hipFree(cl->d_raw);
@@ -884,6 +896,7 @@ static void fill_sweep_args(lchd_ctx* c, SweepArgs& sw) {
 // Everything of one from_primitives pass; no host synchronisation (the workspace only grows between passes).
 static int prims_enqueue(lchd_ctx* c) {
     auto& P = c->pend;
+    ++c->n_passes;
     lchd_cloud *a = P.a, *b = P.b;
     const int64_t n_pairs = P.n_pairs;
     const double thr = P.thr;
@@ -891,16 +904,19 @@ static int prims_enqueue(lchd_ctx* c) {
     // environments of the default capacity: several per wavefront on a grid of half-threshold cells (lchd_env_group.hip)
     // more than 255 categories: 16-bit ids in the environment store, k_env_cells<.., uint16_t> + k_sweep_wide<.., CAT16>
     const bool cat16 = c->h_cfg.n_categories > kMaxCategories;
-    const bool group = cap == kEnvGroupCap && !c->tune.no_env_group && a->n < ((int64_t)1 << 29) && b->n < ((int64_t)1 << 29) && !cat16;
-    P.group = group;
-    P.group_small = false;
-    const GridPlan ga = plan_grid(a, thr, group ? 2 : 1), gb = plan_grid(b, thr, group ? 2 : 1);
     // Both sides the SAME device object (all-vs-all over one batch of structures, a structure against itself): an anchor's
     // environment does not depend on the side it is used on (src/locohd.rs:514-542 is one closure for both), so the cell
     // list and every environment are built once -- the anchors of both columns share side A's flags, slots and store.
     const bool same = (a == b) && !c->tune.no_share;
     const int64_t max_env_a = same ? std::min<int64_t>(a->n, 2 * n_pairs) : std::min<int64_t>(a->n, n_pairs);
     const int64_t max_env_b = same ? 0 : std::min<int64_t>(b->n, n_pairs);
+    // (the grouped kernel addresses environment slots and records with 32-bit offsets: the limits of launch_env_group; larger
+    //  calls take k_env_cells, which has none)
+    const bool group = cap == kEnvGroupCap && !c->tune.no_env_group && a->n < ((int64_t)1 << 27) && b->n < ((int64_t)1 << 27) &&
+                       max_env_a < ((int64_t)1 << 22) && max_env_b < ((int64_t)1 << 22) && !cat16;
+    P.group = group;
+    P.group_small = false;
+    const GridPlan ga = plan_grid(a, thr, group ? 2 : 1), gb = plan_grid(b, thr, group ? 2 : 1);
     PassBufs pb{};
     {
         Arena dry(nullptr, 0, true);
@@ -922,7 +938,7 @@ static int prims_enqueue(lchd_ctx* c) {
         return v;
     };
     const GridView gva = grid_view(ga, sa), gvb = grid_view(gb, sb);
-    const CloudView cva = a->view(), cvb = b->view();
+    const CloudView cva = a->view(cat16), cvb = b->view(cat16);
     hipStream_t s = c->stream;
     // frames buffers are filled on another stream: order this pass behind their upload
     if (a->ev_ready && a->cap_frames) HIP_TRY(hipStreamWaitEvent(s, a->ev_ready, 0));
@@ -1025,6 +1041,7 @@ extern "C" int lchd_ctx_finish(lchd_ctx* c) {
                                                "categories and 2^23 points (the 64-bit-count sweep)", (long long)biggest, kMaxCategories);
             if (P.group && P.group_small && biggest <= kEnvGroupCap) {
                 c->group_small = false;  // the small instantiation of k_env_group overflowed: the same capacity with the regular one
+                c->last_biggest = std::max<int64_t>(biggest, kEnvGroupCapSmall + 1);  // (also when LCHD_ENV_GROUP_SMALL=1 forces the small one)
             } else {
                 P.cap = next_pow2_host(std::max<int64_t>(biggest, P.cap + 1));
                 c->cap_hint = P.cap;
@@ -1288,7 +1305,7 @@ static int check_wf_index(const lchd_config* cfg, const int32_t* wf_index, int64
 // One structure of a host-pointer call inside the context's I/O block: SoA coordinates, tags, categories.  Fills the pinned
 // staging copy (AoS -> SoA, finiteness check, bounding box) and points a stack-allocated lchd_cloud at the device copy.
 static int stage_cloud(const double* xyz, const int32_t* cat, const int32_t* tag, int64_t n, char* h_base, char* d_base, size_t& off,
-                       lchd_cloud& cl) {
+                       lchd_cloud& cl, bool allow_wide) {
     auto take = [&](size_t bytes) { off = (off + 255) & ~size_t(255); const size_t o = off; off += bytes; return o; };
     const size_t m = (size_t)std::max<int64_t>(n, 1);
     const size_t ox = take(8 * m), oy = take(8 * m), oz = take(8 * m), ot = take(4 * m), oc = take(m), och = take(m);
@@ -1300,7 +1317,8 @@ static int stage_cloud(const double* xyz, const int32_t* cat, const int32_t* tag
     cl.cat_hi = nullptr;
     cl.n = n;
     if (!h_base) return LCHD_OK;  // sizing pass
-    const bool wide = cats_need_hi(cat, n);
+    // (two-byte ids only under a configuration with more than 255 categories: otherwise an id beyond 254 is simply not in the map)
+    const bool wide = allow_wide && cats_need_hi(cat, n);
     if (wide) cl.cat_hi = reinterpret_cast<uint8_t*>(d_base + och);
     double *hx = reinterpret_cast<double*>(h_base + ox), *hy = reinterpret_cast<double*>(h_base + oy), *hz = reinterpret_cast<double*>(h_base + oz);
     int32_t* ht = reinterpret_cast<int32_t*>(h_base + ot);
@@ -1364,8 +1382,8 @@ static int host_call_enqueue(lchd_ctx* c, const lchd_config* cfg, const double* 
     for (int pass = 0; pass < 2; ++pass) {
         size_t off = 0;
         char* hb = pass ? c->h_io : nullptr;
-        if (int rc = stage_cloud(xyz_a, cat_a, tag_a, n_a, hb, c->d_io, off, hc.a)) return rc;
-        if (int rc = stage_cloud(xyz_b, cat_b, tag_b, n_b, hb, c->d_io, off, hc.b)) return rc;
+        if (int rc = stage_cloud(xyz_a, cat_a, tag_a, n_a, hb, c->d_io, off, hc.a, cfg->n_categories > kMaxCategories)) return rc;
+        if (int rc = stage_cloud(xyz_b, cat_b, tag_b, n_b, hb, c->d_io, off, hc.b, cfg->n_categories > kMaxCategories)) return rc;
         auto take = [&](size_t bytes) { off = (off + 255) & ~size_t(255); const size_t o = off; off += bytes; return o; };
         o_anchors = take(sizeof(int64_t) * 2 * (size_t)n);
         o_wf = take(wf_index ? sizeof(int32_t) * (size_t)n : 0);
@@ -1696,8 +1714,8 @@ static int dense_pass(lchd_ctx* c, const lchd_cloud& a, const lchd_cloud& b, con
         }
         DenseArgs da{};
         da.cfg = c->d_cfg;
-        da.s[0] = DenseSide{a.view(), d_ma, cols_a, (int32_t)cols_a, d_len_a};
-        da.s[1] = DenseSide{b.view(), d_mb, cols_b, (int32_t)cols_b, d_len_b};
+        da.s[0] = DenseSide{a.view(cat16), d_ma, cols_a, (int32_t)cols_a, d_len_a};
+        da.s[1] = DenseSide{b.view(cat16), d_mb, cols_b, (int32_t)cols_b, d_len_b};
         da.n_rows = rows;
         da.image_bound = std::max(diag2(a), diag2(b));
         da.wf_index = d_wf;
@@ -1748,11 +1766,11 @@ static int dense_pass(lchd_ctx* c, const lchd_cloud& a, const lchd_cloud& b, con
         d_mb = w_mb;
     }
     mark(c, 2);
-    const RowSide rsa{a.view(), d_ma, cols_a, cols_a, diag2(a), ea, d_len_a}, rsb{b.view(), d_mb, cols_b, cols_b, diag2(b), eb, d_len_b};
+    const RowSide rsa{a.view(cat16), d_ma, cols_a, cols_a, diag2(a), ea, d_len_a}, rsb{b.view(cat16), d_mb, cols_b, cols_b, diag2(b), eb, d_len_b};
     if (old_rows || cat16 || !launch_env_rows2(s, c->d_cfg, rsa, rsb, rows, c->d_status)) {  // (rows beyond 20480 points: keys sorted in global memory)
         const RowExtras exa{nullptr, d_len_a, nullptr}, exb{nullptr, d_len_b, nullptr};
-        if (!launch_env_rows(s, cap_a, c->d_cfg, a.view(), d_ma, cols_a, rows, cols_a, diag2(a), ea, c->d_status, exa) ||
-            !launch_env_rows(s, cap_b, c->d_cfg, b.view(), d_mb, cols_b, rows, cols_b, diag2(b), eb, c->d_status, exb))
+        if (!launch_env_rows(s, cap_a, c->d_cfg, a.view(cat16), d_ma, cols_a, rows, cols_a, diag2(a), ea, c->d_status, exa) ||
+            !launch_env_rows(s, cap_b, c->d_cfg, b.view(cat16), d_mb, cols_b, rows, cols_b, diag2(b), eb, c->d_status, exb))
             return fail(LCHD_EUNSUPPORTED, "no dense environment kernel for this row length");
     }
     mark(c, 3);
@@ -1795,8 +1813,8 @@ static int dense_driver(lchd_ctx* c, const lchd_config* cfg, const int32_t* seq_
     for (int pass = 0; pass < 2; ++pass) {
         size_t off = 0;
         char* hb = pass ? c->h_io : nullptr;
-        if (int rc = stage_cloud(xyz_a, seq_a, nullptr, cols_a, hb, c->d_io, off, a)) return rc;
-        if (int rc = stage_cloud(xyz_b, seq_b, nullptr, cols_b, hb, c->d_io, off, b)) return rc;
+        if (int rc = stage_cloud(xyz_a, seq_a, nullptr, cols_a, hb, c->d_io, off, a, cfg->n_categories > kMaxCategories)) return rc;
+        if (int rc = stage_cloud(xyz_b, seq_b, nullptr, cols_b, hb, c->d_io, off, b, cfg->n_categories > kMaxCategories)) return rc;
         auto take = [&](size_t bytes) { off = (off + 255) & ~size_t(255); const size_t o = off; off += bytes; return o; };
         o_wf = take(wf_index ? sizeof(int32_t) * (size_t)rows : 0);
         o_la = take(row_len_a ? sizeof(int32_t) * (size_t)rows : 0);

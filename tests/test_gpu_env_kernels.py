@@ -184,3 +184,61 @@ def test_packed_list_cache_sees_every_change(lh, oracle):
     ducks[3].coordinates = [9.0, 9.0, 9.0]
     d2 = np.asarray(lchd.from_primitives(tuple(pa), ducks, [(i, i) for i in range(50)], 9.0))
     assert d2[3] > 0.0
+
+
+def test_category_ids_beyond_the_map_raise_under_a_narrow_configuration():
+    """A device-resident structure whose category array carries ids of 255 and more (raw C-ABI callers, DeviceSession.upload):
+    under a configuration of at most 255 categories such an id is outside the map -- pmf.rs:38-42 raises for every environment
+    that holds the atom -- and must not be scored by its low byte (id 256 is not category 0, id 300 not category 44)."""
+    import torch
+    import loco_hd_amd as lh
+    from loco_hd_amd.device import DeviceSession
+
+    rng = np.random.default_rng(91)
+    n = 400
+    xyz = rng.uniform(0.0, 20.0, (n, 3))
+    cat = rng.integers(0, 10, n).astype(np.int32)
+    lchd = lh.LoCoHD([f"c{i}" for i in range(10)], lh.WeightFunction("uniform", [3.0, 10.0]))
+    sess = DeviceSession(lchd)
+    good = sess.upload(xyz, cat)
+    anchors = torch.tensor([(i, i) for i in range(n)], dtype=torch.int64, device="cuda")
+    want = sess.from_primitives(good, good, anchors, 8.0).cpu().numpy()
+    assert np.max(np.abs(want)) == 0.0
+    for bad_id in (256, 300, 255, 70000):
+        c2 = cat.copy()
+        c2[17] = bad_id
+        bad = sess.upload(xyz, c2)
+        with pytest.raises(ValueError):
+            sess.from_primitives(good, bad, anchors, 8.0)
+        with pytest.raises(ValueError):
+            sess.from_coords(good, bad)
+    again = sess.from_primitives(good, good, anchors, 8.0).cpu().numpy()  # the context still works
+    assert np.array_equal(again, want)
+    sess.close()
+
+
+def test_small_calls_are_one_pass_in_the_steady_state(lh):
+    """A from_primitives call is ONE pass once the context has seen the shape: no capacity retry, no repeat for the sweep launch set
+    (the reference's per-call work, src/locohd.rs:479-567, has no retries at all).  Host-pointer calls of 1000 atoms / 334 pairs and
+    3000 atoms / 1000 pairs, alternating."""
+    from loco_hd_amd import _native as N
+
+    types = ["Cent", "AmideC", "OH", "Pos", "Neg", "Aro", "Ali", "Sulf"]
+    lchd = lh.LoCoHD(types, lh.WeightFunction("uniform", [3.0, 10.0]), lh.TagPairingRule({"accept_same": False}))
+    calls = []
+    for nn in (1000, 3000):
+        rs = np.random.default_rng(nn)
+        sd = (nn / 0.023) ** (1 / 3)
+        xa, xb = rs.uniform(0, sd, (nn, 3)), rs.uniform(0, sd, (nn, 3))
+        ct = rs.integers(0, 8, nn).astype(np.int32)
+        tg = (np.arange(nn) // 3).astype(np.int32)
+        anchors = np.stack([np.arange(0, nn, 3), np.arange(0, nn, 3)], 1)
+        calls.append((lh.api._Packed(xa, ct, tg), lh.api._Packed(xb, ct, tg), anchors))
+    for pa, pb, an in calls * 3:  # warm-up: both shapes, capacity and launch-set hints settled
+        lchd.from_packed(pa, pb, an, 10.0)
+    ctx = lchd._context()
+    for pa, pb, an in calls * 10:
+        before = N.lib().lchd_ctx_pass_count(ctx)
+        first = np.asarray(lchd.from_packed(pa, pb, an, 10.0))
+        assert N.lib().lchd_ctx_pass_count(ctx) - before == 1
+        assert np.array_equal(first, np.asarray(lchd.from_packed(pa, pb, an, 10.0)))
