@@ -171,7 +171,9 @@ def roofline_block(workload: str, kernel: str, algo_bytes: float, launch_ms: flo
                      "8 TB/s HBM peak, as section 8d defines the figure; frac_step = the algorithmic bytes of the WHOLE step / ms_per_step / "
                      "peak (what the byte model actually covers: points in, score out).  What binds the kernels of this path is VALU "
                      "issue, not bandwidth (`bound`): valu_issue_frac = SQ_ACTIVE_INST_VALU x 4 cycles / 1024 SIMDs / kernel cycles, "
-                     "hbm_measured_frac = PMC traffic / time / peak"}
+                     "hbm_measured_frac = PMC traffic / time / peak; valu_ceiling_frac = (vector instructions of the launch per SIMD x the "
+                     "class-weighted cost of the kernel's hot-loop instruction mix, measured per class by profiles/ubench/issue_rates.hip) / "
+                     "launch time: 1.0 = the kernel issues as fast as its own instruction mix allows"}
     if step_ms > 0.0:
         block["frac_step"] = algo_bytes * launches_per_step / (step_ms * 1e-3) / (HBM_PEAK_GBS * 1e9)
     prof = profile_numbers(workload)
@@ -182,6 +184,10 @@ def roofline_block(workload: str, kernel: str, algo_bytes: float, launch_ms: flo
             block["hbm_measured_frac"] = block["traffic"] / (launch_ms * 1e-3) / (HBM_PEAK_GBS * 1e9)
         if prof.get("valu_issue_frac") is not None:
             block["valu_issue_frac"] = prof["valu_issue_frac"]
+        for k in ("valu_ceiling_frac", "valu_avg_ns_per_instr_measured", "valu_avg_ns_per_instr_class_mix", "valu_share_of_2_cycle_class",
+                  "valu_ceiling_source"):
+            if prof.get(k) is not None:
+                block[k] = prof[k]
         block["binding"] = prof.get("binding", "valu issue")
     return block
 

@@ -2917,6 +2917,9 @@ constexpr int kDuoTile = 240;  // merged events per pair: 16 lanes x 15, the mos
 #ifndef LCHD_TEAM_LOOP_UNROLL
 #define LCHD_TEAM_LOOP_UNROLL 1
 #endif
+#ifndef LCHD_TEAM_LDSCNT
+#define LCHD_TEAM_LDSCNT 1   // k_sweep_duo with 20 .. 28 category slots: per-lane counts of the event loop in LDS bytes (0: packed registers)
+#endif
 #define LCHD_DUO_TL 16   // lanes per pair of k_sweep_duo's <= 240-event form: four pairs per wavefront (round 1 / 2: 32 lanes, two pairs, 224 events)
 // inclusive scan / sum inside each team of TL consecutive lanes (TL = 16: one DPP row; 32: two rows joined by row_bcast:15)
 template <int TL>
@@ -2972,6 +2975,15 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_W
     // one buffer per team: list A's points, then list B's (at most TILE together; + the spare entries the head re-reads may touch)
     __shared__ uint64_t s_[WPB][TEAMS][TILE + 2];
     __shared__ uint8_t c_[WPB][TEAMS][TILE + 8];
+    // 20 .. 28 category slots (three or four count words per side): the per-lane counts of the event loop live in LDS BYTES -- slot
+    // c of side A at byte c, of side B at byte CMAX + c of the lane's row, [word][lane][8 bytes] so that a lane writes its chunk-start
+    // counts as whole words and no two lanes of a 16-lane group share a bank.  Two byte reads at computed addresses and one byte
+    // write replace the word-select chains over the count words and the 4-bit chunk fields (C5, 28 slots: 25 of the event's 88
+    // vector instructions were v_cndmask_b32_e64).  The rows cost (2 CMAX / 8) x 512 bytes per wavefront: three workgroups per CU
+    // -- what these instantiations are compiled for -- still fit up to 28 slots; with 32 they would not (registers there).
+    constexpr bool LCNT = (CMAX > 16) && (CMAX <= 28) && (LCHD_TEAM_LDSCNT != 0);
+    constexpr int LW = LCNT ? (2 * CMAX + 7) / 8 : 1;
+    __shared__ uint64_t lc_[LCNT ? WPB : 1][LCNT ? LW * 64 : 1];
     if (!args.forced && rule_in_force(args) != RULE) return;  // another rule's pairs are the majority, or none's: k_sweep sweeps everything
     const int tid = threadIdx.x, lane = tid & 63, tl = lane & (TL - 1), team = lane / TL;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2984,6 +2996,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_W
     __syncthreads();
     uint64_t* sA = s_[wv][team];
     uint8_t* cA = c_[wv][team];
+    unsigned char* lcl = reinterpret_cast<unsigned char*>(lc_[LCNT ? wv : 0]) + lane * 8;  // this lane's eight bytes of word 0
     auto field = [&](const uint64_t (&ex)[NW], int c) -> int { return (int)((ex[c / FPW] >> ((c % FPW) * FB)) & 0xFFull); };
 
     const int64_t pstride = (int64_t)gridDim.x * WPB * TEAMS;
@@ -3101,6 +3114,18 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_W
             }
         }
         double ra = t_rsqrt[1 + i0], rb = t_rsqrt[1 + j0];
+        if constexpr (LCNT) {
+            // bytes [8 k, 8 k + 8) of  A's CMAX count bytes | B's CMAX count bytes  (CMAX is a multiple of 4: B starts on a word or a half word)
+#pragma unroll
+            for (int k = 0; k < LW; ++k) {
+                uint64_t w;
+                if (8 * k + 8 <= CMAX) w = exA[k];
+                else if (8 * k < CMAX) w = (exA[k] & 0xFFFFFFFFull) | (exB[0] << 32);
+                else if (CMAX % 8 == 0) w = exB[(8 * k - CMAX) / 8];
+                else w = (exB[(8 * k - CMAX) / 8] >> 32) | ((8 * k - CMAX) / 8 + 1 < NW ? exB[(8 * k - CMAX) / 8 + 1] << 32 : 0ull);
+                *reinterpret_cast<uint64_t*>(lcl + k * 512) = w;
+            }
+        }
 
         // pass 2 (same scheme as k_sweep): both list heads in registers, chunk-local additions in 4-bit fields
         int i = i0, j = j0;
@@ -3162,7 +3187,15 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_W
                 const unsigned uct = (unsigned)ct;
                 const int sh = (int)((NW == 1 ? uct : (uct % FPW)) * FB), sh4 = (int)((uct & 15u) * 4u);
                 int cntA_, cntB_;  // counts of category ct before the update
-                if constexpr (NW == 1) {
+                if constexpr (LCNT) {
+                    // (LDS serves a wavefront's requests in order: the lane's next event sees the incremented byte)
+                    const unsigned sb_ = uct + (unsigned)CMAX;
+                    unsigned char* pa_ = lcl + ((uct >> 3) << 9) + (uct & 7u);
+                    unsigned char* pb_ = lcl + ((sb_ >> 3) << 9) + (sb_ & 7u);
+                    cntA_ = *pa_;
+                    cntB_ = *pb_;
+                    *(takeA ? pa_ : pb_) = (unsigned char)((takeA ? cntA_ : cntB_) + 1);
+                } else if constexpr (NW == 1) {
                     // one count word per side (<= 8 slots): the event is added to the word itself -- no chunk-local fields, no second
                     // shift-and-mask pair per side
                     cntA_ = (int)((exA[0] >> sh) & 0xFFull);
@@ -3201,7 +3234,14 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_W
                 double h2 = fma(-(ra * rb), D, 1.0);
                 if (h2 < kExactH2Below) {  // literal difference-of-roots form where the cancellation form loses accuracy (k_sweep::exact_h2)
                     double acc2 = 0.0;
-                    if constexpr (CMAX <= LCHD_TEAM_EXACT_UNROLL_MAX) {
+                    if constexpr (LCNT) {
+#pragma unroll 1
+                        for (int c = 0; c < CMAX; ++c) {
+                            const int ca = lcl[((c >> 3) << 9) + (c & 7)], cb = lcl[(((c + CMAX) >> 3) << 9) + ((c + CMAX) & 7)];
+                            const double dd = t_sqrt[ca] * ra - t_sqrt[cb] * rb;
+                            acc2 = fma(dd, dd, acc2);
+                        }
+                    } else if constexpr (CMAX <= LCHD_TEAM_EXACT_UNROLL_MAX) {
 #pragma unroll
                         for (int k = 0; k < NW; ++k) {
 #pragma unroll

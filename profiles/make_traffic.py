@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """traffic_<workload>.json for bench.py's roofline block, from a workload's PMC summary (profiles/summarize_pmc.py) and its
-kernel-trace statistics:  make_traffic.py <workload> <pmc_summary.txt> <kernel_stats.csv>
+kernel-trace statistics:  make_traffic.py <workload> <pmc_summary.txt> <kernel_stats.csv> [directory of the isa_histogram_*.json files]
 
 HBM-side bytes follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE counts 64 B per 128-B fabric
 read request, so read bytes = 2 x FETCH_SIZE x 1024 (cross-check printed: TCC_MISS_sum x 128 B); WRITE_SIZE x 1024 as is.
@@ -9,12 +9,14 @@ which a SIMD issued a vector instruction (SQ_ACTIVE_INST_* count quad-cycles sum
 import ast
 import csv
 import json
+import os
+import re
 import sys
 
 # (c4: since round 3 the sweep is the longer phase; `c4_env`, `c5_env` describe the environment kernel of those workloads; the small-pair
 # sweeps are k_sweep_duo<slots, lanes per pair, events per pair>: four pairs per wavefront for C3 / C4, two for C2a / C5)
 DOMINANT = {"c2a": "k_sweep_duo<12, 32, 480>", "c5": "k_sweep_duo<28, 32, 480>", "c4": "k_sweep_duo<8, 16, 240>", "c3": "k_sweep_duo<8, 16, 240>",
-            "c2b": "k_env_rows2<1024, 10",
+            "c2b": "k_dense_fused<12, false>",
             "c4_env": "k_env_group<false, 320", "c5_env": "k_env_group<false, 320"}
 
 
@@ -55,6 +57,19 @@ def main(workload, summary, stats):
         out["binding"] = "valu issue" if out["valu_issue_frac"] > 0.5 else "latency (neither the vector pipes nor HBM are busy half the time)"
     if counters.get("SQ_INSTS_VALU") and counters.get("SQ_WAVES"):
         out["valu_insts_per_wave"] = counters["SQ_INSTS_VALU"] / counters["SQ_WAVES"]
+    # class-weighted issue ceiling: the launch's vector instructions x the average cost of the kernel's hot-loop instruction mix
+    # (profiles/isa_histogram.py on top of the measured per-class costs of profiles/ubench/issue_rates.hip), against the launch time
+    hist_dir = os.path.dirname(os.path.abspath(summary)) if len(sys.argv) < 5 else sys.argv[4]
+    kshort = out["kernel"]
+    hist = os.path.join(hist_dir, "isa_histogram_" + re.sub(r"[<>, ]+", "_", kshort).strip("_") + ".json")
+    if counters.get("SQ_INSTS_VALU") and avg_ns and os.path.exists(hist):
+        hl = json.load(open(hist))["hot_loop"]
+        per_simd = counters["SQ_INSTS_VALU"] / 1024.0
+        out["valu_avg_ns_per_instr_measured"] = avg_ns / per_simd
+        out["valu_avg_ns_per_instr_class_mix"] = hl["avg_ns_per_valu_instr_w4"]
+        out["valu_ceiling_frac"] = per_simd * hl["avg_ns_per_valu_instr_w4"] / avg_ns
+        out["valu_share_of_2_cycle_class"] = hl["share_of_2_cycle_class"]
+        out["valu_ceiling_source"] = os.path.basename(hist) + " (hot-loop instruction mix) x issue_rates.json (measured cost per class, 4 waves/SIMD)"
     print(json.dumps(out, indent=1))
 
 
