@@ -692,7 +692,7 @@ def run_pairs(args, torch, dist, dev, rank, world, use_dist):
         if strong:
             slot = int(p / vworld * 1.5) + 4096  # gather slot per rank (the shares differ by a bin's worth of pairs)
             locals_ = [torch.zeros((2, slot), dtype=torch.float64, device=dev) for _ in range(2)]
-            sels = [torch.empty((slot, 2), dtype=torch.int64, device=dev) for _ in range(2)]
+            sels, planned = [None, None], [None, None]
             gathered = [torch.empty(vworld * 2 * slot, dtype=torch.float64, device=dev) if (collective and rank == 0) else None for _ in range(2)]
             full = torch.empty(p, dtype=torch.float64, device=dev)
             counts_seen = [None, None]
@@ -727,20 +727,19 @@ def run_pairs(args, torch, dist, dev, rank, world, use_dist):
             wait_gather(k)
             if strong:
                 t0 = time.perf_counter()
-                from loco_hd_amd import _native as N
-                import ctypes as C
-
-                counts = (C.c_int64 * vworld)()
-                N.check(N.lib().lchd_shard_plan_dev(sessions[k]._ctx, C.c_void_p(anchors.data_ptr()), p, w["n"], w["n"], vworld, counts))
-                counts = [int(v) for v in counts]
+                # the partition of a pair list is a pure function of the list: planned once per (list, rank, session), reused by
+                # every later step on the unchanged tensor (dist.select_shard(cache=True)) -- no partition kernels in the steady state
+                sel, idx, counts = select_shard(anchors, w["n"], vworld, vrank, session=sessions[k], n_atoms_b=w["n"], cache=not args.no_plan_cache)
                 n_mine = counts[vrank]
                 assert n_mine <= slot, (n_mine, slot)
-                N.check(N.lib().lchd_shard_select_dev(sessions[k]._ctx, C.c_void_p(anchors.data_ptr()), p, w["n"], w["n"], vrank,
-                                                      C.c_void_p(sels[k].data_ptr()), C.c_void_p(locals_[k][1].data_ptr())))
+                if planned[k] is not sel:  # first step of this session (or the cache is off): positions into the gather buffer
+                    locals_[k][1, :n_mine] = idx.view(torch.float64)
+                    planned[k] = sel
+                sels[k] = sel
                 if collect[0]:
                     phase_ms["shard"] += (time.perf_counter() - t0) * 1e3
                 counts_seen[k] = counts
-                sessions[k].from_primitives_async(clouds[k][0], clouds[k][1], sels[k][:n_mine], w["thr"], locals_[k][0])
+                sessions[k].from_primitives_async(clouds[k][0], clouds[k][1], sels[k], w["thr"], locals_[k][0])
                 in_flight[k] = True
                 if collective and args.gather == "step":
                     pending[k] = gather_scores(locals_[k], gathered[k], vworld, rank, force_collective=True, async_op=True)
@@ -901,6 +900,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=1_000_000, help="c2a / c5: anchor pairs (per GPU when weak, in total when strong)")
     ap.add_argument("--gather", default=None, choices=["end", "step"],
                     help="multi-GPU: RCCL gather of the scores to rank 0 inside every timed step (default for N > 1) or once behind the timed region")
+    ap.add_argument("--no-plan-cache", action="store_true", help="strong scaling: plan and select the rank's share in every step (two partition kernels)")
     ap.add_argument("--emulate-world", type=int, default=0, help="one GPU, --scaling strong: time every rank's share of a W-GPU job in turn")
     ap.add_argument("--dense-atoms", type=int, default=10_000, help="c2b: atoms per structure (= anchor pairs; the environment is the whole structure)")
     ap.add_argument("--streams", type=int, default=None, choices=[1, 2],

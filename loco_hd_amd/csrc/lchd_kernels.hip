@@ -2953,7 +2953,10 @@ __device__ __forceinline__ double team_sum_f64(double v) {  // the last lane of 
 // TILE_ = 240: pairs of at most 240 merged events (small_rule 0); TILE_ = 480 (TL = 32): pairs whose environments both have at most
 // 255 points and that have at most 480 merged events (small_rule 2) -- the 8-bit-count k_sweep's pairs, two per wavefront (C2a: ~343
 // events per pair)
-template <int CMAX, int TL = LCHD_DUO_TL, int TILE_ = kDuoTile>
+// WGT: category weights other than 1 (pmf.rs:47-63 adds weight[c] per point): H^2 = 1 - sum_c w_c sqrt(a_c b_c) / sqrt(W_a W_b) with the
+// weighted totals W = sum_c w_c count_c -- the same integer count fields and tables, one multiplier per category from LDS, two
+// running totals and one reciprocal square root per event instead of the two table look-ups of the unit-weight form.
+template <int CMAX, int TL = LCHD_DUO_TL, int TILE_ = kDuoTile, bool WGT = false>
 __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_WAVES)) void k_sweep_duo(SweepArgs args) {
     static_assert(TL == 16 || TL == 32, "a team is one or two DPP rows");
     constexpr int TEAMS = 64 / TL, EPL = TILE_ / TL, TILE = TILE_, WPB = kSweepWaves;
@@ -2984,6 +2987,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_W
     constexpr bool LCNT = (CMAX > 16) && (CMAX <= 28) && (LCHD_TEAM_LDSCNT != 0);
     constexpr int LW = LCNT ? (2 * CMAX + 7) / 8 : 1;
     __shared__ uint64_t lc_[LCNT ? WPB : 1][LCNT ? LW * 64 : 1];
+    __shared__ double w_s[WGT ? 32 : 1];
     if (!args.forced && rule_in_force(args) != RULE) return;  // another rule's pairs are the majority, or none's: k_sweep sweeps everything
     const int tid = threadIdx.x, lane = tid & 63, tl = lane & (TL - 1), team = lane / TL;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2992,6 +2996,9 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_W
     for (int k = tid; k < NT; k += 64 * WPB) {
         t_sqrt[k] = args.sqrt_tab[k];
         t_rsqrt[k] = args.rsqrt_tab[k];
+    }
+    if constexpr (WGT) {
+        if (tid < 32) w_s[tid] = tid < cfgp->n_categories ? cfgp->cat_w[tid] : 0.0;
     }
     __syncthreads();
     uint64_t* sA = s_[wv][team];
@@ -3104,16 +3111,32 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_W
             exB[k] = (((c0b / FPW) == k) ? (1ull << ((c0b % FPW) * FB)) : 0ull) + sb_ - vb_;
         }
         double D = 0.0;  // (points seen per side incl. the anchor: 1 + i and 1 + j -- the list positions ARE the totals)
+        double na = 0.0, nb = 0.0;  // WGT: weighted totals of the two sides
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
 #pragma unroll
             for (int f = 0; f < FPW; ++f) {
                 const int c = FPW * k + f;
-                if (c < CMAX) D += t_sqrt[field(exA, c)] * t_sqrt[field(exB, c)];
+                if (c < CMAX) {
+                    if constexpr (WGT) {
+                        const int fa = field(exA, c), fb = field(exB, c);
+                        D = fma(w_s[c], t_sqrt[fa] * t_sqrt[fb], D);
+                        na = fma(w_s[c], (double)fa, na);
+                        nb = fma(w_s[c], (double)fb, nb);
+                    } else {
+                        D += t_sqrt[field(exA, c)] * t_sqrt[field(exB, c)];
+                    }
+                }
                 if ((f & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
         }
-        double ra = t_rsqrt[1 + i0], rb = t_rsqrt[1 + j0];
+        auto rsqrt_w = [](double x) -> double {  // 1 / sqrt(weighted total): v_rsq_f64 + two Newton steps
+            double y = __builtin_amdgcn_rsq(x);
+            y = y * fma(-0.5 * x, y * y, 1.5);
+            y = y * fma(-0.5 * x, y * y, 1.5);
+            return y;
+        };
+        double ra = WGT ? rsqrt_w(na) : t_rsqrt[1 + i0], rb = WGT ? rsqrt_w(nb) : t_rsqrt[1 + j0];
         if constexpr (LCNT) {
             // bytes [8 k, 8 k + 8) of  A's CMAX count bytes | B's CMAX count bytes  (CMAX is a multiple of 4: B starts on a word or a half word)
 #pragma unroll
@@ -3228,9 +3251,19 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_W
                 }
                 }
                 const int mine_ = takeA ? cntA_ : cntB_, other = takeA ? cntB_ : cntA_;
-                D = fma(t_sqrt[mine_ + 1] - t_sqrt[mine_], t_sqrt[other], D);
-                ra = t_rsqrt[1 + i];
-                rb = t_rsqrt[1 + j];
+                if constexpr (WGT) {
+                    const double wv_ = w_s[uct & 31u];
+                    D = fma(wv_ * (t_sqrt[mine_ + 1] - t_sqrt[mine_]), t_sqrt[other], D);
+                    na += takeA ? wv_ : 0.0;
+                    nb += takeA ? 0.0 : wv_;
+                    const double rr = rsqrt_w(takeA ? na : nb);
+                    ra = takeA ? rr : ra;
+                    rb = takeA ? rb : rr;
+                } else {
+                    D = fma(t_sqrt[mine_ + 1] - t_sqrt[mine_], t_sqrt[other], D);
+                    ra = t_rsqrt[1 + i];
+                    rb = t_rsqrt[1 + j];
+                }
                 double h2 = fma(-(ra * rb), D, 1.0);
                 if (h2 < kExactH2Below) {  // literal difference-of-roots form where the cancellation form loses accuracy (k_sweep::exact_h2)
                     double acc2 = 0.0;
@@ -3239,7 +3272,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_W
                         for (int c = 0; c < CMAX; ++c) {
                             const int ca = lcl[((c >> 3) << 9) + (c & 7)], cb = lcl[(((c + CMAX) >> 3) << 9) + ((c + CMAX) & 7)];
                             const double dd = t_sqrt[ca] * ra - t_sqrt[cb] * rb;
-                            acc2 = fma(dd, dd, acc2);
+                            acc2 = WGT ? fma(w_s[c & 31] * dd, dd, acc2) : fma(dd, dd, acc2);
                         }
                     } else if constexpr (CMAX <= LCHD_TEAM_EXACT_UNROLL_MAX) {
 #pragma unroll
@@ -3251,7 +3284,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_W
                                     const int ca = field(exA, c) + (NW == 1 ? 0 : (int)((dA[0] >> (c * 4)) & (H4)15));
                                     const int cb = field(exB, c) + (NW == 1 ? 0 : (int)((dB[0] >> (c * 4)) & (H4)15));
                                     const double dd = t_sqrt[ca] * ra - t_sqrt[cb] * rb;
-                                    acc2 = fma(dd, dd, acc2);
+                                    acc2 = WGT ? fma(w_s[c & 31] * dd, dd, acc2) : fma(dd, dd, acc2);
                                 }
                                 if ((f & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                             }
@@ -3266,7 +3299,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_W
                             const int ca = (int)((wA >> ((c % FPW) * FB)) & 0xFFull) + (int)((qA >> ((c & 15) * 4)) & (H4)15);
                             const int cb = (int)((wB >> ((c % FPW) * FB)) & 0xFFull) + (int)((qB >> ((c & 15) * 4)) & (H4)15);
                             const double dd = t_sqrt[ca] * ra - t_sqrt[cb] * rb;
-                            acc2 = fma(dd, dd, acc2);
+                            acc2 = WGT ? fma(w_s[c & 31] * dd, dd, acc2) : fma(dd, dd, acc2);
                         }
                     }
                     h2 = 0.5 * acc2;
@@ -3703,6 +3736,17 @@ __global__ void k_pair_meta(SweepArgs args) {
     }
 }
 
+// A team kernel (tile240: four pairs of <= 240 events per wavefront, else two 8-bit-count pairs of <= 480), the INDIRECT companion for
+// the pairs its rule leaves over, and -- a pass without a hint -- the second team rule's kernel (tgrid != 0).
+template <int CM, bool WGT>
+static void launch_team(hipStream_t s, bool tile240, unsigned dgrid, unsigned bgrid, bool others, unsigned tgrid, const SweepArgs& a) {
+    constexpr int NTH = 64 * kSweepWaves;
+    if (tile240) k_sweep_duo<CM, LCHD_DUO_TL, kDuoTile, WGT><<<dgrid, NTH, 0, s>>>(a);
+    else k_sweep_duo<CM, 32, kTeam8Tile, WGT><<<dgrid, NTH, 0, s>>>(a);
+    if (others) k_sweep<CM, WGT ? MODE_H2W : MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a);
+    if (tgrid) k_sweep_duo<CM, 32, kTeam8Tile, WGT><<<tgrid, NTH, 0, s>>>(a);
+}
+
 int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinger2, bool unit_weights, bool wf_pow, int sweep_hint,
                  const SweepArgs& a_in) {
     if (a_in.n_pairs <= 0) return 0;
@@ -3740,7 +3784,10 @@ int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinge
     // Two kernels for "small" pairs exist for the default configuration (Hellinger-2, unit weights, CDF-keyed environments):
     // k_sweep_duo (two pairs of <= 240 merged events per wavefront, <= 16 category slots) and the 8-bit-count k_sweep (both
     // environments <= 255 points, more than 16 slots); the INDIRECT 16-bit k_sweep takes what they leave over.
-    const bool fast_cfg = !wide && hellinger2 && unit_weights && small && fmode == F_KEY && !a.wf_index;
+    // ... and, up to 16 slots, for category weights other than 1 (the WGT instantiations of the team kernels; the one-pair-per-wavefront
+    // 8-bit-count sweep has no weighted form, so both team rules must be available)
+    const bool weighted_team = !unit_weights && cmax <= 16 && !t.no_duo && !t.no_c8_team && !t.no_count8 && (t.c8_team_max == 0 || t.c8_team_max >= cmax);
+    const bool fast_cfg = !wide && hellinger2 && (unit_weights || weighted_team) && small && fmode == F_KEY && !a.wf_index;
     // sweep_hint (what k_pair_meta counted in the previous pass of this configuration): 0 = nothing known, else
     // 4 | (pairs of <= 240 events were the majority ? 1 : 0) | (pairs with both environments <= 255 points were ? 2 : 0).
     // Up to 16 slots k_sweep_duo is the first choice and the 8-bit-count sweep the second (C2a: environments of ~170 points,
@@ -3789,27 +3836,33 @@ int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinge
                 constexpr int kTeamPairs = (64 / LCHD_DUO_TL) * kSweepWaves;  // pairs per workgroup and round
                 const int64_t dblocks = (a.n_pairs + kTeamPairs - 1) / kTeamPairs;
                 const unsigned dgrid = (unsigned)(dblocks < tcap ? dblocks : tcap);
-                if (cmax <= 8) { k_sweep_duo<8><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<8, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
-                else if (cmax <= 12) { k_sweep_duo<12><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<12, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
-                else { k_sweep_duo<16><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<16, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
-                if (a.second_rule) {
-                    const int64_t tblocks = (a.n_pairs + 2 * kSweepWaves - 1) / (2 * kSweepWaves);
-                    const unsigned tgrid = (unsigned)(tblocks < tcap ? tblocks : tcap);
-                    if (cmax <= 8) k_sweep_duo<8, 32, kTeam8Tile><<<tgrid, NTH, 0, s>>>(a);
-                    else if (cmax <= 12) k_sweep_duo<12, 32, kTeam8Tile><<<tgrid, NTH, 0, s>>>(a);
-                    else k_sweep_duo<16, 32, kTeam8Tile><<<tgrid, NTH, 0, s>>>(a);
+                const int64_t tblocks = (a.n_pairs + 2 * kSweepWaves - 1) / (2 * kSweepWaves);
+                const unsigned tgrid = (unsigned)(tblocks < tcap ? tblocks : tcap);
+                if (unit_weights) {
+                    if (cmax <= 8) launch_team<8, false>(s, true, dgrid, bgrid, !no_others, a.second_rule ? tgrid : 0u, a);
+                    else if (cmax <= 12) launch_team<12, false>(s, true, dgrid, bgrid, !no_others, a.second_rule ? tgrid : 0u, a);
+                    else launch_team<16, false>(s, true, dgrid, bgrid, !no_others, a.second_rule ? tgrid : 0u, a);
+                } else {
+                    if (cmax <= 8) launch_team<8, true>(s, true, dgrid, bgrid, !no_others, a.second_rule ? tgrid : 0u, a);
+                    else if (cmax <= 12) launch_team<12, true>(s, true, dgrid, bgrid, !no_others, a.second_rule ? tgrid : 0u, a);
+                    else launch_team<16, true>(s, true, dgrid, bgrid, !no_others, a.second_rule ? tgrid : 0u, a);
                 }
             } else if (c8_team) {
                 constexpr int kTeamPairs = 2 * kSweepWaves;
                 const int64_t dblocks = (a.n_pairs + kTeamPairs - 1) / kTeamPairs;
                 const unsigned dgrid = (unsigned)(dblocks < tcap ? dblocks : tcap);
-                if (cmax <= 8) { k_sweep_duo<8, 32, kTeam8Tile><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<8, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
-                else if (cmax <= 12) { k_sweep_duo<12, 32, kTeam8Tile><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<12, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
-                else if (cmax <= 16) { k_sweep_duo<16, 32, kTeam8Tile><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<16, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
-                else if (cmax <= 20) { k_sweep_duo<20, 32, kTeam8Tile><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<20, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
-                else if (cmax <= 24) { k_sweep_duo<24, 32, kTeam8Tile><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<24, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
-                else if (cmax <= 28) { k_sweep_duo<28, 32, kTeam8Tile><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<28, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
-                else { k_sweep_duo<32, 32, kTeam8Tile><<<dgrid, NTH, 0, s>>>(a); if (!no_others) k_sweep<32, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
+                if (!unit_weights) {
+                    if (cmax <= 8) launch_team<8, true>(s, false, dgrid, bgrid, !no_others, 0u, a);
+                    else if (cmax <= 12) launch_team<12, true>(s, false, dgrid, bgrid, !no_others, 0u, a);
+                    else launch_team<16, true>(s, false, dgrid, bgrid, !no_others, 0u, a);
+                }
+                else if (cmax <= 8) launch_team<8, false>(s, false, dgrid, bgrid, !no_others, 0u, a);
+                else if (cmax <= 12) launch_team<12, false>(s, false, dgrid, bgrid, !no_others, 0u, a);
+                else if (cmax <= 16) launch_team<16, false>(s, false, dgrid, bgrid, !no_others, 0u, a);
+                else if (cmax <= 20) launch_team<20, false>(s, false, dgrid, bgrid, !no_others, 0u, a);
+                else if (cmax <= 24) launch_team<24, false>(s, false, dgrid, bgrid, !no_others, 0u, a);
+                else if (cmax <= 28) launch_team<28, false>(s, false, dgrid, bgrid, !no_others, 0u, a);
+                else launch_team<32, false>(s, false, dgrid, bgrid, !no_others, 0u, a);
             } else {
                 if (cmax <= 8) { k_sweep<8, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); if (!no_others) k_sweep<8, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
                 else if (cmax <= 12) { k_sweep<12, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); if (!no_others) k_sweep<12, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }

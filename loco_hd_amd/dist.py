@@ -63,8 +63,33 @@ def shard_rule(anchors, n_atoms_a: int, world: int, n_atoms_b: Optional[int] = N
     return rank_of_pair, counts
 
 
-def select_shard(anchors, n_atoms_a: int, world: int, rank: int, session=None, n_atoms_b: Optional[int] = None):
-    """This rank's pairs: (sel_anchors [n][2], sel_index [n] = positions in the full list, counts of every rank)."""
+# Partitions of pair lists that were seen before (select_shard(..., cache=True)).  The rule is a pure function of the list, so a
+# caller that scores the SAME list again -- the frames of a trajectory, the rounds of a permutation test, the steps of bench.py --
+# neither reads it twice per call nor launches the two partition kernels again.  An entry is valid for the very tensor object it
+# was made from (kept alive by the entry) and only while that tensor has not been written to (torch's version counter).
+_PLAN_CACHE: dict = {}
+_PLAN_CACHE_MAX = 16
+
+
+def clear_shard_cache() -> None:
+    _PLAN_CACHE.clear()
+
+
+def select_shard(anchors, n_atoms_a: int, world: int, rank: int, session=None, n_atoms_b: Optional[int] = None, cache: bool = False):
+    """This rank's pairs: (sel_anchors [n][2], sel_index [n] = positions in the full list, counts of every rank).
+
+    cache=True: the result is remembered per (tensor object, its version, world, rank, structure sizes, session) and returned
+    again -- the same tensors, do not modify them -- while `anchors` is unchanged."""
+    if cache:
+        key = (id(anchors), world, rank, int(n_atoms_a), int(n_atoms_b or 0), id(session))
+        hit = _PLAN_CACHE.get(key)
+        if hit is not None and hit[0] is anchors and hit[1] == anchors._version:
+            return hit[2]
+        res = select_shard(anchors, n_atoms_a, world, rank, session, n_atoms_b, cache=False)
+        if len(_PLAN_CACHE) >= _PLAN_CACHE_MAX:
+            _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
+        _PLAN_CACHE[key] = (anchors, anchors._version, res)
+        return res
     import torch
 
     p = anchors.shape[0]
@@ -123,14 +148,15 @@ def unshard(gathered, counts: List[int], stride: int, n_pairs: int, out=None, se
 
 
 def score_sharded(score_fn: Callable, anchors, world: int, rank: int, group=None, n_atoms_a: Optional[int] = None, session=None,
-                  partition: str = "anchor", force_collective: bool = False, n_atoms_b: Optional[int] = None):
+                  partition: str = "anchor", force_collective: bool = False, n_atoms_b: Optional[int] = None, cache_plan: bool = False):
     """Score this rank's share of `anchors` with `score_fn(anchor_subset [n][2]) -> 1-D float64 tensor [n]` and gather.
 
     `anchors` is the FULL [P][2] int64 tensor (same on every rank).  Returns the full [P] score tensor on rank 0 (output i
     belongs to anchor pair i) and None elsewhere.  partition="anchor" needs n_atoms_a (the size of structure A; with n_atoms_b
     a list that is degenerate on side A is binned by side B);
     "contiguous" is the plain slice (best when consecutive pairs share anchors already, e.g. (i, perm(i)) lists).
-    With `session` (a DeviceSession on this rank's GPU) partition and restore run in the library's kernels."""
+    With `session` (a DeviceSession on this rank's GPU) partition and restore run in the library's kernels.
+    cache_plan=True: the partition of this very `anchors` tensor is computed once and reused while the tensor is unchanged."""
     import torch
 
     p = anchors.shape[0]
@@ -147,7 +173,7 @@ def score_sharded(score_fn: Callable, anchors, world: int, rank: int, group=None
         raise ValueError(f"unknown partition {partition!r}")
     if n_atoms_a is None:
         raise ValueError('partition="anchor" needs n_atoms_a')
-    sel, idx, counts = select_shard(anchors, n_atoms_a, world, rank, session, n_atoms_b)
+    sel, idx, counts = select_shard(anchors, n_atoms_a, world, rank, session, n_atoms_b, cache=cache_plan)
     stride = max(max(counts), 1)
     local = torch.zeros((2, stride), dtype=torch.float64, device=dev)
     n = counts[rank]

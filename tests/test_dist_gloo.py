@@ -136,3 +136,29 @@ def test_sharded_scores_match_single_process(tmp_path, partition):
     got = np.load(out)
     want = _score_fn()(torch.from_numpy(_workload()[4])).numpy()
     assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_partition_cache_follows_the_tensor():
+    """select_shard(cache=True): the partition of an unchanged pair-list tensor is computed once; writing to the tensor (torch's
+    version counter) or passing another tensor makes it be computed again."""
+    import torch
+
+    from loco_hd_amd import dist as D
+
+    D.clear_shard_cache()
+    g = torch.Generator().manual_seed(7)
+    anchors = torch.randint(0, 5000, (20000, 2), generator=g, dtype=torch.int64)
+    first = D.select_shard(anchors, 5000, 4, 1, n_atoms_b=5000, cache=True)
+    again = D.select_shard(anchors, 5000, 4, 1, n_atoms_b=5000, cache=True)
+    assert again[0] is first[0] and again[1] is first[1]
+    plain = D.select_shard(anchors, 5000, 4, 1, n_atoms_b=5000)
+    assert torch.equal(plain[0], first[0]) and torch.equal(plain[1], first[1]) and plain[2] == first[2]
+    other_rank = D.select_shard(anchors, 5000, 4, 2, n_atoms_b=5000, cache=True)
+    assert other_rank[0] is not first[0] and other_rank[2] == first[2]
+    anchors[:10000, 0] = 0  # in place: the cached partition no longer describes the list
+    changed = D.select_shard(anchors, 5000, 4, 1, n_atoms_b=5000, cache=True)
+    assert changed[0] is not first[0]
+    want = D.select_shard(anchors, 5000, 4, 1, n_atoms_b=5000)
+    assert torch.equal(changed[0], want[0]) and torch.equal(changed[1], want[1])
+    clone = anchors.clone()
+    assert D.select_shard(clone, 5000, 4, 1, n_atoms_b=5000, cache=True)[0] is not changed[0]

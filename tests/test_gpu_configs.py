@@ -623,3 +623,37 @@ def test_same_object_on_both_sides_shares_environments(lh, oracle, monkeypatch):
     got = run(lambda s: s.upload(xs, cs, ts), lambda: np.stack([np.arange(m), np.arange(m)[::-1]], 1).astype(np.int64), 10.0)
     want = np.asarray(lo.from_arrays(xs, cs, ts, xs, cs, ts, np.stack([np.arange(m), np.arange(m)[::-1]], 1), 10.0))
     assert np.max(np.abs(got - want)) < TIGHT
+
+
+@pytest.mark.parametrize("density,n_cat", [(0.05, 10), (0.023, 8), (0.05, 16), (0.023, 5)])
+def test_category_weights_through_the_team_sweeps(lh, oracle, density, n_cat):
+    """category_weights != 1 (src/locohd.rs:319-346, pmf.rs:47-63; python_codes/pisces/pisces_random_pairs.py:146-158) on pair lists
+    long enough for the team sweeps: the first call of a context decides on the device, the later ones launch the weighted
+    instantiations of k_sweep_duo (four pairs of <= 240 events or two 8-bit-count pairs per wavefront) and their companion."""
+    rng = np.random.default_rng(int(density * 1000) + n_cat)
+    n, n_pairs = 2500, 24000
+    side = (n / density) ** (1 / 3)
+    cats = [f"c{i}" for i in range(n_cat)]
+    weights = [float(v) for v in rng.uniform(0.2, 3.0, n_cat)]
+    xa, xb = rng.uniform(0, side, (n, 3)), rng.uniform(0, side, (n, 3))
+    sa, sb = [cats[k] for k in rng.integers(0, n_cat, n)], [cats[k] for k in rng.integers(0, n_cat, n)]
+    pairs = [(int(a), int(b)) for a, b in zip(rng.integers(0, n, n_pairs), rng.integers(0, n, n_pairs))]
+    # a few long pairs among the short ones (the companion launch): a dense clump in both structures
+    xa[:40] = xa[0] + rng.normal(0, 1.5, (40, 3))
+    xb[:40] = xb[0] + rng.normal(0, 1.5, (40, 3))
+
+    def build(mod):
+        lchd = mod.LoCoHD(cats, mod.WeightFunction("hyper_exp", [1.0, 0.1]), category_weights=weights)
+        return lchd, [mod.PrimitiveAtom(t, "", c) for t, c in zip(sa, xa)], [mod.PrimitiveAtom(t, "", c) for t, c in zip(sb, xb)]
+
+    lo, pa, pb = build(oracle)
+    want = np.asarray(lo.from_primitives(pa, pb, pairs, 10.0))
+    lchd, pa, pb = build(lh)
+    first = np.asarray(lchd.from_primitives(pa, pb, pairs, 10.0))
+    second = np.asarray(lchd.from_primitives(pa, pb, pairs, 10.0))
+    third = np.asarray(lchd.from_primitives(pa, pb, pairs, 10.0))
+    assert np.max(np.abs(first - want)) < TIGHT
+    assert np.max(np.abs(second - want)) < TIGHT
+    assert np.array_equal(second, third)
+    unit = np.asarray(lh.LoCoHD(cats, lh.WeightFunction("hyper_exp", [1.0, 0.1])).from_primitives(pa, pb, pairs, 10.0))
+    assert np.max(np.abs(unit - second)) > 1e-4  # the weights do change the scores
