@@ -4,7 +4,7 @@
 # Kernel trace and the PMC passes are separate runs (never --pmc together with a trace other than --kernel-trace); the program
 # itself follows `--` (no env / bash -c hop under the profiler).
 set -o pipefail
-ROUND=${1:-r03}; TAG=${2:-x}; shift 2
+ROUND=${1:-r04}; TAG=${2:-x}; shift 2
 WLS=${@:-c2a c5 c4 c3 c2b}
 REPO=$PWD
 OUT=$REPO/gpurun_out/prof_${ROUND}_${TAG}
@@ -19,8 +19,8 @@ for W in $WLS; do
   rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc_write_$W" -- $BENCH --steps 2 --warmup 1 > "$OUT/${W}_pmc_write.log" 2>&1 || exit 1
   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sq_$W" -- $BENCH --steps 2 --warmup 1 > "$OUT/${W}_pmc_sq.log" 2>&1 || exit 1
   python3 $REPO/profiles/summarize_pmc.py "$OUT/pmc_fetch_$W" "$OUT/pmc_write_$W" "$OUT/pmc_sq_$W" > "$OUT/${W}_pmc_summary.txt" 2>&1
-  python3 $REPO/profiles/make_traffic.py $W "$OUT/${W}_pmc_summary.txt" "$OUT/${W}_kernel_stats.csv" > "$OUT/traffic_$W.json" 2> "$OUT/${W}_traffic.err"
-  if [ $W = c4 ] || [ $W = c5 ]; then python3 $REPO/profiles/make_traffic.py ${W}_env "$OUT/${W}_pmc_summary.txt" "$OUT/${W}_kernel_stats.csv" > "$OUT/traffic_${W}_env.json" 2>> "$OUT/${W}_traffic.err"; fi
+  python3 $REPO/profiles/make_traffic.py $W "$OUT/${W}_pmc_summary.txt" "$OUT/${W}_kernel_stats.csv" "$REPO/profiles/$ROUND" > "$OUT/traffic_$W.json" 2> "$OUT/${W}_traffic.err"
+  if [ $W = c4 ] || [ $W = c5 ]; then python3 $REPO/profiles/make_traffic.py ${W}_env "$OUT/${W}_pmc_summary.txt" "$OUT/${W}_kernel_stats.csv" "$REPO/profiles/$ROUND" > "$OUT/traffic_${W}_env.json" 2>> "$OUT/${W}_traffic.err"; fi
   rm -rf "$OUT/stats_$W" "$OUT/pmc_fetch_$W" "$OUT/pmc_write_$W" "$OUT/pmc_sq_$W"
 done
 cd "$REPO"
