@@ -23,11 +23,12 @@ passes after start-up run ~6 % slow -- and every context has seen the workload o
 previous pass's pair statistics), then the W warm-up steps, barrier + synchronize, EXACTLY K timed steps, barrier + synchronize.
 
 Multi-GPU (--scaling):
-  weak (default; anchor pairs are independent, the path has no exchange step): every rank holds both structures and its OWN
-        P pairs; value = N x P pairs per max-over-ranks step time.
-  strong: ONE list of P pairs for the whole job (BASELINE configs[2] and [4] are fixed-size 8-GPU jobs): every rank runs the
-        library's partition kernels on the full list (pairs binned by their side-A anchor, loco_hd_amd/dist.py), scores its
-        share, and the shares travel to rank 0, which restores anchor-pair order.  c3 shards whole decoy pairs (tiles of the
+  strong (default for N > 1 ranks -- WORLD_SIZE or --gpus --, and for --emulate-world): ONE list of P pairs for the whole job
+        (BASELINE configs[2] and [4] are fixed-size 8-GPU jobs): every rank partitions the full list with the library's kernels
+        (pairs binned by their side-A anchor, loco_hd_amd/dist.py; planned once per list and reused while the tensor is unchanged,
+        --no-plan-cache plans in every step), scores its share, and the shares travel to rank 0, which restores anchor-pair order.
+  weak (default at N = 1; anchor pairs are independent, the path has no exchange step): every rank holds both structures and its
+        OWN P pairs; value = N x P pairs per max-over-ranks step time.  c3 shards whole decoy pairs (tiles of the
         50 x 50 pair matrix) so that a rank touches few decoys.
   In both modes the RCCL gather of the scores to rank 0 is INSIDE the timed steps for N > 1 (asynchronous, overlapped with the
   next step's scoring; `--gather end` moves it behind the timed region).
@@ -908,6 +909,15 @@ def main():
                          "2 for N > 1 and --emulate-world: consecutive steps overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg, the parity gate and the extras (profiling runs)")
     args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:  # (the launcher's world is what runs; the defaults below follow it, not just --gpus)
+        if world == 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        if args.gpus != 1:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch as many ranks as GPUs")
+        args.gpus = world  # torchrun without --gpus: the job is `world` GPUs wide
     if args.gather is None:
         args.gather = "step"
     if args.streams is None:
@@ -918,12 +928,6 @@ def main():
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or bool(os.environ.get("LCHD_BENCH_FORCE_DIST"))  # the latter: exercise RCCL init + gather on one GPU
