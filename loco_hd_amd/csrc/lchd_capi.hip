@@ -1475,9 +1475,18 @@ static int shard_rule_host(const int64_t* anchors, int64_t n_pairs, int64_t n_at
     return 2;
 }
 
+static int shard_plan_enqueue(lchd_ctx* c, const int64_t* d_anchors, const int64_t* h_src, int64_t n_pairs, int64_t n_atoms_a, int64_t n_atoms_b,
+                              int32_t world);
+static int shard_plan_wait(lchd_ctx* c, int64_t n_pairs, int64_t n_atoms_a, int64_t n_atoms_b, int32_t world, int64_t* counts_out);
+
 struct lchd_group {
     std::vector<lchd_ctx*> ctx;
     std::vector<int64_t> last_counts;
+    // the caller's pair list and the scores in the caller's order: pinned, visible to every device of the group (grow-only)
+    int64_t* h_list = nullptr;
+    double* h_out = nullptr;
+    char* h_stage = nullptr;  // both structures, staged ONCE per call (SoA, categories, tags): every device copies from here
+    size_t list_cap = 0, out_cap = 0, stage_cap = 0;
 };
 
 extern "C" int lchd_group_create(const int32_t* devices, int32_t n_devices, lchd_group** out) {
@@ -1496,7 +1505,135 @@ extern "C" int lchd_group_create(const int32_t* devices, int32_t n_devices, lchd
 extern "C" void lchd_group_destroy(lchd_group* g) {
     if (!g) return;
     for (lchd_ctx* c : g->ctx) lchd_ctx_destroy(c);
+    if (g->h_list) (void)hipHostFree(g->h_list);
+    if (g->h_out) (void)hipHostFree(g->h_out);
+    if (g->h_stage) (void)hipHostFree(g->h_stage);
     delete g;
+}
+
+// Device-side partition of a group call (no per-pair work on the calling thread): the pair list goes ONCE into a pinned block that
+// every device copies from; every device plans the partition itself (k_shard_plan: the same pure function of the list on all of
+// them), selects its share (k_shard_select), scores it, and writes its scores straight to their positions in ONE pinned, host-mapped
+// score block (k_scatter_scores); the caller gets one bulk copy of that block.  The calling thread touches the list twice (copy in,
+// copy out) whatever the number of devices; the host-side partition it replaces walked the list once per step of: histogram, W index
+// lists, gather into W staging blocks, scatter of the scores -- ~5 ns per pair that did not shrink with W.
+struct GroupDev {
+    lchd_cloud a, b;
+    size_t o_list = 0, o_sel = 0, o_idx = 0, o_sc = 0;
+    int64_t n_mine = 0;
+    bool planned = false, enqueued = false;
+};
+static int group_call_device_partition(lchd_group* g, const lchd_config* cfg, const double* xyz_a, const int32_t* cat_a, const int32_t* tag_a,
+                                       int64_t n_a, const double* xyz_b, const int32_t* cat_b, const int32_t* tag_b, int64_t n_b,
+                                       const int64_t* anchors, int64_t n_pairs, double thr, double* out) {
+    const int world = (int)g->ctx.size();
+    const size_t list_bytes = sizeof(int64_t) * 2 * (size_t)n_pairs, out_bytes = sizeof(double) * (size_t)n_pairs;
+    if (g->list_cap < list_bytes) {
+        if (g->h_list) (void)hipHostFree(g->h_list);
+        g->h_list = nullptr; g->list_cap = 0;
+        HIP_TRY(hipHostMalloc(&g->h_list, list_bytes + list_bytes / 8, hipHostMallocPortable | hipHostMallocMapped));
+        g->list_cap = list_bytes + list_bytes / 8;
+    }
+    if (g->out_cap < out_bytes) {
+        if (g->h_out) (void)hipHostFree(g->h_out);
+        g->h_out = nullptr; g->out_cap = 0;
+        HIP_TRY(hipHostMalloc(&g->h_out, out_bytes + out_bytes / 8, hipHostMallocPortable | hipHostMallocMapped));
+        g->out_cap = out_bytes + out_bytes / 8;
+    }
+    memcpy(g->h_list, anchors, list_bytes);  // (the caller's memory is pageable: one copy, every device reads the pinned block)
+    std::vector<GroupDev> dev((size_t)world);
+    int first_rc = LCHD_OK;
+    char first_msg[sizeof g_err] = "";
+    auto note = [&](int rc) {
+        if (rc && !first_rc) { first_rc = rc; memcpy(first_msg, g_err, sizeof g_err); }
+        return rc;
+    };
+    const int64_t slot = n_pairs / world + n_pairs / (2 * world) + 4096;  // most pairs of a share under the balance rule (1.25 P / W + 1), with headroom
+    // 1. both structures are staged ONCE (AoS -> SoA, finiteness, bounding box: host work that must not grow with the number of
+    //    devices) into the group's pinned block; every device copies them and the pair list from there and plans the partition
+    lchd_cloud sa, sb;  // device pointers relative to a null base: offsets
+    size_t in_bytes = 0;
+    {
+        size_t off = 0;
+        if (int rc = stage_cloud(xyz_a, cat_a, tag_a, n_a, nullptr, nullptr, off, sa, cfg->n_categories > kMaxCategories)) return rc;
+        if (int rc = stage_cloud(xyz_b, cat_b, tag_b, n_b, nullptr, nullptr, off, sb, cfg->n_categories > kMaxCategories)) return rc;
+        in_bytes = off;
+        if (g->stage_cap < in_bytes) {
+            if (g->h_stage) (void)hipHostFree(g->h_stage);
+            g->h_stage = nullptr; g->stage_cap = 0;
+            HIP_TRY(hipHostMalloc(&g->h_stage, in_bytes + in_bytes / 8, hipHostMallocPortable));
+            g->stage_cap = in_bytes + in_bytes / 8;
+        }
+        off = 0;
+        if (int rc = stage_cloud(xyz_a, cat_a, tag_a, n_a, g->h_stage, nullptr, off, sa, cfg->n_categories > kMaxCategories)) return rc;
+        if (int rc = stage_cloud(xyz_b, cat_b, tag_b, n_b, g->h_stage, nullptr, off, sb, cfg->n_categories > kMaxCategories)) return rc;
+    }
+    auto rebase = [](const lchd_cloud& src, char* d_base) {  // the staged structure as device `d_base` sees it
+        lchd_cloud cl = src;
+        auto mv = [&](auto*& p) { p = reinterpret_cast<std::remove_reference_t<decltype(p)>>(d_base + reinterpret_cast<uintptr_t>(p)); };
+        mv(cl.x); mv(cl.y); mv(cl.z); mv(cl.tag); mv(cl.cat);  // (offsets from a null base; x sits at offset 0)
+        if (cl.cat_hi) mv(cl.cat_hi);                            // (absent unless the configuration has more than 255 categories)
+        return cl;
+    };
+    for (int r = 0; r < world; ++r) {
+        lchd_ctx* c = g->ctx[(size_t)r];
+        GroupDev& D = dev[(size_t)r];
+        if (c->pend.active) { note(fail(LCHD_EVALUE, "an asynchronous call has not been finished (lchd_ctx_finish)")); continue; }
+        CTX_GUARD(c);
+        if (note(lchd_ctx_set_config(c, cfg))) continue;
+        size_t off = in_bytes;
+        auto take = [&](size_t bytes) { off = (off + 255) & ~size_t(255); const size_t o = off; off += bytes; return o; };
+        D.o_list = take(list_bytes);
+        D.o_sel = take(sizeof(int64_t) * 2 * (size_t)slot);
+        D.o_idx = take(sizeof(int64_t) * (size_t)slot);
+        D.o_sc = take(sizeof(double) * (size_t)slot);
+        if (note(grow_io(c, off))) continue;
+        D.a = rebase(sa, c->d_io);
+        D.b = rebase(sb, c->d_io);
+        if (hipMemcpyAsync(c->d_io, g->h_stage, in_bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) { note(fail(LCHD_EDEVICE, "H2D copy of the structures failed")); continue; }
+        if (note(shard_plan_enqueue(c, reinterpret_cast<const int64_t*>(c->d_io + D.o_list), g->h_list, n_pairs, n_a, n_b, world))) continue;
+        D.planned = true;
+    }
+    // 2. every device: its share's size, the selection, the pass
+    for (int r = 0; r < world; ++r) {
+        lchd_ctx* c = g->ctx[(size_t)r];
+        GroupDev& D = dev[(size_t)r];
+        if (!D.planned) continue;
+        CTX_GUARD(c);
+        int64_t counts[kShardMaxWorld];
+        if (note(shard_plan_wait(c, n_pairs, n_a, n_b, world, counts))) continue;
+        D.n_mine = counts[r];
+        g->last_counts[(size_t)r] = D.n_mine;
+        if (D.n_mine > slot) { note(fail(LCHD_EDEVICE, "a share of %lld pairs exceeds the slot of %lld", (long long)D.n_mine, (long long)slot)); continue; }
+        if (D.n_mine == 0) continue;
+        int64_t* d_sel = reinterpret_cast<int64_t*>(c->d_io + D.o_sel);
+        int64_t* d_idx = reinterpret_cast<int64_t*>(c->d_io + D.o_idx);
+        if (note(lchd_shard_select_dev(c, reinterpret_cast<const int64_t*>(c->d_io + D.o_list), n_pairs, n_a, n_b, r, d_sel, d_idx))) continue;
+        if (note(lchd_from_primitives_dev_async(c, &D.a, &D.b, d_sel, nullptr, D.n_mine, thr, reinterpret_cast<double*>(c->d_io + D.o_sc)))) continue;
+        D.enqueued = true;
+    }
+    // 3. finish (capacity retries happen here), then the scores to their positions in the pinned block
+    for (int r = 0; r < world; ++r) {
+        lchd_ctx* c = g->ctx[(size_t)r];
+        GroupDev& D = dev[(size_t)r];
+        if (!D.enqueued) continue;
+        CTX_GUARD(c);
+        if (note(lchd_ctx_finish(c))) { D.enqueued = false; continue; }
+        launch_scatter_scores(c->stream, reinterpret_cast<const double*>(c->d_io + D.o_sc), reinterpret_cast<const int64_t*>(c->d_io + D.o_idx),
+                              D.n_mine, g->h_out);
+    }
+    for (int r = 0; r < world; ++r) {
+        lchd_ctx* c = g->ctx[(size_t)r];
+        GroupDev& D = dev[(size_t)r];
+        c->last_valid = false;
+        c->pend.a = c->pend.b = nullptr;  // the structures of the call live in the I/O block, which the next call overwrites
+        if (!D.enqueued) continue;
+        CTX_GUARD(c);
+        if (hipStreamSynchronize(c->stream) != hipSuccess) note(fail(LCHD_EDEVICE, "HIP error while waiting for device %d of the group", r));
+    }
+    if (first_rc) { memcpy(g_err, first_msg, sizeof g_err); return first_rc; }
+    memcpy(out, g->h_out, out_bytes);
+    return LCHD_OK;
 }
 extern "C" int32_t lchd_group_size(const lchd_group* g) { return g ? (int32_t)g->ctx.size() : 0; }
 extern "C" int lchd_group_last_counts(const lchd_group* g, int64_t* counts_out) {
@@ -1519,6 +1656,9 @@ extern "C" int lchd_group_from_primitives(lchd_group* g, const lchd_config* cfg,
             if (int rc = lchd_ctx_set_config(c, cfg)) return rc;  // the reference validates its arguments even for an empty list
         return LCHD_OK;
     }
+    // several devices, one weight function: the partition runs on the devices (above)
+    if (world > 1 && n_a > 0 && !wf_index && !getenv("LCHD_GROUP_HOST_PARTITION"))
+        return group_call_device_partition(g, cfg, xyz_a, cat_a, tag_a, n_a, xyz_b, cat_b, tag_b, n_b, anchors, n_pairs, thr, out);
     // the pair list, binned by anchor (the rule of k_shard_plan): device r gets the positions subset[r]
     std::vector<std::vector<int64_t>> subset((size_t)world);
     if (world == 1 || n_a <= 0) {
@@ -1579,6 +1719,30 @@ static int ensure_shard_state(lchd_ctx* c) {
     }
     return LCHD_OK;
 }
+// The plan in two halves: enqueue (asynchronous, on the context's side stream) and wait (the per-rank counts come back through
+// pinned memory).  A caller that drives several devices enqueues all plans before it waits for the first.
+// h_src: when not null the pair list is first copied from this (pinned) host block to d_anchors, on the same side stream.
+static int shard_plan_enqueue(lchd_ctx* c, const int64_t* d_anchors, const int64_t* h_src, int64_t n_pairs, int64_t n_atoms_a, int64_t n_atoms_b,
+                              int32_t world) {
+    c->shard_world = 0;
+    if (int rc = ensure_shard_state(c)) return rc;
+    // On the context's side stream: the pair list is an INPUT (the caller has it ready), so the plan neither waits for the
+    // scoring passes queued on the context's stream nor makes the host wait for them.
+    if (c->shard_sel_pending) { HIP_TRY(hipStreamWaitEvent(c->shard_stream, c->shard_sel_ev, 0)); c->shard_sel_pending = false; }
+    if (h_src) HIP_TRY(hipMemcpyAsync(const_cast<int64_t*>(d_anchors), h_src, sizeof(int64_t) * 2 * (size_t)n_pairs, hipMemcpyHostToDevice, c->shard_stream));
+    launch_shard_plan(c->shard_stream, d_anchors, n_pairs, n_atoms_a, n_atoms_b, world, c->d_shard, c->h_counts);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->shard_ev, c->shard_stream));
+    return LCHD_OK;
+}
+static int shard_plan_wait(lchd_ctx* c, int64_t n_pairs, int64_t n_atoms_a, int64_t n_atoms_b, int32_t world, int64_t* counts_out) {
+    HIP_TRY(hipStreamSynchronize(c->shard_stream));
+    int64_t total = 0;
+    for (int r = 0; r < world; ++r) { counts_out[r] = c->h_counts[r]; total += counts_out[r]; }
+    if (total != n_pairs) return fail(LCHD_EDEVICE, "the shard plan accounts for %lld of %lld pairs", (long long)total, (long long)n_pairs);
+    c->shard_world = world; c->shard_pairs = n_pairs; c->shard_atoms = n_atoms_a; c->shard_atoms_b = n_atoms_b;
+    return LCHD_OK;
+}
 extern "C" int lchd_shard_plan_dev(lchd_ctx* c, const int64_t* d_anchors, int64_t n_pairs, int64_t n_atoms_a, int64_t n_atoms_b, int32_t world,
                                    int64_t* counts_out) {
     if (!c || !counts_out) return fail(LCHD_EVALUE, "null argument");
@@ -1589,19 +1753,8 @@ extern "C" int lchd_shard_plan_dev(lchd_ctx* c, const int64_t* d_anchors, int64_
     if (n_pairs == 0) { c->shard_world = world; c->shard_pairs = 0; c->shard_atoms = n_atoms_a; c->shard_atoms_b = n_atoms_b; return LCHD_OK; }
     if (!d_anchors) return fail(LCHD_EVALUE, "null anchor pointer");
     CTX_GUARD(c);
-    if (int rc = ensure_shard_state(c)) return rc;
-    // On the context's side stream: the pair list is an INPUT (the caller has it ready), so the plan neither waits for the
-    // scoring passes queued on the context's stream nor makes the host wait for them.
-    if (c->shard_sel_pending) { HIP_TRY(hipStreamWaitEvent(c->shard_stream, c->shard_sel_ev, 0)); c->shard_sel_pending = false; }
-    launch_shard_plan(c->shard_stream, d_anchors, n_pairs, n_atoms_a, n_atoms_b, world, c->d_shard, c->h_counts);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->shard_ev, c->shard_stream));
-    HIP_TRY(hipStreamSynchronize(c->shard_stream));
-    int64_t total = 0;
-    for (int r = 0; r < world; ++r) { counts_out[r] = c->h_counts[r]; total += counts_out[r]; }
-    if (total != n_pairs) return fail(LCHD_EDEVICE, "the shard plan accounts for %lld of %lld pairs", (long long)total, (long long)n_pairs);
-    c->shard_world = world; c->shard_pairs = n_pairs; c->shard_atoms = n_atoms_a; c->shard_atoms_b = n_atoms_b;
-    return LCHD_OK;
+    if (int rc = shard_plan_enqueue(c, d_anchors, nullptr, n_pairs, n_atoms_a, n_atoms_b, world)) return rc;
+    return shard_plan_wait(c, n_pairs, n_atoms_a, n_atoms_b, world, counts_out);
 }
 extern "C" int lchd_shard_select_dev(lchd_ctx* c, const int64_t* d_anchors, int64_t n_pairs, int64_t n_atoms_a, int64_t n_atoms_b, int32_t rank,
                                      int64_t* d_sel_anchors, int64_t* d_sel_index) {

@@ -336,6 +336,7 @@ void launch_shard_plan(hipStream_t s, const int64_t* anchors, int64_t n_pairs, i
                        int world, ShardState* st, int64_t* counts_host /* host-mapped [kShardMaxWorld + 1]: counts, then the key side */);
 void launch_shard_select(hipStream_t s, const int64_t* anchors, int64_t n_pairs, int64_t n_atoms_a, int64_t n_atoms_b, int rank, int world,
                          ShardState* st, int64_t* sel_anchors, int64_t* sel_index);
+void launch_scatter_scores(hipStream_t s, const double* scores, const int64_t* index, int64_t n, double* out);
 void launch_unshard_scores(hipStream_t s, const double* gathered, const ShardCounts& counts, int world, int64_t stride, double* out,
                            int64_t n_pairs, uint32_t* bad);
 void launch_env_points(hipStream_t s, const SweepArgs& a, unsigned long long* out);

@@ -4108,6 +4108,15 @@ void launch_shard_select(hipStream_t s, const int64_t* anchors, int64_t n_pairs,
     k_shard_select<<<(unsigned)(nb < 1024 ? (nb > 0 ? nb : 1) : 1024), 256, 0, s>>>(anchors, n_pairs, n_atoms_a, n_atoms_b, rank, world, st, sel_anchors,
                                                                                     sel_index);
 }
+// one share's scores back to their positions in the caller's order (out: any device-visible memory, e.g. a host-mapped block)
+__global__ void k_scatter_scores(const double* __restrict__ scores, const int64_t* __restrict__ index, int64_t n, double* __restrict__ out) {
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) out[index[k]] = scores[k];
+}
+void launch_scatter_scores(hipStream_t s, const double* scores, const int64_t* index, int64_t n, double* out) {
+    if (n <= 0) return;
+    const int64_t nb = (n + 255) / 256;
+    k_scatter_scores<<<(unsigned)(nb < 4096 ? nb : 4096), 256, 0, s>>>(scores, index, n, out);
+}
 void launch_unshard_scores(hipStream_t s, const double* gathered, const ShardCounts& counts, int world, int64_t stride, double* out,
                            int64_t n_pairs, uint32_t* bad) {
     k_unshard_scores<<<1024, 256, 0, s>>>(gathered, counts, world, stride, out, n_pairs, bad);
