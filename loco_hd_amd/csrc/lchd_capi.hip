@@ -1091,7 +1091,6 @@ extern "C" int lchd_frames_create(lchd_ctx* c, const lchd_cloud* tmpl, int32_t c
     if (!c || !tmpl || !out || capacity_frames < 1) return fail(LCHD_EVALUE, "bad argument");
     CTX_GUARD(c);
     if (tmpl->sid) return fail(LCHD_EVALUE, "the template of a frames buffer must be a single structure");
-    if (tmpl->cat_hi) return fail(LCHD_EUNSUPPORTED, "frames buffers take structures with at most 255 categories");
     const int64_t nt = tmpl->n, total = nt * capacity_frames;
     if (nt < 1 || total > ((int64_t)1 << 30)) return fail(LCHD_EUNSUPPORTED, "frames buffer of %lld atoms is out of range", (long long)total);
     lchd_cloud* cl = new lchd_cloud();
@@ -1117,6 +1116,12 @@ extern "C" int lchd_frames_create(lchd_ctx* c, const lchd_cloud* tmpl, int32_t c
     if ((e = hipEventCreateWithFlags(&cl->ev_ready, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipEventCreateWithFlags(&cl->ev_used, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     launch_frames_labels(c->stream, tmpl->cat, tmpl->tag, nt, capacity_frames, cl->cat, cl->tag, cl->sid);
+    if (tmpl->cat_hi) {  // more than 255 categories: the high bytes and the one-byte view travel with every frame as well
+        if ((e = hipMalloc(&cl->cat_hi, total)) != hipSuccess) return bail(e, "hipMalloc(cat_hi)");
+        if ((e = hipMalloc(&cl->cat_narrow, total)) != hipSuccess) return bail(e, "hipMalloc(cat_narrow)");
+        launch_frames_labels(c->stream, tmpl->cat_hi, tmpl->tag, nt, capacity_frames, cl->cat_hi, cl->tag, cl->sid);
+        launch_frames_labels(c->stream, tmpl->cat_narrow, tmpl->tag, nt, capacity_frames, cl->cat_narrow, cl->tag, cl->sid);
+    }
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(e, "frames label fill");
     *out = cl;
     return LCHD_OK;
@@ -2079,17 +2084,18 @@ extern "C" int lchd_from_anchors(lchd_ctx* c, const lchd_config* cfg, const int3
     // environments of more than 65 535 points: the 64-bit-count form of the wide sweep (8-bit category ids, 24-bit lengths)
     if ((len_seq_a > 65535 || len_seq_b > 65535) && (cfg->n_categories > kMaxCategories || len_seq_a >= (1 << 24) || len_seq_b >= (1 << 24)))
         return fail(LCHD_EUNSUPPORTED, "environments of more than 65535 points are supported with at most %d categories and fewer than 2^24 points", kMaxCategories);
+    bool ascending = true;  // (the reference never checks: lists that do not ascend take the literal walk of its loop, below)
     for (int side = 0; side < 2; ++side) {
         const double* d = side ? dists_b : dists_a;
         const int64_t n = side ? len_dists_b : len_dists_a;
         for (int64_t i = 0; i < n; ++i) {
             if (std::isnan(d[i])) return fail(LCHD_EPANIC, "internal error: entered unreachable code (NaN distance)");
             if (d[i] < 0.0) return fail(LCHD_EVALUE, "Invalid input value: %g. All values must be non-negative!", d[i]);
-            if (i && d[i] < d[i - 1])
-                return fail(LCHD_EUNSUPPORTED, "dists must be ascending (the reference does not check this and its result for "
-                                               "unsorted input is unspecified)");
+            if (i && d[i] < d[i - 1]) ascending = false;
         }
     }
+    if (!ascending && (len_seq_a > (1 << 24) || len_seq_b > (1 << 24)))
+        return fail(LCHD_EUNSUPPORTED, "lists whose distances do not ascend are walked by one lane: at most 2^24 points each");
     // pmf.rs:38-42: every point of both lists enters a PMF.  (The environment kernels make this check for the other entry
     // points; here the lists go to the sweep kernel as they are, and that kernel does not test categories.)
     for (int side = 0; side < 2; ++side) {
@@ -2138,6 +2144,15 @@ extern "C" int lchd_from_anchors(lchd_ctx* c, const lchd_config* cfg, const int3
     mark(c, 2);
     mark(c, 3);
     double* h_out = reinterpret_cast<double*>(c->h_io + o_out);
+    if (!ascending) {
+        // src/locohd.rs:97-221 on lists that do not ascend: no sort-based kernel computes what that loop computes; one lane walks it
+        c->status_dirty = false;
+        launch_anchors_literal(s, c->d_cfg, cfg->n_categories, ea, eb, (int)len_seq_a, (int)len_seq_b, wf_index, h_out);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(s));
+        *out = *h_out;
+        return LCHD_OK;
+    }
     // a single pair: its weight-function index travels as a 1-element device array only when it is not 0
     int rc = sweep_rows(c, ea, eb, wf_index != 0 ? reinterpret_cast<const int32_t*>(c->d_io + o_wf) : nullptr, 1, h_out,
                         reinterpret_cast<int4*>(c->d_io + o_meta), DRV_ANCHORS);

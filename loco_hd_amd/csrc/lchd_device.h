@@ -340,5 +340,8 @@ void launch_scatter_scores(hipStream_t s, const double* scores, const int64_t* i
 void launch_unshard_scores(hipStream_t s, const double* gathered, const ShardCounts& counts, int world, int64_t stride, double* out,
                            int64_t n_pairs, uint32_t* bad);
 void launch_env_points(hipStream_t s, const SweepArgs& a, unsigned long long* out);
+// from_anchors on lists whose distances do not ascend: the reference's loop walked literally by one lane (lchd_kernels.hip)
+void launch_anchors_literal(hipStream_t s, const DevConfig* cfg, int n_categories, const EnvStore& ea, const EnvStore& eb, int nA, int nB, int wfi,
+                            double* out);
 
 }  // namespace lchd

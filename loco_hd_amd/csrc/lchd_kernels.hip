@@ -2138,6 +2138,84 @@ __device__ __noinline__ double sd_generic(int kind, double p0, double p1, const 
     return sd_eval<0>(kind, p0, p1, [&](int c) { return p[c]; }, [&](int c) { return q[c]; }, C);
 }
 
+// from_anchors on lists whose distances do NOT ascend.  The reference never checks (src/locohd.rs:70-77 only looks at dists[0]) and
+// its two-pointer loop then still computes a well-defined number: the heads are compared as they come, the tail of the list that
+// is left over is walked in list order, and the first tail interval starts at the LAST element of the finished list (:134-221).
+// None of the sort-based kernels can reproduce that, so this one walks the loop itself: one lane, the two weighted count vectors
+// (pmf.rs:47-63) in LDS, the statistical distance through the generic evaluator on the normalised vectors (pmf.rs:65-88) at
+// every step, F(to) - F(from) per interval (weight_function.rs:118-120).  O((n_A + n_B) C) on one lane: an edge path, not a fast one.
+__global__ __launch_bounds__(64) void k_anchors_literal(const DevConfig* __restrict__ cfgp, EnvStore ea, EnvStore eb, int nA, int nB, int wfi,
+                                                        double* __restrict__ out) {
+    extern __shared__ double lit_s[];  // [4][C]: weighted counts of A, of B, the two normalised vectors
+    const int C = cfgp->n_categories;
+    double *pa = lit_s, *pb = lit_s + C, *qa = lit_s + 2 * C, *qb = lit_s + 3 * C;
+    for (int c = threadIdx.x; c < 2 * C; c += 64) lit_s[c] = 0.0;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const DevConfig cfg = *cfgp;
+    const WfEntry wf = cfg.wf[wfi];
+    const double* prm = cfg.wf_params + wf.offset;
+    auto cat_of = [&](const EnvStore& e, int i) -> int { return e.cat16 ? (int)reinterpret_cast<const uint16_t*>(e.cat)[i] : (int)e.cat[i]; };
+    auto dist_of = [&](const EnvStore& e, int i) -> double { return u2d(e.key[i]); };
+    auto F = [&](double x) -> double { return x == INFINITY ? cfg.wf_finf[wfi] : cdf_eval(wf.kind, prm, wf.n_params, x); };
+    auto range = [&](double from, double to) -> double { const double hi = F(to); return hi - F(from); };
+    auto H = [&]() -> double {  // pmf.rs:65-88: fresh sums, normalised copies, the configured distance
+        double sa = 0.0, sb = 0.0;
+        for (int c = 0; c < C; ++c) { sa += pa[c]; sb += pb[c]; }
+        for (int c = 0; c < C; ++c) { qa[c] = pa[c] / sa; qb[c] = pb[c] / sb; }
+        return sd_generic(cfg.sd_kind, cfg.sd_p0, cfg.sd_p1, qa, qb, C);
+    };
+    auto add_a = [&](int i) { const int c = cat_of(ea, i); pa[c] += cfg.cat_w[c]; };
+    auto add_b = [&](int j) { const int c = cat_of(eb, j); pb[c] += cfg.cat_w[c]; };
+    add_a(0);
+    add_b(0);
+    int i = 0, j = 0;
+    double acc = 0.0, prev = 0.0;
+    while (i < nA - 1 && j < nB - 1) {
+        const double h = H();
+        const double a = dist_of(ea, i + 1), b = dist_of(eb, j + 1);
+        double nd;
+        if (a < b) { ++i; add_a(i); nd = a; }
+        else if (a > b) { ++j; add_b(j); nd = b; }
+        else { ++i; ++j; add_a(i); add_b(j); nd = a; }  // (equal: NaN distances were refused on the host)
+        acc += range(prev, nd) * h;
+        prev = nd;
+    }
+    const double last_a = dist_of(ea, nA - 1), last_b = dist_of(eb, nB - 1);
+    if (j < nB - 1) {  // list A is finished
+        double h = H();
+        ++j;
+        acc += range(last_a, dist_of(eb, j)) * h;
+        add_b(j);
+        while (j < nB - 1) {
+            ++j;
+            h = H();
+            acc += range(dist_of(eb, j - 1), dist_of(eb, j)) * h;
+            add_b(j);
+        }
+        acc += range(last_b, INFINITY) * H();
+    } else if (i < nA - 1) {  // list B is finished
+        double h = H();
+        ++i;
+        acc += range(last_b, dist_of(ea, i)) * h;
+        add_a(i);
+        while (i < nA - 1) {
+            ++i;
+            h = H();
+            acc += range(dist_of(ea, i - 1), dist_of(ea, i)) * h;
+            add_a(i);
+        }
+        acc += range(last_a, INFINITY) * H();
+    } else {
+        acc += range(last_a, INFINITY) * H();
+    }
+    *out = acc;
+}
+void launch_anchors_literal(hipStream_t s, const DevConfig* cfg, int n_categories, const EnvStore& ea, const EnvStore& eb, int nA, int nB, int wfi,
+                            double* out) {
+    k_anchors_literal<<<1, 64, sizeof(double) * 4 * (size_t)n_categories, s>>>(cfg, ea, eb, nA, nB, wfi, out);
+}
+
 // Diagnostic build only (-DLCHD_SWEEP_STAMPS, never the shipped library): per-phase s_memtime deltas summed over all
 // wavefronts, read back with lchd_debug_sweep_stamps().
 #ifdef LCHD_SWEEP_STAMPS

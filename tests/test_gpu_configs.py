@@ -657,3 +657,31 @@ def test_category_weights_through_the_team_sweeps(lh, oracle, density, n_cat):
     assert np.array_equal(second, third)
     unit = np.asarray(lh.LoCoHD(cats, lh.WeightFunction("hyper_exp", [1.0, 0.1])).from_primitives(pa, pb, pairs, 10.0))
     assert np.max(np.abs(unit - second)) > 1e-4  # the weights do change the scores
+
+
+def test_trajectory_frames_with_more_than_255_categories(lh, oracle):
+    """A frames buffer of a template with 300 categories (two-byte category ids travel with every frame; src/locohd.rs:312-316 takes
+    any number of categories) against per-frame oracle calls."""
+    from loco_hd_amd.device import DeviceSession
+
+    rng = np.random.default_rng(88)
+    n, n_frames = 600, 9
+    cats = [f"k{i}" for i in range(300)]
+    seq = [cats[k] for k in rng.integers(0, 300, n)]
+    xyz = rng.uniform(0.0, 24.0, (n, 3))
+    tags = [f"A/{i // 3}" for i in range(n)]
+    frames = xyz[None, :, :] + rng.normal(0.0, 0.4, (n_frames,) + xyz.shape)
+    la = np.arange(0, n, 5)
+    local_pairs = np.stack([la, la], 1)
+    lchd = lh.LoCoHD(cats, lh.WeightFunction("hyper_exp", [1.0, 0.2]))
+    interner = {}
+    packed = lchd.pack(prims(lh, seq, xyz, tags), interner)
+    sess = DeviceSession(lchd, interner=interner)
+    ref = sess.upload(packed.xyz, packed.cat, packed.tag)
+    got = sess.score_trajectory(ref, frames, local_pairs, 9.0, chunk=4)
+    sess.close()
+    lo = oracle.LoCoHD(cats, oracle.WeightFunction("hyper_exp", [1.0, 0.2]))
+    ref_p = prims(oracle, seq, xyz, tags)
+    for f in (0, 3, 4, 8):
+        want = np.asarray(lo.from_primitives(ref_p, prims(oracle, seq, frames[f], tags), [(int(i), int(i)) for i in la], 9.0))
+        assert np.max(np.abs(got[f] - want)) < TIGHT, f

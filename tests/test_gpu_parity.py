@@ -691,3 +691,36 @@ def test_points_exactly_on_the_threshold(lh, oracle):
 
         got, want = both(lh, oracle, run)
         assert np.max(np.abs(got - want)) < TIGHT, thr
+
+
+def test_from_anchors_on_lists_that_do_not_ascend(lh, oracle):
+    """The reference checks only dists[0] (src/locohd.rs:70-77) and its two-pointer loop still computes a well-defined number on
+    lists whose distances do not ascend (heads compared as they come, the tail walked in list order, the first tail interval
+    starting at the LAST element of the finished list, :134-221).  One lane walks the same loop on the device."""
+    rng = np.random.default_rng(123)
+    wfs = [("uniform", [0.0, 6.0]), ("hyper_exp", [1.0, 0.3]), ("kumaraswamy", [1.0, 9.0, 2.0, 3.0]), ("dagum", [2.0, 4.0, 1.5])]
+    sds = [None, ("Kolmogorov-Smirnov", []), ("Kullback-Leibler", [1e-3]), ("Renyi", [2.5, 1e-3]), ("Hellinger", [3.0])]
+    for trial in range(24):
+        na, nb = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        da = np.concatenate([[0.0], rng.uniform(0.0, 8.0, na - 1)])  # NOT sorted
+        db = np.concatenate([[0.0], rng.uniform(0.0, 8.0, nb - 1)])
+        if trial % 4 == 0 and na > 3 and nb > 3:
+            db[1:3] = da[1:3]  # equal heads: the branch that advances both lists
+        sa, sb = [CATS[k] for k in rng.integers(0, 5, na)], [CATS[k] for k in rng.integers(0, 5, nb)]
+        wf, sd = wfs[trial % 4], sds[trial % 5]
+        weights = None if trial % 3 else [1.0, 0.5, 2.25, 3.0, 0.1]
+
+        def run(mod):
+            kw = {}
+            if sd is not None:
+                kw["statistical_distance"] = mod.StatisticalDistance(*sd)
+            if weights is not None:
+                kw["category_weights"] = weights
+            return mod.LoCoHD(CATS, mod.WeightFunction(*wf), **kw).from_anchors(sa, sb, da.tolist(), db.tolist())
+
+        got, want = run(lh), run(oracle)
+        assert abs(got - want) < TIGHT, (trial, na, nb, wf, sd)
+    # an ascending pair of lists still takes the sweep kernel and agrees with the literal walk of the oracle
+    da, db = np.sort(da), np.sort(db)
+    assert abs(lh.LoCoHD(CATS, lh.WeightFunction("uniform", [0.0, 6.0])).from_anchors(sa, sb, da.tolist(), db.tolist())
+               - oracle.LoCoHD(CATS, oracle.WeightFunction("uniform", [0.0, 6.0])).from_anchors(sa, sb, da.tolist(), db.tolist())) < TIGHT
