@@ -529,6 +529,8 @@ extern "C" int lchd_ctx_set_config(lchd_ctx* c, const lchd_config* cfg) {
                      cfg->sd_params[1] * 512.0 * std::max(1.0, std::fabs(al - 1.0)) <= 1e-6)
                 c->sd_fast = 2;
         }
+        // Kolmogorov-Smirnov on unit weights: max_c |a_c N_b - b_c N_a| / (N_a N_b) on integer counts (the KSM team sweep)
+        if (cfg->sd_kind == LCHD_SD_KOLMOGOROV_SMIRNOV) c->sd_fast = 3;
     }
     c->wf_pow = false;
     for (int i = 0; i < cfg->n_weight_functions; ++i)

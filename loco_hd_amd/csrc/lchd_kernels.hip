@@ -3034,8 +3034,12 @@ __device__ __forceinline__ double team_sum_f64(double v) {  // the last lane of 
 // WGT: category weights other than 1 (pmf.rs:47-63 adds weight[c] per point): H^2 = 1 - sum_c w_c sqrt(a_c b_c) / sqrt(W_a W_b) with the
 // weighted totals W = sum_c w_c count_c -- the same integer count fields and tables, one multiplier per category from LDS, two
 // running totals and one reciprocal square root per event instead of the two table look-ups of the unit-weight form.
-template <int CMAX, int TL = LCHD_DUO_TL, int TILE_ = kDuoTile, bool WGT = false>
+// KSM: the Kolmogorov-Smirnov distance max_c |a_c / N_a - b_c / N_b| (statistical_distances.rs:12-21) with unit weights instead of
+// Hellinger-2: every event needs all categories, but as INTEGERS -- max_c |a_c N_b - b_c N_a| over the 8-bit count fields (two 24-bit
+// multiplies, one v_sad_u32, one max per category), scaled once by 1 / (N_a N_b) from the reciprocal-root table; no square root.
+template <int CMAX, int TL = LCHD_DUO_TL, int TILE_ = kDuoTile, bool WGT = false, bool KSM = false>
 __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_WAVES)) void k_sweep_duo(SweepArgs args) {
+    static_assert(!KSM || (!WGT && CMAX <= 16), "the Kolmogorov-Smirnov form: unit weights, one or two count words per side");
     static_assert(TL == 16 || TL == 32, "a team is one or two DPP rows");
     constexpr int TEAMS = 64 / TL, EPL = TILE_ / TL, TILE = TILE_, WPB = kSweepWaves;
     constexpr int RULE = TILE_ == kDuoTile ? 0 : 2;
@@ -3296,6 +3300,16 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_W
                     cntA_ = *pa_;
                     cntB_ = *pb_;
                     *(takeA ? pa_ : pb_) = (unsigned char)((takeA ? cntA_ : cntB_) + 1);
+                } else if constexpr (KSM && NW > 1) {
+                    // every category is looked at after every event: the event goes straight into the count words
+                    cntA_ = cntB_ = 0;
+                    const uint64_t inc8 = 1ull << sh;
+#pragma unroll
+                    for (int k = 0; k < NW; ++k) {
+                        const bool hit = ((uct / FPW) == (unsigned)k);
+                        exA[k] += (hit && takeA) ? inc8 : 0ull;
+                        exB[k] += (hit && !takeA) ? inc8 : 0ull;
+                    }
                 } else if constexpr (NW == 1) {
                     // one count word per side (<= 8 slots): the event is added to the word itself -- no chunk-local fields, no second
                     // shift-and-mask pair per side
@@ -3328,6 +3342,24 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_W
                     dB[0] += takeA ? (H4)0 : inc4;
                 }
                 }
+                if constexpr (KSM) {
+                    const uint32_t Na = (uint32_t)(1 + i), Nb = (uint32_t)(1 + j);  // (the list positions are the totals)
+                    uint32_t best = 0u;
+#pragma unroll
+                    for (int k = 0; k < NW; ++k) {
+#pragma unroll
+                        for (int f = 0; f < FPW; ++f) {
+                            if (FPW * k + f < CMAX) {
+                                const uint32_t ca = (uint32_t)(exA[k] >> (f * FB)) & 0xFFu, cb = (uint32_t)(exB[k] >> (f * FB)) & 0xFFu;
+                                const uint32_t x = ca * Nb, y = cb * Na;  // (< 2^16 each)
+                                best = max(best, x > y ? x - y : y - x);
+                            }
+                        }
+                    }
+                    const double ia = t_rsqrt[Na], ib = t_rsqrt[Nb];
+                    Hp = (double)best * ((ia * ia) * (ib * ib));
+                    Fp = F;
+                } else {
                 const int mine_ = takeA ? cntA_ : cntB_, other = takeA ? cntB_ : cntA_;
                 if constexpr (WGT) {
                     const double wv_ = w_s[uct & 31u];
@@ -3384,6 +3416,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_W
                 }
                 Hp = sqrt_unit(h2);
                 Fp = F;
+                }
             }
         }
         // stitch the lane chunks of a team, add the last interval to +inf, reduce over the team
@@ -3816,13 +3849,18 @@ __global__ void k_pair_meta(SweepArgs args) {
 
 // A team kernel (tile240: four pairs of <= 240 events per wavefront, else two 8-bit-count pairs of <= 480), the INDIRECT companion for
 // the pairs its rule leaves over, and -- a pass without a hint -- the second team rule's kernel (tgrid != 0).
-template <int CM, bool WGT>
+// TM: 0 Hellinger-2 with unit weights, 1 with category weights, 2 Kolmogorov-Smirnov with unit weights
+template <int CM, int TM>
 static void launch_team(hipStream_t s, bool tile240, unsigned dgrid, unsigned bgrid, bool others, unsigned tgrid, const SweepArgs& a) {
     constexpr int NTH = 64 * kSweepWaves;
-    if (tile240) k_sweep_duo<CM, LCHD_DUO_TL, kDuoTile, WGT><<<dgrid, NTH, 0, s>>>(a);
-    else k_sweep_duo<CM, 32, kTeam8Tile, WGT><<<dgrid, NTH, 0, s>>>(a);
-    if (others) k_sweep<CM, WGT ? MODE_H2W : MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a);
-    if (tgrid) k_sweep_duo<CM, 32, kTeam8Tile, WGT><<<tgrid, NTH, 0, s>>>(a);
+    constexpr bool WGT = TM == 1, KSM = TM == 2;
+    if (tile240) k_sweep_duo<CM, LCHD_DUO_TL, kDuoTile, WGT, KSM><<<dgrid, NTH, 0, s>>>(a);
+    else k_sweep_duo<CM, 32, kTeam8Tile, WGT, KSM><<<dgrid, NTH, 0, s>>>(a);
+    if (others) {
+        if constexpr (KSM) k_sweep<CM, MODE_GEN, F_KEY, false, true><<<bgrid, NTH, 0, s>>>(a);
+        else k_sweep<CM, WGT ? MODE_H2W : MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a);
+    }
+    if (tgrid) k_sweep_duo<CM, 32, kTeam8Tile, WGT, KSM><<<tgrid, NTH, 0, s>>>(a);
 }
 
 int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinger2, bool unit_weights, bool wf_pow, int sweep_hint,
@@ -3865,7 +3903,10 @@ int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinge
     // ... and, up to 16 slots, for category weights other than 1 (the WGT instantiations of the team kernels; the one-pair-per-wavefront
     // 8-bit-count sweep has no weighted form, so both team rules must be available)
     const bool weighted_team = !unit_weights && cmax <= 16 && !t.no_duo && !t.no_c8_team && !t.no_count8 && (t.c8_team_max == 0 || t.c8_team_max >= cmax);
-    const bool fast_cfg = !wide && hellinger2 && (unit_weights || weighted_team) && small && fmode == F_KEY && !a.wf_index;
+    // ... and for the Kolmogorov-Smirnov distance with unit weights (SweepArgs::sd_fast == 3: the KSM instantiations)
+    const bool ks_team = !hellinger2 && a.sd_fast == 3 && unit_weights && cmax <= 16 && !t.no_duo && !t.no_c8_team && !t.no_count8 && !t.force_generic &&
+                         (t.c8_team_max == 0 || t.c8_team_max >= cmax);
+    const bool fast_cfg = !wide && ((hellinger2 && (unit_weights || weighted_team)) || ks_team) && small && fmode == F_KEY && !a.wf_index;
     // sweep_hint (what k_pair_meta counted in the previous pass of this configuration): 0 = nothing known, else
     // 4 | (pairs of <= 240 events were the majority ? 1 : 0) | (pairs with both environments <= 255 points were ? 2 : 0).
     // Up to 16 slots k_sweep_duo is the first choice and the 8-bit-count sweep the second (C2a: environments of ~170 points,
@@ -3916,31 +3957,39 @@ int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinge
                 const unsigned dgrid = (unsigned)(dblocks < tcap ? dblocks : tcap);
                 const int64_t tblocks = (a.n_pairs + 2 * kSweepWaves - 1) / (2 * kSweepWaves);
                 const unsigned tgrid = (unsigned)(tblocks < tcap ? tblocks : tcap);
-                if (unit_weights) {
-                    if (cmax <= 8) launch_team<8, false>(s, true, dgrid, bgrid, !no_others, a.second_rule ? tgrid : 0u, a);
-                    else if (cmax <= 12) launch_team<12, false>(s, true, dgrid, bgrid, !no_others, a.second_rule ? tgrid : 0u, a);
-                    else launch_team<16, false>(s, true, dgrid, bgrid, !no_others, a.second_rule ? tgrid : 0u, a);
+                if (ks_team) {
+                    if (cmax <= 8) launch_team<8, 2>(s, true, dgrid, bgrid, !no_others, a.second_rule ? tgrid : 0u, a);
+                    else if (cmax <= 12) launch_team<12, 2>(s, true, dgrid, bgrid, !no_others, a.second_rule ? tgrid : 0u, a);
+                    else launch_team<16, 2>(s, true, dgrid, bgrid, !no_others, a.second_rule ? tgrid : 0u, a);
+                } else if (unit_weights) {
+                    if (cmax <= 8) launch_team<8, 0>(s, true, dgrid, bgrid, !no_others, a.second_rule ? tgrid : 0u, a);
+                    else if (cmax <= 12) launch_team<12, 0>(s, true, dgrid, bgrid, !no_others, a.second_rule ? tgrid : 0u, a);
+                    else launch_team<16, 0>(s, true, dgrid, bgrid, !no_others, a.second_rule ? tgrid : 0u, a);
                 } else {
-                    if (cmax <= 8) launch_team<8, true>(s, true, dgrid, bgrid, !no_others, a.second_rule ? tgrid : 0u, a);
-                    else if (cmax <= 12) launch_team<12, true>(s, true, dgrid, bgrid, !no_others, a.second_rule ? tgrid : 0u, a);
-                    else launch_team<16, true>(s, true, dgrid, bgrid, !no_others, a.second_rule ? tgrid : 0u, a);
+                    if (cmax <= 8) launch_team<8, 1>(s, true, dgrid, bgrid, !no_others, a.second_rule ? tgrid : 0u, a);
+                    else if (cmax <= 12) launch_team<12, 1>(s, true, dgrid, bgrid, !no_others, a.second_rule ? tgrid : 0u, a);
+                    else launch_team<16, 1>(s, true, dgrid, bgrid, !no_others, a.second_rule ? tgrid : 0u, a);
                 }
             } else if (c8_team) {
                 constexpr int kTeamPairs = 2 * kSweepWaves;
                 const int64_t dblocks = (a.n_pairs + kTeamPairs - 1) / kTeamPairs;
                 const unsigned dgrid = (unsigned)(dblocks < tcap ? dblocks : tcap);
-                if (!unit_weights) {
-                    if (cmax <= 8) launch_team<8, true>(s, false, dgrid, bgrid, !no_others, 0u, a);
-                    else if (cmax <= 12) launch_team<12, true>(s, false, dgrid, bgrid, !no_others, 0u, a);
-                    else launch_team<16, true>(s, false, dgrid, bgrid, !no_others, 0u, a);
+                if (ks_team) {
+                    if (cmax <= 8) launch_team<8, 2>(s, false, dgrid, bgrid, !no_others, 0u, a);
+                    else if (cmax <= 12) launch_team<12, 2>(s, false, dgrid, bgrid, !no_others, 0u, a);
+                    else launch_team<16, 2>(s, false, dgrid, bgrid, !no_others, 0u, a);
+                } else if (!unit_weights) {
+                    if (cmax <= 8) launch_team<8, 1>(s, false, dgrid, bgrid, !no_others, 0u, a);
+                    else if (cmax <= 12) launch_team<12, 1>(s, false, dgrid, bgrid, !no_others, 0u, a);
+                    else launch_team<16, 1>(s, false, dgrid, bgrid, !no_others, 0u, a);
                 }
-                else if (cmax <= 8) launch_team<8, false>(s, false, dgrid, bgrid, !no_others, 0u, a);
-                else if (cmax <= 12) launch_team<12, false>(s, false, dgrid, bgrid, !no_others, 0u, a);
-                else if (cmax <= 16) launch_team<16, false>(s, false, dgrid, bgrid, !no_others, 0u, a);
-                else if (cmax <= 20) launch_team<20, false>(s, false, dgrid, bgrid, !no_others, 0u, a);
-                else if (cmax <= 24) launch_team<24, false>(s, false, dgrid, bgrid, !no_others, 0u, a);
-                else if (cmax <= 28) launch_team<28, false>(s, false, dgrid, bgrid, !no_others, 0u, a);
-                else launch_team<32, false>(s, false, dgrid, bgrid, !no_others, 0u, a);
+                else if (cmax <= 8) launch_team<8, 0>(s, false, dgrid, bgrid, !no_others, 0u, a);
+                else if (cmax <= 12) launch_team<12, 0>(s, false, dgrid, bgrid, !no_others, 0u, a);
+                else if (cmax <= 16) launch_team<16, 0>(s, false, dgrid, bgrid, !no_others, 0u, a);
+                else if (cmax <= 20) launch_team<20, 0>(s, false, dgrid, bgrid, !no_others, 0u, a);
+                else if (cmax <= 24) launch_team<24, 0>(s, false, dgrid, bgrid, !no_others, 0u, a);
+                else if (cmax <= 28) launch_team<28, 0>(s, false, dgrid, bgrid, !no_others, 0u, a);
+                else launch_team<32, 0>(s, false, dgrid, bgrid, !no_others, 0u, a);
             } else {
                 if (cmax <= 8) { k_sweep<8, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); if (!no_others) k_sweep<8, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
                 else if (cmax <= 12) { k_sweep<12, MODE_H2U, F_KEY, true, false, false, true><<<grid, NTH, 0, s>>>(a); if (!no_others) k_sweep<12, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a); }
@@ -3954,7 +4003,7 @@ int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinge
         }
     }
     if (!hellinger2) {
-        if (a.sd_fast && unit_weights && small && fmode == F_KEY && !a.wf_index && cmax <= 32) launch_sweep_inc(s, a.sd_fast, cmax, a);
+        if ((a.sd_fast == 1 || a.sd_fast == 2) && unit_weights && small && fmode == F_KEY && !a.wf_index && cmax <= 32) launch_sweep_inc(s, a.sd_fast, cmax, a);
         else launch_sweep_f<MODE_GEN, false>(s, cmax, grid, fmode, a);
     } else if (unit_weights) {
         if (small) launch_sweep_f<MODE_H2U, true>(s, cmax, grid, fmode, a);

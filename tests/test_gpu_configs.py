@@ -659,6 +659,41 @@ def test_category_weights_through_the_team_sweeps(lh, oracle, density, n_cat):
     assert np.max(np.abs(unit - second)) > 1e-4  # the weights do change the scores
 
 
+@pytest.mark.parametrize("density,n_cat", [(0.05, 10), (0.023, 8), (0.05, 16), (0.023, 3)])
+def test_kolmogorov_smirnov_through_the_team_sweeps(lh, oracle, density, n_cat, monkeypatch):
+    """StatisticalDistance("Kolmogorov-Smirnov", []) (src/statistical_distances.rs:16-21: max_c |p_c - q_c|) with unit category weights on
+    pair lists long enough for the team sweeps: integer counts, max_c |a_c N_b - b_c N_a| / (N_a N_b).  The KSM instantiations of
+    k_sweep_duo against the oracle and against the generic one-pair-per-wavefront sweep (LCHD_FORCE_GENERIC)."""
+    rng = np.random.default_rng(int(density * 1000) + n_cat + 77)
+    n, n_pairs = 2500, 24000
+    side = (n / density) ** (1 / 3)
+    cats = [f"c{i}" for i in range(n_cat)]
+    xa, xb = rng.uniform(0, side, (n, 3)), rng.uniform(0, side, (n, 3))
+    sa, sb = [cats[k] for k in rng.integers(0, n_cat, n)], [cats[k] for k in rng.integers(0, n_cat, n)]
+    pairs = [(int(a), int(b)) for a, b in zip(rng.integers(0, n, n_pairs), rng.integers(0, n, n_pairs))]
+    xa[:40] = xa[0] + rng.normal(0, 1.5, (40, 3))  # a few long pairs among the short ones (the companion launch)
+    xb[:40] = xb[0] + rng.normal(0, 1.5, (40, 3))
+
+    def build(mod):
+        lchd = mod.LoCoHD(cats, mod.WeightFunction("uniform", [3.0, 10.0]), statistical_distance=mod.StatisticalDistance("Kolmogorov-Smirnov", []))
+        return lchd, [mod.PrimitiveAtom(t, "", c) for t, c in zip(sa, xa)], [mod.PrimitiveAtom(t, "", c) for t, c in zip(sb, xb)]
+
+    lo, pa, pb = build(oracle)
+    want = np.asarray(lo.from_primitives(pa, pb, pairs, 10.0))
+    lchd, pa, pb = build(lh)
+    first = np.asarray(lchd.from_primitives(pa, pb, pairs, 10.0))
+    second = np.asarray(lchd.from_primitives(pa, pb, pairs, 10.0))
+    third = np.asarray(lchd.from_primitives(pa, pb, pairs, 10.0))
+    assert np.max(np.abs(first - want)) < TIGHT
+    assert np.max(np.abs(second - want)) < TIGHT
+    assert np.array_equal(second, third)
+    monkeypatch.setenv("LCHD_FORCE_GENERIC", "1")
+    generic = np.asarray(build(lh)[0].from_primitives(pa, pb, pairs, 10.0))
+    assert np.max(np.abs(generic - second)) < TIGHT
+    h2 = np.asarray(lh.LoCoHD(cats, lh.WeightFunction("uniform", [3.0, 10.0])).from_primitives(pa, pb, pairs, 10.0))
+    assert np.max(np.abs(h2 - second)) > 1e-4  # (a different distance)
+
+
 def test_trajectory_frames_with_more_than_255_categories(lh, oracle):
     """A frames buffer of a template with 300 categories (two-byte category ids travel with every frame; src/locohd.rs:312-316 takes
     any number of categories) against per-frame oracle calls."""
