@@ -243,6 +243,13 @@ int32_t lchd_ctx_last_dense_fused(lchd_ctx *ctx);
  * repeated when an environment overflowed the capacity tried (src/locohd.rs:514-542 has no capacity) or when the sweep launch
  * set picked from the previous call's pair statistics did not cover this call's pairs. */
 int64_t lchd_ctx_pass_count(lchd_ctx *ctx);
+/* Second passes run so far.  Environments live in fixed-stride slots (512 points by default); the reference's environments have no
+ * capacity (src/locohd.rs:514-542: a Vec per anchor).  When a FEW environments of a call do not fit their slots, only the pairs
+ * that touch them are scored again -- a pass of their own with larger slots, its scores scattered over the first pass's --
+ * instead of giving every environment of the call the larger slot. */
+int64_t lchd_ctx_subset_pass_count(lchd_ctx *ctx);
+/* Environment-store bytes (keys + categories, both sides) carved by the passes of the most recent from_primitives call, summed. */
+int64_t lchd_ctx_last_store_bytes(lchd_ctx *ctx);
 
 #ifdef __cplusplus
 }

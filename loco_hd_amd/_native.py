@@ -98,6 +98,8 @@ _PROTOS = {
     "lchd_ctx_last_env_points": (C.c_int64, [_VP]),
     "lchd_ctx_last_dense_fused": (C.c_int32, [_VP]),
     "lchd_ctx_pass_count": (C.c_int64, [_VP]),
+    "lchd_ctx_subset_pass_count": (C.c_int64, [_VP]),
+    "lchd_ctx_last_store_bytes": (C.c_int64, [_VP]),
 }
 
 _lib = None

@@ -194,6 +194,11 @@ struct lchd_ctx {
     int64_t last_biggest = 0;  // largest environment of the last pass (0: unknown): anchors per wavefront of k_env_group
     int shrink_votes = 0;  // consecutive passes whose largest environment would fit half of cap_hint
     bool last_dense_fused = false;  // the most recent dense pass ran the fused sort + sweep kernel (lchd_dense_fused.hip)
+    // second pass over the pairs of overflowed environments (lchd_ctx_finish): grow-only device blocks outside the arena
+    char *d_ovf_bits = nullptr, *d_ovf_lists = nullptr;
+    size_t ovf_bits_cap = 0, ovf_lists_cap = 0;
+    int64_t n_subset_passes = 0;    // second passes run so far
+    size_t last_store_bytes = 0;    // environment-store bytes (keys + categories, both sides) of the passes of the last from_primitives call
     int64_t n_passes = 0;           // from_primitives passes enqueued so far (a call is one pass unless a capacity / launch-set retry repeats it)
     // timing
     bool timing = false;
@@ -212,6 +217,9 @@ struct lchd_ctx {
         bool group = false, group_small = false;  // which environment kernel the enqueued pass uses
         int sweep_info = 0;                        // launch_sweep's return value
         SweepArgs sw{};
+        const uint32_t *ovf_a = nullptr, *ovf_b = nullptr;  // overflow lists of the enqueued pass (null: its kernels keep none)
+        int64_t n_slots_a = 0, n_slots_b = 0;               // environment slots per side
+        bool subset = false;                                // the enqueued pass IS a second pass over the pairs of overflowed environments
     } pend;
     // multi-GPU sharding helpers (lchd_shard_*): device state, host-mapped counts, the plan they belong to
     ShardState* d_shard = nullptr;
@@ -283,6 +291,7 @@ static Tuning tuning_from_env() {  // the ONLY place that reads LCHD_* hooks (te
     t.no_dense_fused = getenv("LCHD_NO_DENSE_FUSED") != nullptr;
     t.no_tables = getenv("LCHD_NO_SD_TABLES") != nullptr;
     t.no_env_group = getenv("LCHD_NO_ENV_GROUP") != nullptr;
+    t.no_overflow_subset = getenv("LCHD_NO_OVERFLOW_SUBSET") != nullptr;
     t.env_apw = env_int("LCHD_ENV_APW", 0);
     t.env_small = env_int("LCHD_ENV_GROUP_SMALL", -1);
     t.sweep_grid = env_int("LCHD_SWEEP_GRID", 0);
@@ -370,6 +379,8 @@ extern "C" void lchd_ctx_destroy(lchd_ctx* c) {
     (void)hipFree(c->d_powtab);
     (void)hipFree(c->d_done);
     (void)hipFree(c->d_io);
+    (void)hipFree(c->d_ovf_bits);
+    (void)hipFree(c->d_ovf_lists);
     (void)hipFree(c->d_shard);
     (void)hipFree(c->d_bad);
     if (c->shard_stream) (void)hipStreamDestroy(c->shard_stream);
@@ -816,6 +827,7 @@ struct SideBufs {
     EnvStore env;
     double* raw_key;   // environments of more than 16384 points: unsorted scratch rows (k_env_collect)
     uint8_t* raw_cat;
+    uint32_t* ovf_list;  // slots of the environments that overflowed (EnvSide::ovf_list)
 };
 
 // Workspace layout of one pass.  Everything that must be zero when the prologue starts -- the general cell list's counters
@@ -861,6 +873,7 @@ static void carve_pass(Arena& ar, int64_t n_a, int cells_a, int64_t envs_a, int6
         b.env.cat16 = cat16 ? 1 : 0;
         b.raw_key = cap > 16384 ? ar.take<double>(ne * (size_t)cap) : nullptr;
         b.raw_cat = cap > 16384 ? ar.take<uint8_t>(ne * (size_t)cap) : nullptr;
+        b.ovf_list = cap <= 16384 ? ar.take<uint32_t>(ne) : nullptr;
     }
     pb.pair_meta = ar.take<int4>((size_t)n_pairs);
 }
@@ -961,7 +974,13 @@ static int prims_enqueue(lchd_ctx* c) {
     mark(c, 1);
     mark(c, 2);  // (cell lists and anchor de-duplication are one phase now; "anchors" reads 0)
     const bool tag_list = c->h_cfg.tag_mode != 0;
-    const EnvSide esa{cva, gva, sa.uniq, sa.env, max_env_a, sa.raw_key, sa.raw_cat}, esb{cvb, gvb, sb.uniq, sb.env, max_env_b, sb.raw_key, sb.raw_cat};
+    const EnvSide esa{cva, gva, sa.uniq, sa.env, max_env_a, sa.raw_key, sa.raw_cat, sa.ovf_list},
+                  esb{cvb, gvb, sb.uniq, sb.env, max_env_b, sb.raw_key, sb.raw_cat, sb.ovf_list};
+    P.ovf_a = sa.ovf_list;
+    P.ovf_b = sb.ovf_list;
+    P.n_slots_a = max_env_a;
+    P.n_slots_b = max_env_b;
+    c->last_store_bytes += (size_t)(std::max<int64_t>(max_env_a, 1) + std::max<int64_t>(max_env_b, 1)) * (size_t)cap * (cat16 ? 10 : 9);
     if (group) {
         // anchors per wavefront: as many as fit ONE group of the kernel's LDS buffer (measured, env phase in ms for 1 / 2 / 4 / 8 /
         // 16 anchors: C4, ~96-point environments 3.87 / 2.88 / 2.68 / 2.69 / 2.96; C5, ~200 points 0.81 / 0.75 / 0.75 / 0.78 / 0.81 --
@@ -1020,24 +1039,113 @@ extern "C" int lchd_from_primitives_dev_async(lchd_ctx* c, lchd_cloud* a, lchd_c
     auto& P = c->pend;
     P.a = a; P.b = b; P.anchors = d_anchors; P.wf = d_wf_index; P.n_pairs = n_pairs; P.thr = thr; P.out = d_out;
     P.cap = c->cap_hint;
+    P.subset = false;
+    c->last_store_bytes = 0;
     if (int rc = prims_enqueue(c)) return rc;
     P.active = true;
     return LCHD_OK;
 }
 
-extern "C" int lchd_ctx_finish(lchd_ctx* c) {
-    if (!c) return fail(LCHD_EVALUE, "null context");
+static int grow_block(char*& blk, size_t& cap, size_t need) {
+    if (need <= cap) return LCHD_OK;
+    if (blk) (void)hipFree(blk);
+    blk = nullptr;
+    cap = 0;
+    const size_t got = need + need / 4 + 4096;
+    if (hipMalloc(&blk, got) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(LCHD_EUNSUPPORTED, "no device memory for %zu bytes of the second pass over overflowed environments", got);
+    }
+    cap = got;
+    return LCHD_OK;
+}
+
+static int finish_passes(lchd_ctx* c, uint32_t* flags_out);
+
+// The pass that just finished flagged environments that did not fit their slots, and they are few: instead of repeating the
+// WHOLE pass with larger slots (fixed stride: every environment of the call would pay for the largest one -- one 6 000-point
+// cluster in a sparse 2 10^5-point cloud turns a 1.8 GB store into 15 GB), only the pairs that touch such an environment are
+// scored again: selected on the device in list order, run as a pass of their own (its own unique anchors, slots of the size the
+// overflow asked for, the regular retry loop), their scores scattered over the first pass's.  The first pass gave those
+// environments the anchor alone (a valid one-point environment), so every other score and status word of it stands.
+// *handled = false: not applicable (too many overflowed environments, nothing recorded), the caller repeats the whole pass.
+static int rescore_overflow_pairs(lchd_ctx* c, uint32_t f1, int64_t biggest, bool* handled, uint32_t* flags_out) {
+    *handled = false;
     auto& P = c->pend;
-    if (!P.active) return LCHD_OK;
-    P.active = false;
-    CTX_GUARD(c);
+    const HostStatus* h = c->h_status;
+    const uint32_t na = h->n_overflow[0], nb = h->n_overflow[1];
+    const uint64_t n_uniq = (uint64_t)h->n_unique[0] + h->n_unique[1];
+    if (P.subset || c->tune.no_overflow_subset || !P.ovf_a || na + nb == 0 || (f1 & ST_EMPTY_ENV)) return LCHD_OK;
+    if ((uint64_t)(na + nb) * 8 > n_uniq) return LCHD_OK;  // not a minority: larger slots for everything
+    hipStream_t s = c->stream;
+    const SweepArgs sw = P.sw;  // the finished pass's arrays (the arena stays as it is until the second pass is enqueued)
+    const bool same = sw.slot_a == sw.slot_b && sw.env_a.key == sw.env_b.key;
+    // bit sets over the slots + the selection's scratch
+    const size_t wa = (size_t)(P.n_slots_a + 31) / 32 + 1, wb = same ? 0 : (size_t)(P.n_slots_b + 31) / 32 + 1;
+    const size_t o_cnt = (wa + wb) * 4, o_tot = o_cnt + (size_t)kOverflowWaves * 8, bits_bytes = o_tot + 8;
+    if (int rc = grow_block(c->d_ovf_bits, c->ovf_bits_cap, bits_bytes)) return rc;
+    uint32_t* bits_a = reinterpret_cast<uint32_t*>(c->d_ovf_bits);
+    uint32_t* bits_b = same ? bits_a : bits_a + wa;
+    HIP_TRY(hipMemsetAsync(c->d_ovf_bits, 0, bits_bytes, s));
+    launch_mark_overflow(s, P.ovf_a, na, P.ovf_b, nb, bits_a, bits_b);
+    OverflowSelect sel{};
+    sel.anchors = sw.anchors; sel.n_pairs = sw.n_pairs; sel.slot_a = sw.slot_a; sel.slot_b = sw.slot_b;
+    sel.bits_a = bits_a; sel.bits_b = bits_b; sel.wf = sw.wf_index;
+    sel.wave_count = reinterpret_cast<unsigned long long*>(c->d_ovf_bits + o_cnt);
+    unsigned long long* d_total = reinterpret_cast<unsigned long long*>(c->d_ovf_bits + o_tot);
+    launch_count_overflow(s, sel, d_total);
+    unsigned long long n_sub = 0;
+    HIP_TRY(hipMemcpyAsync(&n_sub, d_total, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (n_sub == 0 || n_sub * 2 > (unsigned long long)sw.n_pairs) return LCHD_OK;  // (most pairs touch one: the whole pass again)
+    const size_t o_anc = (size_t)n_sub * 8, o_out = o_anc + (size_t)n_sub * 16, o_wf = o_out + (size_t)n_sub * 8,
+                 list_bytes = o_wf + (sw.wf_index ? (size_t)n_sub * 4 : 0);
+    if (int rc = grow_block(c->d_ovf_lists, c->ovf_lists_cap, list_bytes)) return rc;
+    sel.sel_index = reinterpret_cast<int64_t*>(c->d_ovf_lists);
+    sel.sel_anchors = reinterpret_cast<int64_t*>(c->d_ovf_lists + o_anc);
+    sel.sel_wf = sw.wf_index ? reinterpret_cast<int32_t*>(c->d_ovf_lists + o_wf) : nullptr;
+    double* sub_out = reinterpret_cast<double*>(c->d_ovf_lists + o_out);
+    launch_write_overflow(s, sel);
+    HIP_TRY(hipGetLastError());
+    // the second pass: the context's hints describe the caller's workload, not this selection -- saved and restored around it
+    const auto saved = P;
+    const int cap_hint = c->cap_hint, sweep_hint = c->sweep_hint, shrink_votes = c->shrink_votes;
+    const bool group_small = c->group_small;
+    const int64_t last_biggest = c->last_biggest;
+    P.anchors = sel.sel_anchors; P.wf = sel.sel_wf; P.n_pairs = (int64_t)n_sub; P.out = sub_out;
+    // (an anchor whose candidate table overflowed reported its candidates, an upper bound: a few large slots cost little here)
+    P.cap = next_pow2_host(std::max<int64_t>(std::max<int64_t>(biggest, h->max_bound), saved.cap + 1));
+    P.subset = true;
+    c->sweep_hint = 0;
+    c->last_biggest = biggest;
+    ++c->n_subset_passes;
+    uint32_t f2 = 0;
+    int rc = prims_enqueue(c);
+    if (!rc) rc = finish_passes(c, &f2);
+    const SweepArgs sub_sw = P.sw;
+    P = saved;
+    c->cap_hint = cap_hint; c->sweep_hint = sweep_hint; c->shrink_votes = shrink_votes; c->group_small = group_small; c->last_biggest = last_biggest;
+    (void)sub_sw;
+    if (rc) return rc;
+    launch_scatter_scores(s, sub_out, sel.sel_index, (int64_t)n_sub, saved.out);
+    HIP_TRY(hipStreamSynchronize(s));
+    c->last_valid = false;  // (c->last would describe the first pass, whose arena the second one has reused)
+    *flags_out = (f1 & ~ST_ENV_OVERFLOW) | f2;
+    *handled = true;
+    return LCHD_OK;
+}
+
+// Waits for the enqueued pass and repeats it while the device asks for it (larger slots, the full launch set); *flags_out = the
+// status words of the pass that stood.
+static int finish_passes(lchd_ctx* c, uint32_t* flags_out) {
+    auto& P = c->pend;
     for (int attempt = 0; attempt < 6; ++attempt) {
         uint32_t f = 0;
         if (int rc = wait_pass(c, &f)) return rc;
         collect_times(c, 0, 4);
-        if (f & ST_BAD_ANCHOR) return status_to_rc(f, DRV_PRIMS);
+        if (f & ST_BAD_ANCHOR) { *flags_out = f; return LCHD_OK; }
         const int64_t biggest = c->h_status->max_env;  // largest environment of the pass (k_pair_meta), or what overflowed
-        if (f & ST_ENV_OVERFLOW) {  // an environment did not fit the kernel variant's LDS capacity: run the pass again, larger
+        if (f & ST_ENV_OVERFLOW) {  // an environment did not fit its slot: its pairs again with larger slots, or the whole pass
             if (biggest > 65535 && (c->h_cfg.n_categories > kMaxCategories || biggest > (1 << 23)))
                 return fail(LCHD_EUNSUPPORTED, "an environment holds %lld points; beyond 65535 per environment this build handles at most %d "
                                                "categories and 2^23 points (the 64-bit-count sweep)", (long long)biggest, kMaxCategories);
@@ -1045,19 +1153,26 @@ extern "C" int lchd_ctx_finish(lchd_ctx* c) {
                 c->group_small = false;  // the small instantiation of k_env_group overflowed: the same capacity with the regular one
                 c->last_biggest = std::max<int64_t>(biggest, kEnvGroupCapSmall + 1);  // (also when LCHD_ENV_GROUP_SMALL=1 forces the small one)
             } else {
-                P.cap = next_pow2_host(std::max<int64_t>(biggest, P.cap + 1));
-                c->cap_hint = P.cap;
-                c->shrink_votes = 0;
+                bool handled = false;
+                if (int rc = rescore_overflow_pairs(c, f, biggest, &handled, flags_out)) return rc;
+                if (handled) return LCHD_OK;
+                // (candidate-table overflows reported an upper bound -- candidates, ~2.4 environments' worth on a uniform cloud --: the whole
+                //  pass tries the slot size that would fit a typical share of them first; a subset's few slots take the bound itself)
+                const int64_t bound = c->h_status->max_bound;
+                P.cap = next_pow2_host(std::max<int64_t>(std::max<int64_t>(biggest, P.subset ? bound : bound / 3), P.cap + 1));
+                if (!P.subset) { c->cap_hint = P.cap; c->shrink_votes = 0; }
             }
             if (int rc = prims_enqueue(c)) return rc;
             continue;
         }
         // The capacity hint decays: a single dense environment should not make every later call of this context pay for
         // its slot size (slots are fixed-stride).  Eight passes in a row that would have fitted half the capacity halve it.
-        if (c->cap_hint > 512 && !c->tune.cap_hint && biggest > 0 && 2 * next_pow2_host(biggest) <= c->cap_hint) {
-            if (++c->shrink_votes >= 8) { c->cap_hint = std::max(512, c->cap_hint / 2); c->shrink_votes = 0; }
-        } else {
-            c->shrink_votes = 0;
+        if (!P.subset) {
+            if (c->cap_hint > 512 && !c->tune.cap_hint && biggest > 0 && 2 * next_pow2_host(biggest) <= c->cap_hint) {
+                if (++c->shrink_votes >= 8) { c->cap_hint = std::max(512, c->cap_hint / 2); c->shrink_votes = 0; }
+            } else {
+                c->shrink_votes = 0;
+            }
         }
         if ((P.sweep_info & 2) && c->h_status->n_small != ~0ull) {
             // the companion sweep for the larger pairs was left out because the previous pass had none: did this one?
@@ -1075,10 +1190,25 @@ extern "C" int lchd_ctx_finish(lchd_ctx* c) {
                             (c->h_status->n_duo == (unsigned long long)P.n_pairs ? 8 : 0) | (c->h_status->n_c8 == (unsigned long long)P.n_pairs ? 16 : 0);
         c->last = P.sw;
         c->last_valid = true;
-        return status_to_rc(f, DRV_PRIMS);
+        *flags_out = f;
+        return LCHD_OK;
     }
     return fail(LCHD_EDEVICE, "environment capacity retry did not converge");
 }
+
+extern "C" int lchd_ctx_finish(lchd_ctx* c) {
+    if (!c) return fail(LCHD_EVALUE, "null context");
+    auto& P = c->pend;
+    if (!P.active) return LCHD_OK;
+    P.active = false;
+    CTX_GUARD(c);
+    uint32_t f = 0;
+    if (int rc = finish_passes(c, &f)) return rc;
+    return status_to_rc(f, DRV_PRIMS);
+}
+
+extern "C" int64_t lchd_ctx_subset_pass_count(lchd_ctx* c) { return c ? c->n_subset_passes : -1; }
+extern "C" int64_t lchd_ctx_last_store_bytes(lchd_ctx* c) { return c ? (int64_t)c->last_store_bytes : -1; }
 
 extern "C" int lchd_from_primitives_dev(lchd_ctx* c, lchd_cloud* a, lchd_cloud* b, const int64_t* d_anchors,
                                         const int32_t* d_wf_index, int64_t n_pairs, double thr, double* d_out) {

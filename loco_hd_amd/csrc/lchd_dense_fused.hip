@@ -487,8 +487,8 @@ __global__ __launch_bounds__(kNT, 4) void k_dense_fused(DenseArgs a) {
                         for (int u = 0; u < 4; ++u) kj[u] = skey[min(j + u, hi - 1u)];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
-                            less += (j + u < hi) & (kj[u] < mine) ? 1u : 0u;
-                            same += (j + u < hi) & (kj[u] == mine) ? 1u : 0u;
+                            less += ((j + u < hi) & (kj[u] < mine)) ? 1u : 0u;
+                            same += ((j + u < hi) & (kj[u] == mine)) ? 1u : 0u;
                         }
                     }
                     if (same > 1u) {  // (itself and at least one other member)

@@ -37,9 +37,11 @@ struct DeviceStatus {
     uint32_t flags;
     uint32_t max_env;        // largest environment seen (for the overflow retry)
     uint32_t n_unique[2];    // unique anchors per side
-    uint32_t pad[2];
+    uint32_t n_overflow[2];  // environments per side that did not fit their slot (entries of EnvSide::ovf_list); reset with the flags
     unsigned long long n_small;     // pairs under the pass's first-choice small rule (k_pair_meta): who sweeps them is decided on the device
     unsigned long long n_c8;        // pairs under SweepArgs::c8_rule (the second choice of a pass without a hint)
+    uint32_t max_bound;      // k_env_group: most CANDIDATES of an anchor whose candidate table overflowed (an upper bound of its environment; max_env
+    uint32_t pad_;           //  then only says "more than the capacity"); reset with the flags
 };
 // Host-mapped (pinned, device-visible) mirror: written with plain stores only -- the snapshot by one thread of k_pair_meta,
 // the error words by whichever sweep wavefront meets the (rare) condition; every writer of a word stores the same value.
@@ -52,6 +54,9 @@ struct HostStatus {
     uint32_t snapshot_seq;   // pass counter written with the snapshot (the host checks that the pass it waited for got this far)
     uint32_t pad;
     unsigned long long n_duo, n_c8;  // pairs of at most kDuoTile merged events / with both environments <= 255 points (both always counted)
+    uint32_t n_overflow[2];  // DeviceStatus::n_overflow at the end of the record pass
+    uint32_t max_bound;      // DeviceStatus::max_bound
+    uint32_t pad2;
 };
 
 // Test / tuning hooks.  Read from the environment ONCE, when a context is created (lchd_ctx_create), and handed to the
@@ -73,6 +78,7 @@ struct Tuning {
     bool no_c8_team = false;        // LCHD_NO_C8_TEAM: the 8-bit-count sweep always one pair per wavefront (k_sweep<.., CNT8>)
     int c8_team_max = 0;            // LCHD_C8_TEAM_MAX: ... above this many category slots (0: the two-pairs form up to 32)
     bool no_tables = false;         // LCHD_NO_SD_TABLES: generic distances without the per-launch power / log tables
+    bool no_overflow_subset = false;  // LCHD_NO_OVERFLOW_SUBSET: an overflowing environment repeats the WHOLE pass with larger slots (never only its pairs)
     bool no_env_group = false;      // LCHD_NO_ENV_GROUP: environments of the default capacity through k_env_cells (one per wavefront) too
     bool no_sd_inc = false;         // LCHD_NO_SD_INC: Kullback-Leibler / Renyi through the generic sweep even where k_sweep_inc applies
     int sweep_grid = 0;             // LCHD_SWEEP_GRID: most workgroups of a sweep launch (0: 8192)
@@ -192,6 +198,10 @@ struct EnvSide {
     int64_t max_envs;   // upper bound of the side's unique anchors (the kernel stops at DeviceStatus::n_unique[side])
     double* raw_key;    // environments of more than 16384 points only: [max_envs][cap] unsorted distances ...
     uint8_t* raw_cat;   // ... and categories (k_env_collect -> k_env_rows)
+    // Environments that do not fit their slot (k_env_group / k_env_cells): the slot receives the anchor alone (a valid one-point
+    // environment, so the sweeps of this pass run cleanly over it) and the slot index is appended here
+    // (DeviceStatus::n_overflow[side] counts); the host scores the pairs of these anchors again with larger slots.
+    uint32_t* ovf_list;
 };
 struct EnvSides {
     EnvSide s[2];
@@ -336,6 +346,22 @@ void launch_shard_plan(hipStream_t s, const int64_t* anchors, int64_t n_pairs, i
                        int world, ShardState* st, int64_t* counts_host /* host-mapped [kShardMaxWorld + 1]: counts, then the key side */);
 void launch_shard_select(hipStream_t s, const int64_t* anchors, int64_t n_pairs, int64_t n_atoms_a, int64_t n_atoms_b, int rank, int world,
                          ShardState* st, int64_t* sel_anchors, int64_t* sel_index);
+// The pairs of a finished pass that touch an overflowed environment (EnvSide::ovf_list), in list order: lchd_ctx_finish scores
+// them again with larger slots.  wave_count: kOverflowWaves words of scratch.
+constexpr int kOverflowWaves = 4096;
+struct OverflowSelect {
+    const int64_t* anchors;
+    int64_t n_pairs;
+    const uint32_t *slot_a, *slot_b;   // atom -> environment slot of the finished pass
+    const uint32_t *bits_a, *bits_b;   // bit sets over the slots (launch_mark_overflow)
+    const int32_t* wf;                 // per-pair weight-function index or null
+    unsigned long long* wave_count;
+    int64_t *sel_index, *sel_anchors;  // [n], [n][2]
+    int32_t* sel_wf;
+};
+void launch_mark_overflow(hipStream_t s, const uint32_t* list_a, uint32_t na, const uint32_t* list_b, uint32_t nb, uint32_t* bits_a, uint32_t* bits_b);
+void launch_count_overflow(hipStream_t s, const OverflowSelect& a, unsigned long long* total);
+void launch_write_overflow(hipStream_t s, const OverflowSelect& a);
 void launch_scatter_scores(hipStream_t s, const double* scores, const int64_t* index, int64_t n, double* out);
 void launch_unshard_scores(hipStream_t s, const double* gathered, const ShardCounts& counts, int world, int64_t stride, double* out,
                            int64_t n_pairs, uint32_t* bad);

@@ -83,6 +83,33 @@ __device__ __forceinline__ const LCHD_AS4 T* as_const(const T* p) {  // memory t
     return (const LCHD_AS4 T*)(unsigned long long)p;
 }
 
+// An environment that does not fit this instantiation (one lane): flagged, its size reported, its slot index appended to the side's
+// overflow list; the slot itself receives the anchor alone -- a valid one-point environment, so that the sweeps of this pass run
+// cleanly over the pairs of this anchor (the host scores those pairs again with larger slots: lchd_ctx_finish).
+// bound != 0: the anchor's candidate table overflowed before anything was counted; `bound` candidates are an upper bound of the environment.
+#ifndef LCHD_OVF_VARIANT
+#define LCHD_OVF_VARIANT 1
+#endif
+#if LCHD_OVF_VARIANT == 2
+__device__ __attribute__((noinline))
+#else
+__device__ __forceinline__
+#endif
+void env_group_overflow(const LCHD_AS4 EnvSide* p, DeviceStatus* st, int side, int e, uint32_t count, uint32_t bound, uint32_t apos32, int n_cat) {
+#if LCHD_OVF_VARIANT == 0
+    atomicOr(&st->flags, ST_ENV_OVERFLOW); atomicMax(&st->max_env, count); p->env.len[e] = 0; return;
+#endif
+    atomicOr(&st->flags, ST_ENV_OVERFLOW);
+    atomicMax(&st->max_env, count);
+    if (bound) atomicMax(&st->max_bound, bound);
+    const uint32_t k = atomicAdd(&st->n_overflow[side], 1u);
+    if (p->ovf_list) p->ovf_list[k] = (uint32_t)e;
+    const uint32_t cat = reinterpret_cast<const CellRec*>(reinterpret_cast<const char*>(p->g.rec) + apos32)->cat;
+    p->env.len[e] = 1;
+    p->env.key[(uint32_t)e << 9] = 0ull;  // distance 0 = F(0) bits for the weight functions of cdfs.rs (all start at 0)
+    p->env.cat[(uint32_t)e << 9] = (int)cat < n_cat ? (uint8_t)cat : (uint8_t)0;
+}
+
 #ifndef LCHD_GROUP_WPB
 #define LCHD_GROUP_WPB 1   // independent wavefronts per workgroup (each with its own LDS block; no workgroup barrier anywhere)
 #endif
@@ -207,11 +234,8 @@ __global__ __launch_bounds__(64 * LCHD_GROUP_WPB) __attribute__((amdgpu_waves_pe
             if (NG > kGTab) {
                 // more candidate groups than the table holds (a very dense neighbourhood): the host repeats the pass with the
                 // one-environment-per-workgroup kernel, whose capacity grows
-                if (lane == 0) {
-                    atomicOr(&st->flags, ST_ENV_OVERFLOW);
-                    atomicMax(&st->max_env, (uint32_t)(kGCap + 1));
-                    opaque(ks)->env.len[e] = 0;
-                }
+                if (lane == 0)
+                    env_group_overflow(opaque(ks), st, (unsigned long long)opaque(ks) != (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr() + 8ull ? 1 : 0, e, (uint32_t)(kGCap + 1), (uint32_t)NG * 8u, (uint32_t)__builtin_amdgcn_readlane((int)v_apos32, 32 * hh), opaque(kc)->n_categories);
                 ++j;
                 do_flush = true;
             } else if (ngrp > 0 && fill + (int)((float)(NG * 8) * seen_pts * __builtin_amdgcn_rcpf(seen_cand)) > kGCap) {
@@ -274,11 +298,7 @@ __global__ __launch_bounds__(64 * LCHD_GROUP_WPB) __attribute__((amdgpu_waves_pe
                 seen_pts += (float)(count + 8);
                 if (fill + count > kGCap) {
                     if (ngrp == 0) {  // this environment alone is too large: the host re-launches a larger variant
-                        if (lane == 0) {
-                            atomicOr(&st->flags, ST_ENV_OVERFLOW);
-                            atomicMax(&st->max_env, (uint32_t)count);
-                            opaque(ks)->env.len[e] = 0;
-                        }
+                        if (lane == 0) env_group_overflow(opaque(ks), st, (unsigned long long)opaque(ks) != (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr() + 8ull ? 1 : 0, e, (uint32_t)count, 0u, apos32, opaque(kc)->n_categories);
                         ++j;
                     } else {
                         do_flush = true;  // close the group; the anchor is searched again into the empty buffer

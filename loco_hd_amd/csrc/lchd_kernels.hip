@@ -849,11 +849,19 @@ const DevConfig* __restrict__ cfgp, EnvSides sides, double thr, int cap, DeviceS
         count = count_s;
     }
     ESTAMP(1);
-    if (count > cap) {  // the host re-launches a larger variant
+    if (count > cap) {
+        // The environment does not fit its slot: flagged, its size reported, its slot index appended to the side's overflow list.  The
+        // slot receives the anchor alone -- a valid one-point environment, so the sweeps of this pass run cleanly over the pairs of
+        // this anchor; the host scores those pairs again with larger slots (lchd_ctx_finish).
         if (tid == 0) {
             atomicOr(&st->flags, ST_ENV_OVERFLOW);
             atomicMax(&st->max_env, (uint32_t)count);
-            env.len[e] = 0;
+            const uint32_t k = atomicAdd(&st->n_overflow[side], 1u);
+            if (S.ovf_list) S.ovf_list[k] = (uint32_t)e;
+            const uint32_t acat = g.rec[arec.apos].cat;
+            env.len[e] = 1;
+            env.key[e * env.stride] = 0ull;
+            reinterpret_cast<VT*>(env.cat)[e * env.stride] = (int)acat < cfg.n_categories ? (VT)acat : (VT)0;
         }
         return;
     }
@@ -1988,9 +1996,15 @@ __device__ __forceinline__ void publish_status(const SweepArgs& args, unsigned l
     h->n_unique[0] = st->n_unique[0];
     h->n_unique[1] = st->n_unique[1];
     h->n_small = n_small;
+    h->n_overflow[0] = st->n_overflow[0];
+    h->n_overflow[1] = st->n_overflow[1];
+    h->max_bound = __hip_atomic_load(&st->max_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     h->snapshot_seq = args.seq;
     st->flags = 0u;
     st->max_env = 0u;
+    st->n_overflow[0] = 0u;
+    st->n_overflow[1] = 0u;
+    st->max_bound = 0u;
 }
 
 
@@ -4235,6 +4249,87 @@ void launch_shard_select(hipStream_t s, const int64_t* anchors, int64_t n_pairs,
     k_shard_select<<<(unsigned)(nb < 1024 ? (nb > 0 ? nb : 1) : 1024), 256, 0, s>>>(anchors, n_pairs, n_atoms_a, n_atoms_b, rank, world, st, sel_anchors,
                                                                                     sel_index);
 }
+// ---- the pairs of a finished pass that touch an overflowed environment (EnvSide::ovf_list) ----------------------------------
+// k_mark_overflow: overflow lists -> bit sets over the sides' slots (zeroed by the host).  k_select_overflow<false>: every
+// wavefront counts the marked pairs of its contiguous share of the list; k_scan_overflow: exclusive scan of the (at most
+// kOverflowWaves) counts; k_select_overflow<true>: the same walk again, now writing pair index, anchor pair and weight-function
+// index in list order (ordered compaction: the second pass sees the pairs in the caller's order).
+__global__ void k_mark_overflow(const uint32_t* __restrict__ list_a, uint32_t na, const uint32_t* __restrict__ list_b, uint32_t nb,
+                                uint32_t* bits_a, uint32_t* bits_b) {
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < na + nb; k += gridDim.x * blockDim.x) {
+        const uint32_t e = k < na ? list_a[k] : list_b[k - na];
+        atomicOr(&(k < na ? bits_a : bits_b)[e >> 5], 1u << (e & 31));
+    }
+}
+template <bool WRITE>
+__global__ __launch_bounds__(64) void k_select_overflow(OverflowSelect a) {
+    const int lane = threadIdx.x;
+    const int64_t share = (a.n_pairs + gridDim.x - 1) / gridDim.x;
+    const int64_t p0 = (int64_t)blockIdx.x * share, p1 = p0 + share < a.n_pairs ? p0 + share : a.n_pairs;
+    unsigned long long at = WRITE ? a.wave_count[blockIdx.x] : 0ull;  // (after the scan: the share's first position in the selection)
+    for (int64_t q = p0; q < p1; q += 64) {
+        const int64_t p = q + lane;
+        bool big = false;
+        int64_t ia = 0, ib = 0;
+        if (p < p1) {
+            ia = a.anchors[2 * p];
+            ib = a.anchors[2 * p + 1];
+            const uint32_t sa = a.slot_a[ia], sb = a.slot_b[ib];
+            big = ((a.bits_a[sa >> 5] >> (sa & 31)) & 1u) | ((a.bits_b[sb >> 5] >> (sb & 31)) & 1u);
+        }
+        const unsigned long long m = __ballot(big);
+        if constexpr (WRITE) {
+            if (big) {
+                const unsigned long long k = at + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+                a.sel_index[k] = p;
+                a.sel_anchors[2 * k] = ia;
+                a.sel_anchors[2 * k + 1] = ib;
+                if (a.wf) a.sel_wf[k] = a.wf[p];
+            }
+        }
+        at += (unsigned long long)__popcll(m);
+    }
+    if constexpr (!WRITE)
+        if (lane == 0) a.wave_count[blockIdx.x] = at;
+}
+__global__ __launch_bounds__(1024) void k_scan_overflow(unsigned long long* wave_count, int n, unsigned long long* total) {
+    __shared__ unsigned long long part[1024];
+    const int tid = threadIdx.x;
+    constexpr int PER = kOverflowWaves / 1024;
+    unsigned long long v[PER], sum = 0;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) { v[u] = tid * PER + u < n ? wave_count[tid * PER + u] : 0ull; sum += v[u]; }
+    part[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const unsigned long long add = tid >= d ? part[tid - d] : 0ull;
+        __syncthreads();
+        part[tid] += add;
+        __syncthreads();
+    }
+    unsigned long long pre = part[tid] - sum;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) { if (tid * PER + u < n) wave_count[tid * PER + u] = pre; pre += v[u]; }
+    if (tid == 1023) *total = part[1023];
+}
+void launch_mark_overflow(hipStream_t s, const uint32_t* list_a, uint32_t na, const uint32_t* list_b, uint32_t nb, uint32_t* bits_a, uint32_t* bits_b) {
+    if (na + nb == 0) return;
+    const uint32_t nbk = (na + nb + 255) / 256;
+    k_mark_overflow<<<nbk < 1024 ? nbk : 1024, 256, 0, s>>>(list_a, na, list_b, nb, bits_a, bits_b);
+}
+int overflow_select_waves(int64_t n_pairs) {
+    const int64_t w = (n_pairs + 255) / 256;
+    return (int)(w < kOverflowWaves ? (w > 0 ? w : 1) : kOverflowWaves);
+}
+void launch_count_overflow(hipStream_t s, const OverflowSelect& a, unsigned long long* total) {
+    const int w = overflow_select_waves(a.n_pairs);
+    k_select_overflow<false><<<w, 64, 0, s>>>(a);
+    k_scan_overflow<<<1, 1024, 0, s>>>(a.wave_count, w, total);
+}
+void launch_write_overflow(hipStream_t s, const OverflowSelect& a) {
+    k_select_overflow<true><<<overflow_select_waves(a.n_pairs), 64, 0, s>>>(a);
+}
+
 // one share's scores back to their positions in the caller's order (out: any device-visible memory, e.g. a host-mapped block)
 __global__ void k_scatter_scores(const double* __restrict__ scores, const int64_t* __restrict__ index, int64_t n, double* __restrict__ out) {
     for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) out[index[k]] = scores[k];

@@ -50,6 +50,13 @@ class DeviceSession:
         """True if the most recent from_coords call ran the fused sort + sweep kernel (lchd_ctx_last_dense_fused)."""
         return bool(N.lib().lchd_ctx_last_dense_fused(self._ctx))
 
+    def pass_counts(self) -> dict:
+        """Passes the context has run: all of them, and the second passes over the pairs of overflowed environments
+        (lchd_ctx_pass_count, lchd_ctx_subset_pass_count); store_bytes: environment-store bytes of the last call's passes."""
+        lib = N.lib()
+        return {"passes": int(lib.lchd_ctx_pass_count(self._ctx)), "subset_passes": int(lib.lchd_ctx_subset_pass_count(self._ctx)),
+                "store_bytes": int(lib.lchd_ctx_last_store_bytes(self._ctx))}
+
     def upload(self, xyz: np.ndarray, cat: np.ndarray, tag: Optional[np.ndarray] = None):
         """Put one structure (xyz [n][3] f64, category ids, interned tags) into HBM; returns an opaque handle."""
         xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)

@@ -242,3 +242,98 @@ def test_small_calls_are_one_pass_in_the_steady_state(lh):
         first = np.asarray(lchd.from_packed(pa, pb, an, 10.0))
         assert N.lib().lchd_ctx_pass_count(ctx) - before == 1
         assert np.array_equal(first, np.asarray(lchd.from_packed(pa, pb, an, 10.0)))
+
+
+def _cluster_in_sparse_cloud(seed, n_sparse, n_cluster, n_cat):
+    """A sparse cloud (environments of ~10 points at 10 A) with ONE dense cluster (every cluster point sees the whole cluster)."""
+    rng = np.random.default_rng(seed)
+    side = (n_sparse / 0.0025) ** (1 / 3)
+    xyz = rng.uniform(0.0, side, (n_sparse + n_cluster, 3))
+    centre = xyz[0] + 40.0
+    v = rng.normal(0.0, 1.0, (n_cluster, 3))
+    xyz[n_sparse:] = centre + v / np.linalg.norm(v, axis=1)[:, None] * (4.5 * rng.uniform(0.0, 1.0, (n_cluster, 1)) ** (1 / 3))
+    cat = rng.integers(0, n_cat, len(xyz)).astype(np.int32)
+    tag = rng.integers(0, 50, len(xyz)).astype(np.int32)
+    return xyz, cat, tag
+
+
+@pytest.mark.parametrize("variant", ["two_structures", "same_object", "weight_function_dictionary", "tag_rule", "one_environment_per_workgroup"])
+def test_a_dense_cluster_in_a_sparse_cloud_rescoring_only_its_pairs(lh, oracle, variant, monkeypatch):
+    """Environments have no capacity in the reference (src/locohd.rs:514-542: a Vec per anchor, utils.rs:25-39 sorts whatever
+    it holds); here they live in fixed-stride slots of 512 points.  One 3 000-point cluster inside a sparse 60 000-point cloud: the
+    cluster's anchors overflow their slots, and ONLY the pairs that touch them are scored again (a second pass with 4 096-point slots
+    for that handful of anchors) -- not the whole call with 4 096-point slots for every environment.  Scores against the oracle,
+    against the whole-pass retry (LCHD_NO_OVERFLOW_SUBSET), pass counts and store bytes."""
+    import torch
+    from loco_hd_amd.device import DeviceSession
+
+    n_sparse, n_cluster, n_cat = 60_000, 3_000, 7
+    xa, ca, ta = _cluster_in_sparse_cloud(1, n_sparse, n_cluster, n_cat)
+    xb, cb, tb = _cluster_in_sparse_cloud(2, n_sparse, n_cluster, n_cat)
+    rng = np.random.default_rng(3)
+    n_pairs = 6000
+    pairs = np.stack([rng.integers(0, n_sparse, n_pairs), rng.integers(0, n_sparse, n_pairs)], 1).astype(np.int64)
+    big = rng.choice(n_pairs, 90, replace=False)
+    pairs[big[:30], 0] = n_sparse + rng.integers(0, n_cluster, 30)       # cluster anchor on side A
+    pairs[big[30:60], 1] = n_sparse + rng.integers(0, n_cluster, 30)     # ... on side B
+    pairs[big[60:], 0] = n_sparse + rng.integers(0, n_cluster, 30)       # ... on both
+    pairs[big[60:], 1] = n_sparse + rng.integers(0, n_cluster, 30)
+    cats = [f"c{i}" for i in range(n_cat)]
+    kw, wf_idx = {}, None
+    if variant == "same_object":
+        xb, cb, tb = xa, ca, ta
+    if variant == "tag_rule":
+        kw["tag_pairing_rule"] = {"accept_same": False}  # (points carrying the anchor's tag -- 1 in 50 -- are left out)
+    else:
+        ta, tb = np.zeros_like(ta), np.zeros_like(tb)     # (the default rule keeps the points that carry the anchor's tag)
+
+    def build(mod):
+        wf = mod.WeightFunction("uniform", [3.0, 10.0])
+        if variant == "weight_function_dictionary":
+            wf = {"u": wf, "h": mod.WeightFunction("hyper_exp", [1.0, 0.2])}
+        rule = mod.TagPairingRule(kw["tag_pairing_rule"]) if "tag_pairing_rule" in kw else None
+        return mod.LoCoHD(cats, wf, rule)
+
+    if variant == "weight_function_dictionary":
+        wf_idx = (np.arange(n_pairs) % 2).astype(np.int32)
+    lo = build(oracle)
+    owfs = None
+    if wf_idx is not None:
+        owfs = lo._wfs(["u" if k == 0 else "h" for k in wf_idx], n_pairs)
+    want = np.asarray(lo.from_arrays(xa, ca, ta, xb, cb, tb, pairs, 10.0, *(owfs if owfs else ())))
+
+    def run(no_subset):
+        if variant == "one_environment_per_workgroup":
+            monkeypatch.setenv("LCHD_NO_ENV_GROUP", "1")  # (k_env_cells keeps the overflow list too)
+        if no_subset:
+            monkeypatch.setenv("LCHD_NO_OVERFLOW_SUBSET", "1")
+        else:
+            monkeypatch.delenv("LCHD_NO_OVERFLOW_SUBSET", raising=False)
+        sess = DeviceSession(build(lh))
+        a = sess.upload(xa, ca, ta)
+        b = a if variant == "same_object" else sess.upload(xb, cb, tb)
+        anchors = torch.from_numpy(pairs).cuda()
+        wfi = None if wf_idx is None else torch.from_numpy(wf_idx).cuda()
+        outs, counts = [], []
+        for _ in range(2):
+            before = sess.pass_counts()
+            outs.append(sess.from_primitives(a, b, anchors, 10.0, wf_index=wfi).cpu().numpy())
+            after = sess.pass_counts()
+            counts.append({k: after[k] - before[k] if k != "store_bytes" else after[k] for k in after})
+        sess.close()
+        return outs, counts
+
+    outs, counts = run(False)
+    assert np.max(np.abs(outs[0] - want)) < 1e-11
+    assert np.array_equal(outs[0], outs[1])
+    for cnt in counts:  # every call: the first pass + ONE second pass over the cluster's pairs
+        assert cnt["subset_passes"] == 1 and cnt["passes"] == 2
+    whole, wcounts = run(True)
+    assert np.max(np.abs(whole[0] - want)) < 1e-11
+    assert np.max(np.abs(whole[0] - outs[0])) < 1e-11
+    assert wcounts[0]["subset_passes"] == 0
+    # the whole-pass retry gives EVERY environment of the call a 4 096-point slot; re-scoring the cluster's pairs adds the slots of
+    # ~180 anchors to the first pass's store
+    first_pass_store = 2 * n_pairs * 512 * 9  # (slots for min(atoms, pairs) anchors per side; one side with twice as many when the sides are one object)
+    assert counts[0]["store_bytes"] <= 1.3 * first_pass_store
+    assert wcounts[0]["store_bytes"] >= 6 * counts[0]["store_bytes"]
