@@ -167,6 +167,7 @@ struct lchd_ctx {
     // configuration
     bool cfg_set = false;
     bool hellinger2 = false, unit_weights = false, wf_pow = false;  // which sweep kernel variant applies
+    bool finf_differ = false;  // the weight functions of a dictionary do not share F(+inf) (degenerate parameters): no key sets
     int sd_fast = 0;  // Kullback-Leibler (1) / Renyi (2) with parameters the O(1)-per-event sweep handles (lchd_sweep_inc.hip)
     DevConfig h_cfg{};
     DevConfig* d_cfg = nullptr;
@@ -278,6 +279,7 @@ static Tuning tuning_from_env() {  // the ONLY place that reads LCHD_* hooks (te
     t.no_small_dedupe = getenv("LCHD_NO_SMALL_DEDUPE") != nullptr;
     t.no_share = getenv("LCHD_NO_SHARED_ENVS") != nullptr;
     t.no_cdf_keys = getenv("LCHD_NO_CDF_KEYS") != nullptr;
+    t.no_key_sets = getenv("LCHD_NO_KEY_SETS") != nullptr;
     t.no_duo = getenv("LCHD_NO_DUO") != nullptr;
     t.force_wide = env_int("LCHD_FORCE_WIDE", 0) != 0;
     t.force_generic = env_int("LCHD_FORCE_GENERIC", 0) != 0;
@@ -452,6 +454,7 @@ extern "C" int lchd_ctx_set_config(lchd_ctx* c, const lchd_config* cfg) {
     const size_t o_t = o_i + sizeof(double) * cfg->n_weight_functions;
     const size_t total = o_t + sizeof(uint64_t) * (size_t)cfg->n_tag_pairs;
     std::vector<char> blob(total + 8);
+    c->finf_differ = false;
     memcpy(blob.data() + o_w, cfg->category_weights, sizeof(double) * C);
     WfEntry* ent = reinterpret_cast<WfEntry*>(blob.data() + o_e);
     double* prm = reinterpret_cast<double*>(blob.data() + o_p);
@@ -463,6 +466,7 @@ extern "C" int lchd_ctx_set_config(lchd_ctx* c, const lchd_config* cfg) {
         ent[i] = WfEntry{w.kind, w.n_params, off, 0};
         memcpy(prm + off, w.params, sizeof(double) * w.n_params);
         finf[i] = cdf_eval(w.kind, w.params, w.n_params, (double)INFINITY);
+        if (i > 0 && !(finf[i] == finf[0])) c->finf_differ = true;  // (set to false above)
         // hyper_exp divides by sum_i a_i, uniform / kumaraswamy by (x_max - x_min) (cdfs.rs:15-20,44,61): constants of the
         // weight function, so the kernels multiply by the reciprocal (<= 1 ulp from the quotient) instead of dividing per point
         winv[i] = 1.0;
@@ -840,7 +844,7 @@ struct PassBufs {
     size_t zero_bytes;
 };
 static void carve_pass(Arena& ar, int64_t n_a, int cells_a, int64_t envs_a, int64_t n_b, int cells_b, int64_t envs_b, int cap, int64_t n_pairs,
-                       PassBufs& pb, bool cat16 = false) {
+                       PassBufs& pb, bool cat16 = false, int key_sets = 1) {
     const size_t ma = (size_t)std::max<int64_t>(n_a, 1), mb = (size_t)std::max<int64_t>(n_b, 1);
     ar.off = (ar.off + 255) & ~size_t(255);
     const size_t z0 = ar.off;
@@ -865,7 +869,8 @@ static void carve_pass(Arena& ar, int64_t n_a, int cells_a, int64_t envs_a, int6
         b.pos_of = ar.take<uint32_t>(m);
         b.uniq = ar.take<AnchorRec>(ne);
         b.scan_tmp = ar.take<uint32_t>(std::max<size_t>(m, (size_t)n_cells) / 4096 + 4);
-        b.env.key = ar.take<uint64_t>(ne * (size_t)cap);
+        b.env.key = ar.take<uint64_t>(ne * (size_t)cap * (size_t)std::max(key_sets, 1));
+        b.env.set_stride = (int64_t)(ne * (size_t)cap);
         b.env.cat = ar.take<uint8_t>(ne * (size_t)cap * (cat16 ? 2 : 1));
         b.env.len = ar.take<int32_t>(ne);
         b.env.stride = cap;
@@ -932,16 +937,23 @@ static int prims_enqueue(lchd_ctx* c) {
     P.group = group;
     P.group_small = false;
     const GridPlan ga = plan_grid(a, thr, group ? 2 : 1), gb = plan_grid(b, thr, group ? 2 : 1);
+    // Keys of the store: F(distance) whenever the sweep can use them without evaluating a CDF -- one weight function, or a
+    // dictionary of up to kMaxKeySets (src/locohd.rs:230-283: every pair names its function): k_env_group writes one key set per
+    // function (the sort is shared, the store's key part grows k-fold) and a pair reads the set of its function.
+    const int n_wf = c->h_cfg.n_wf;
+    // (dictionary: set 0 keeps the distances k_env_group writes, k_env_key_sets fills sets 1 .. n_wf; the sweeps' view starts at set 1)
+    const bool dict_sets = n_wf > 1 && group && n_wf <= kMaxKeySets && P.wf && !c->tune.no_key_sets && !c->tune.no_cdf_keys && !c->finf_differ;
+    const int key_sets = c->tune.no_cdf_keys ? 0 : (n_wf == 1 ? 1 : (dict_sets ? n_wf + 1 : 0));
     PassBufs pb{};
     {
         Arena dry(nullptr, 0, true);
-        carve_pass(dry, a->n, ga.n_cells, max_env_a, b->n, gb.n_cells, max_env_b, cap, n_pairs, pb, cat16);
+        carve_pass(dry, a->n, ga.n_cells, max_env_a, b->n, gb.n_cells, max_env_b, cap, n_pairs, pb, cat16, key_sets);
         if (int rc = ensure_ws(c, dry.off + 4096)) return rc;
     }
     Arena ar(c->ws, c->ws_cap, false);
-    carve_pass(ar, a->n, ga.n_cells, max_env_a, b->n, gb.n_cells, max_env_b, cap, n_pairs, pb, cat16);
+    carve_pass(ar, a->n, ga.n_cells, max_env_a, b->n, gb.n_cells, max_env_b, cap, n_pairs, pb, cat16, key_sets);
     SideBufs &sa = pb.a, &sb = pb.b;
-    sa.env.cdf_keys = sb.env.cdf_keys = (c->h_cfg.n_wf == 1 && !c->tune.no_cdf_keys) ? 1 : 0;
+    sa.env.cdf_keys = sb.env.cdf_keys = dict_sets ? 0 : key_sets;  // (what the environment kernels write into set 0)
 
     auto grid_view = [](const GridPlan& g, const SideBufs& s) {
         GridView v{};
@@ -980,7 +992,7 @@ static int prims_enqueue(lchd_ctx* c) {
     P.ovf_b = sb.ovf_list;
     P.n_slots_a = max_env_a;
     P.n_slots_b = max_env_b;
-    c->last_store_bytes += (size_t)(std::max<int64_t>(max_env_a, 1) + std::max<int64_t>(max_env_b, 1)) * (size_t)cap * (cat16 ? 10 : 9);
+    c->last_store_bytes += (size_t)(std::max<int64_t>(max_env_a, 1) + std::max<int64_t>(max_env_b, 1)) * (size_t)cap * ((cat16 ? 2 : 1) + 8 * (size_t)std::max(key_sets, 1));
     if (group) {
         // anchors per wavefront: as many as fit ONE group of the kernel's LDS buffer (measured, env phase in ms for 1 / 2 / 4 / 8 /
         // 16 anchors: C4, ~96-point environments 3.87 / 2.88 / 2.68 / 2.69 / 2.96; C5, ~200 points 0.81 / 0.75 / 0.75 / 0.78 / 0.81 --
@@ -996,6 +1008,13 @@ static int prims_enqueue(lchd_ctx* c) {
     } else if (!launch_env_cells(s, cap, c->d_cfg, tag_list, esa, esb, thr, c->d_status))
         return fail(LCHD_EUNSUPPORTED, cat16 ? "with more than 255 categories an environment may hold at most 8192 points (capacity %d asked for)"
                                              : "no environment kernel variant with capacity %d", cap);
+    if (dict_sets) {
+        launch_env_key_sets(s, c->d_cfg, sa.env, sb.env, n_wf, max_env_a + max_env_b, c->d_status);
+        for (SideBufs* sb_ : {&sa, &sb}) {  // the sweeps' view of the store: the F sets
+            sb_->env.key += sb_->env.set_stride;
+            sb_->env.cdf_keys = n_wf;
+        }
+    }
     mark(c, 3);
     SweepArgs sw{};
     fill_sweep_args(c, sw);

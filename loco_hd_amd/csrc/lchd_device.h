@@ -65,6 +65,7 @@ struct Tuning {
     bool no_struct_cells = false;   // LCHD_NO_STRUCT_CELLS: always the generic (multi-pass, global atomics) cell list
     bool no_small_dedupe = false;   // LCHD_NO_SMALL_DEDUPE: never the fused one-workgroup-per-side prologue
     bool no_share = false;          // LCHD_NO_SHARED_ENVS: build both sides even when they are the same device object
+    bool no_key_sets = false;       // LCHD_NO_KEY_SETS: weight-function dictionaries keep distance keys (the CDF is evaluated by the sweep, per event)
     bool no_cdf_keys = false;       // LCHD_NO_CDF_KEYS: environments keep distance keys even with a single weight function
     bool no_duo = false;            // LCHD_NO_DUO: never two pairs per wavefront
     bool force_wide = false;        // LCHD_FORCE_WIDE: k_sweep_wide for any category count
@@ -157,9 +158,12 @@ struct EnvStore {
     uint8_t* cat;
     int32_t* len;
     int64_t stride;
-    int32_t cdf_keys;  // 1: key = bits of F(distance) for the configuration's single weight function (sweep needs no CDF evaluation)
+    int32_t cdf_keys;  // k >= 1: the store holds k SETS of keys, set w = bits of F_w(distance) for weight function w of the configuration (the
+                       // sweep needs no CDF evaluation: a pair reads the set of its weight function); 0: keys are the distances
     int32_t cat16;     // 1: `cat` holds 16-bit category ids (more than 255 categories): two bytes per point
+    int64_t set_stride;  // elements between two key sets (slots x stride); categories and lengths exist once
 };
+constexpr int kMaxKeySets = 4;  // weight-function dictionaries of up to 4 entries get one key set each (k_env_group); larger ones keep distance keys
 
 // One structure (or batch of structures) of a from_primitives pass as the prologue sees it: the inputs, and the arrays the
 // prologue fills (cell list, anchor slots, anchor records).
@@ -359,6 +363,7 @@ struct OverflowSelect {
     int64_t *sel_index, *sel_anchors;  // [n], [n][2]
     int32_t* sel_wf;
 };
+void launch_env_key_sets(hipStream_t s, const DevConfig* cfg, const EnvStore& ea, const EnvStore& eb, int n_sets, int64_t max_envs, const DeviceStatus* st);
 void launch_mark_overflow(hipStream_t s, const uint32_t* list_a, uint32_t na, const uint32_t* list_b, uint32_t nb, uint32_t* bits_a, uint32_t* bits_b);
 void launch_count_overflow(hipStream_t s, const OverflowSelect& a, unsigned long long* total);
 void launch_write_overflow(hipStream_t s, const OverflowSelect& a);

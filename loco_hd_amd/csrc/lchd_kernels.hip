@@ -2476,8 +2476,11 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? (CMAX <= LCHD
         }
         const int64_t ea = mx, eb = my;
         const int c0a = (mz >> 24) & 255, c0b = (mw >> 24) & 255;  // categories of the two anchors
-        const uint64_t* __restrict__ kA = args.env_a.key + ea * args.env_a.stride;
-        const uint64_t* __restrict__ kB = args.env_b.key + eb * args.env_b.stride;
+        // (a dictionary's key sets, EnvStore::cdf_keys > 1: the set of this pair's weight function)
+        const int kset = (FMODE == F_KEY && args.wf_index) ? args.wf_index[p] : 0;
+        const int64_t kset_ok = (kset >= 0 && kset < n_wf) ? kset : 0;
+        const uint64_t* __restrict__ kA = args.env_a.key + ea * args.env_a.stride + kset_ok * args.env_a.set_stride;
+        const uint64_t* __restrict__ kB = args.env_b.key + eb * args.env_b.stride + kset_ok * args.env_b.set_stride;
         const uint8_t* __restrict__ tA = args.env_a.cat + ea * args.env_a.stride;
         const uint8_t* __restrict__ tB = args.env_b.cat + eb * args.env_b.stride;
         const int wfi = args.wf_index ? args.wf_index[p] : 0;
@@ -3051,8 +3054,14 @@ __device__ __forceinline__ double team_sum_f64(double v) {  // the last lane of 
 // KSM: the Kolmogorov-Smirnov distance max_c |a_c / N_a - b_c / N_b| (statistical_distances.rs:12-21) with unit weights instead of
 // Hellinger-2: every event needs all categories, but as INTEGERS -- max_c |a_c N_b - b_c N_a| over the 8-bit count fields (two 24-bit
 // multiplies, one v_sad_u32, one max per category), scaled once by 1 / (N_a N_b) from the reciprocal-root table; no square root.
+#ifndef LCHD_WGT_LDSCNT
+#define LCHD_WGT_LDSCNT 1   // 1: the weighted instantiations with 9 .. 16 slots keep their per-lane counts in LDS bytes too
+#endif
+#ifndef LCHD_WGT_W3
+#define LCHD_WGT_W3 0       // 1: ... are compiled for 3 waves per SIMD (170 registers: no spills)
+#endif
 template <int CMAX, int TL = LCHD_DUO_TL, int TILE_ = kDuoTile, bool WGT = false, bool KSM = false>
-__global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_WAVES)) void k_sweep_duo(SweepArgs args) {
+__global__ __launch_bounds__(64 * kSweepWaves, ((CMAX <= 16 && !(WGT && CMAX > 8 && (LCHD_WGT_LDSCNT || LCHD_WGT_W3))) ? 4 : LCHD_TEAM_BIG_WAVES)) void k_sweep_duo(SweepArgs args) {
     static_assert(!KSM || (!WGT && CMAX <= 16), "the Kolmogorov-Smirnov form: unit weights, one or two count words per side");
     static_assert(TL == 16 || TL == 32, "a team is one or two DPP rows");
     constexpr int TEAMS = 64 / TL, EPL = TILE_ / TL, TILE = TILE_, WPB = kSweepWaves;
@@ -3080,7 +3089,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_W
     // write replace the word-select chains over the count words and the 4-bit chunk fields (C5, 28 slots: 25 of the event's 88
     // vector instructions were v_cndmask_b32_e64).  The rows cost (2 CMAX / 8) x 512 bytes per wavefront: three workgroups per CU
     // -- what these instantiations are compiled for -- still fit up to 28 slots; with 32 they would not (registers there).
-    constexpr bool LCNT = (CMAX > 16) && (CMAX <= 28) && (LCHD_TEAM_LDSCNT != 0);
+    constexpr bool LCNT = (((CMAX > 16) && (CMAX <= 28)) || (WGT && (LCHD_WGT_LDSCNT != 0) && CMAX > 8 && CMAX <= 16)) && (LCHD_TEAM_LDSCNT != 0);
     constexpr int LW = LCNT ? (2 * CMAX + 7) / 8 : 1;
     __shared__ uint64_t lc_[LCNT ? WPB : 1][LCNT ? LW * 64 : 1];
     __shared__ double w_s[WGT ? 32 : 1];
@@ -3112,8 +3121,11 @@ __global__ __launch_bounds__(64 * kSweepWaves, (CMAX <= 16 ? 4 : LCHD_TEAM_BIG_W
         const bool valid = usable && mine;
         const int mA = valid ? (m.z & 0xFFFFFF) - 1 : 0, mB = valid ? (m.w & 0xFFFFFF) - 1 : 0, T = mA + mB;  // non-anchor events
         const int c0a = (m.z >> 24) & 255, c0b = (m.w >> 24) & 255;
-        const uint64_t* __restrict__ kA = args.env_a.key + (int64_t)m.x * args.env_a.stride;
-        const uint64_t* __restrict__ kB = args.env_b.key + (int64_t)m.y * args.env_b.stride;
+        // (a dictionary's key sets: the set of this pair's weight function -- k_pair_meta has checked the index of every usable pair)
+        int64_t kset = 0;
+        if (args.wf_index) kset = valid ? args.wf_index[p] : 0;
+        const uint64_t* __restrict__ kA = args.env_a.key + (int64_t)m.x * args.env_a.stride + kset * args.env_a.set_stride;
+        const uint64_t* __restrict__ kB = args.env_b.key + (int64_t)m.y * args.env_b.stride + kset * args.env_b.set_stride;
         const uint8_t* __restrict__ tA = args.env_a.cat + (int64_t)m.x * args.env_a.stride;
         const uint8_t* __restrict__ tB = args.env_b.cat + (int64_t)m.y * args.env_b.stride;
         const double F0 = valid ? u2d(kA[0]) : 0.0;            // F(0): both anchors sit at distance 0
@@ -3541,8 +3553,11 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
         }
         const int64_t ea = mx, eb = my;
         const int c0a = CAT16 ? ((mz >> 16) & 0xFFFF) : ((mz >> 24) & 255), c0b = CAT16 ? ((mw >> 16) & 0xFFFF) : ((mw >> 24) & 255);  // categories of the two anchors
-        const uint64_t* __restrict__ kA = args.env_a.key + ea * args.env_a.stride;
-        const uint64_t* __restrict__ kB = args.env_b.key + eb * args.env_b.stride;
+        // (a dictionary's key sets, EnvStore::cdf_keys > 1: the set of this pair's weight function)
+        const int kset = (FMODE == F_KEY && args.wf_index) ? args.wf_index[p] : 0;
+        const int64_t kset_ok = (kset >= 0 && kset < n_wf) ? kset : 0;
+        const uint64_t* __restrict__ kA = args.env_a.key + ea * args.env_a.stride + kset_ok * args.env_a.set_stride;
+        const uint64_t* __restrict__ kB = args.env_b.key + eb * args.env_b.stride + kset_ok * args.env_b.set_stride;
         const CT* __restrict__ tA = reinterpret_cast<const CT*>(args.env_a.cat) + ea * args.env_a.stride;
         const CT* __restrict__ tB = reinterpret_cast<const CT*>(args.env_b.cat) + eb * args.env_b.stride;
         const int wfi = args.wf_index ? args.wf_index[p] : 0;
@@ -3806,6 +3821,12 @@ __global__ void k_pair_meta(SweepArgs args) {
             ok = !(ia_ < 0 || ib_ < 0 || ia_ >= args.n_slot_a || ib_ >= args.n_slot_b);
             if (ok) { ea = args.slot_a[ia_]; eb = args.slot_b[ib_]; }
         }
+        if (args.wf_index && args.env_a.cdf_keys > 1) {
+            // key sets: the pair's weight-function index picks the set its sweep reads -- an index outside the dictionary is reported
+            // here and the pair marked unusable (the sweep answers NaN)
+            const int wfi = args.wf_index[p];
+            if (wfi < 0 || wfi >= args.env_a.cdf_keys) { ok = false; atomicOr(&args.st->flags, ST_BAD_WF); }
+        }
         int nA = 0, nB = 0, c0a = 0, c0b = 0;
         if (ok) {
             nA = args.env_a.len[ea];
@@ -3920,7 +3941,7 @@ int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinge
     // ... and for the Kolmogorov-Smirnov distance with unit weights (SweepArgs::sd_fast == 3: the KSM instantiations)
     const bool ks_team = !hellinger2 && a.sd_fast == 3 && unit_weights && cmax <= 16 && !t.no_duo && !t.no_c8_team && !t.no_count8 && !t.force_generic &&
                          (t.c8_team_max == 0 || t.c8_team_max >= cmax);
-    const bool fast_cfg = !wide && ((hellinger2 && (unit_weights || weighted_team)) || ks_team) && small && fmode == F_KEY && !a.wf_index;
+    const bool fast_cfg = !wide && ((hellinger2 && (unit_weights || weighted_team)) || ks_team) && small && fmode == F_KEY;  // (F_KEY with a weight-function dictionary: the store holds one key set per function)
     // sweep_hint (what k_pair_meta counted in the previous pass of this configuration): 0 = nothing known, else
     // 4 | (pairs of <= 240 events were the majority ? 1 : 0) | (pairs with both environments <= 255 points were ? 2 : 0).
     // Up to 16 slots k_sweep_duo is the first choice and the 8-bit-count sweep the second (C2a: environments of ~170 points,
@@ -4249,6 +4270,48 @@ void launch_shard_select(hipStream_t s, const int64_t* anchors, int64_t n_pairs,
     k_shard_select<<<(unsigned)(nb < 1024 ? (nb > 0 ? nb : 1) : 1024), 256, 0, s>>>(anchors, n_pairs, n_atoms_a, n_atoms_b, rank, world, st, sel_anchors,
                                                                                     sel_index);
 }
+// ---- weight-function dictionaries: one set of F keys per function ------------------------------------------------------------
+// The grouped environment kernel left DISTANCE keys in set 0 of the store (EnvStore::set_stride elements per set); one wavefront per
+// environment writes F_w(distance) into set 1 + w for every function w of the dictionary (src/locohd.rs:230-283: each pair names its
+// function; the sweep then reads the set of the pair's function and never evaluates a CDF).  A running maximum keeps every set sorted
+// whatever the last bits of the floating-point CDF do (keys_to_cdf_lds does the same; equal F values are zero-width intervals).
+__global__ __launch_bounds__(256) void k_env_key_sets(const DevConfig* __restrict__ cfgp, EnvStore ea, EnvStore eb, int n_sets, const DeviceStatus* st) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t nu_a = st->n_unique[0], nu_b = st->n_unique[1];
+    for (int64_t e = (int64_t)blockIdx.x * 4 + wave; e < nu_a + nu_b; e += (int64_t)gridDim.x * 4) {
+        const bool on_b = e >= nu_a;
+        const int64_t slot = on_b ? e - nu_a : e;
+        uint64_t* const base = on_b ? eb.key : ea.key;
+        const int64_t stride = on_b ? eb.stride : ea.stride, set_stride = on_b ? eb.set_stride : ea.set_stride;
+        const int n = (on_b ? eb.len : ea.len)[slot];
+        const uint64_t* __restrict__ src = base + slot * stride;
+        for (int w = 0; w < n_sets; ++w) {
+            const WfEntry wf = cfgp->wf[w];
+            const double* __restrict__ prm = cfgp->wf_params + wf.offset;
+            const double winv = cfgp->wf_inv[w];
+            uint64_t* __restrict__ dst = base + (int64_t)(1 + w) * set_stride + slot * stride;
+            uint64_t carry = 0;
+            for (int i0 = 0; i0 < n; i0 += 64) {
+                const int i = i0 + lane;
+                uint64_t f = i < n ? d2u(cdf_lean(wf.kind, prm, wf.n_params, winv, u2d(src[i])) + 0.0) : 0ull;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint64_t t = shfl_up_u64(f, d);
+                    if (lane >= d) f = t > f ? t : f;
+                }
+                f = carry > f ? carry : f;
+                if (i < n) dst[i] = f;
+                carry = shfl_u64(f, 63);
+            }
+        }
+    }
+}
+void launch_env_key_sets(hipStream_t s, const DevConfig* cfg, const EnvStore& ea, const EnvStore& eb, int n_sets, int64_t max_envs, const DeviceStatus* st) {
+    if (n_sets <= 0 || max_envs <= 0) return;
+    const int64_t nb = (max_envs + 3) / 4;
+    k_env_key_sets<<<(unsigned)(nb < 8192 ? nb : 8192), 256, 0, s>>>(cfg, ea, eb, n_sets, st);
+}
+
 // ---- the pairs of a finished pass that touch an overflowed environment (EnvSide::ovf_list) ----------------------------------
 // k_mark_overflow: overflow lists -> bit sets over the sides' slots (zeroed by the host).  k_select_overflow<false>: every
 // wavefront counts the marked pairs of its contiguous share of the list; k_scan_overflow: exclusive scan of the (at most

@@ -720,3 +720,57 @@ def test_trajectory_frames_with_more_than_255_categories(lh, oracle):
     for f in (0, 3, 4, 8):
         want = np.asarray(lo.from_primitives(ref_p, prims(oracle, seq, frames[f], tags), [(int(i), int(i)) for i in la], 9.0))
         assert np.max(np.abs(got[f] - want)) < TIGHT, f
+
+
+@pytest.mark.parametrize("density,n_cat,n_wf", [(0.05, 10, 2), (0.023, 8, 3), (0.05, 16, 4), (0.023, 5, 5)])
+def test_weight_function_dictionary_through_the_team_sweeps(lh, oracle, density, n_cat, n_wf, monkeypatch):
+    """w_func as a dictionary + one key per anchor pair (src/locohd.rs:27-32,230-283).  Up to four functions: the environment store
+    holds one set of F keys per function (k_env_key_sets) and every pair is swept from the set of its function by the same team
+    kernels as a single-function configuration; five and more: distance keys, the CDF evaluated per event.  Against the oracle,
+    against the distance-key path (LCHD_NO_KEY_SETS), and an index outside the dictionary."""
+    import torch
+    from loco_hd_amd.device import DeviceSession
+
+    rng = np.random.default_rng(int(density * 1000) + n_cat + 31 * n_wf)
+    n, n_pairs = 2500, 24000
+    side = (n / density) ** (1 / 3)
+    cats = [f"c{i}" for i in range(n_cat)]
+    xa, xb = rng.uniform(0, side, (n, 3)), rng.uniform(0, side, (n, 3))
+    ca, cb = rng.integers(0, n_cat, n).astype(np.int32), rng.integers(0, n_cat, n).astype(np.int32)
+    pairs = np.stack([rng.integers(0, n, n_pairs), rng.integers(0, n, n_pairs)], 1).astype(np.int64)
+    xa[:40] = xa[0] + rng.normal(0, 1.5, (40, 3))  # a few long pairs among the short ones (the companion launch)
+    xb[:40] = xb[0] + rng.normal(0, 1.5, (40, 3))
+    specs = [("hyper_exp", [1.0, 0.1]), ("uniform", [3.0, 10.0]), ("kumaraswamy", [2.0, 9.5, 1.7, 2.2]), ("dagum", [2.5, 6.0, 1.3]),
+             ("hyper_exp", [0.3, 0.7, 0.25, 0.08])][:n_wf]
+    wf_idx = rng.integers(0, n_wf, n_pairs).astype(np.int32)
+    tz = np.zeros(n, dtype=np.int32)
+
+    def build(mod):
+        return mod.LoCoHD(cats, {f"w{k}": mod.WeightFunction(nm, prm) for k, (nm, prm) in enumerate(specs)})
+
+    lo = build(oracle)
+    want = np.asarray(lo.from_arrays(xa, ca, tz, xb, cb, tz, pairs, 10.0, *lo._wfs([f"w{k}" for k in wf_idx], n_pairs)))
+
+    def run(idx):
+        sess = DeviceSession(build(lh))
+        a, b = sess.upload(xa, ca), sess.upload(xb, cb)
+        anchors, wfi = torch.from_numpy(pairs).cuda(), torch.from_numpy(idx).cuda()
+        outs = [sess.from_primitives(a, b, anchors, 10.0, wf_index=wfi).cpu().numpy() for _ in range(3)]
+        sess.close()
+        return outs
+
+    outs = run(wf_idx)
+    assert np.max(np.abs(outs[0] - want)) < TIGHT
+    assert np.max(np.abs(outs[1] - want)) < TIGHT
+    assert np.array_equal(outs[1], outs[2])
+    monkeypatch.setenv("LCHD_NO_KEY_SETS", "1")
+    plain = run(wf_idx)
+    assert np.max(np.abs(plain[1] - outs[1])) < TIGHT
+    monkeypatch.delenv("LCHD_NO_KEY_SETS")
+    bad = wf_idx.copy()
+    bad[777] = n_wf
+    with pytest.raises(ValueError):
+        run(bad)
+    bad[777] = -1
+    with pytest.raises(ValueError):
+        run(bad)
