@@ -183,6 +183,9 @@ struct lchd_ctx {
     int sweep_hint = 0;                // 0 unknown, else 4 | 1 (pairs of <= 240 events were the majority of the last pass) | 2 (pairs with both environments <= 255 points were): launch_sweep
     unsigned long long* d_points = nullptr;
     double* d_tabs = nullptr;  // sqrt(k) | 1/sqrt(k), 65536 entries each
+    unsigned char* d_wide_scratch = nullptr;  // more than kWideCategories categories: per-workgroup state of k_sweep_wide<.., HUGE> (lchd_ctx_set_config)
+    size_t wide_scratch_cap = 0;
+    int wide_scratch_waves = 0;
     double* d_powtab = nullptr;  // k^(1/e) | k^(-1/e) for the configured Hellinger exponent (allocated when one is first configured)
     double powtab_e = 0.0;       // the exponent the table holds
     DoneState* d_done = nullptr;     // 'last workgroup' counters / accumulators of k_pair_meta (zero between kernels)
@@ -379,6 +382,7 @@ extern "C" void lchd_ctx_destroy(lchd_ctx* c) {
     (void)hipFree(c->d_points);
     (void)hipFree(c->d_tabs);
     (void)hipFree(c->d_powtab);
+    (void)hipFree(c->d_wide_scratch);
     (void)hipFree(c->d_done);
     (void)hipFree(c->d_io);
     (void)hipFree(c->d_ovf_bits);
@@ -436,9 +440,26 @@ extern "C" int lchd_ctx_set_config(lchd_ctx* c, const lchd_config* cfg) {
     CTX_GUARD(c);
     const int C = cfg->n_categories;
     if (C <= 0) return fail(LCHD_EVALUE, "The number of possible categories (primitive types) cannot be zero!");
-    if (C > kWideCategories)
-        return fail(LCHD_EUNSUPPORTED, "at most %d categories are supported (the sweep keeps one per-lane count column per category in LDS; got %d)",
-                    kWideCategories, C);
+    if (C > kHugeCategories)
+        return fail(LCHD_EUNSUPPORTED, "at most %d categories are supported (category ids travel as 16 bits on the device; got %d)", kHugeCategories, C);
+    if (C > kWideCategories) {
+        // beyond what the sweep's per-lane count columns fit in LDS: a global-memory scratch block per workgroup (k_sweep_wide<.., HUGE>),
+        // up to 1 GB of them (256 workgroups at most, 8 at least)
+        const size_t per = wide_scratch_bytes_per_wave(C);
+        const int waves = (int)std::max<size_t>(8, std::min<size_t>(256, ((size_t)1 << 30) / per));
+        if (c->wide_scratch_cap < per * (size_t)waves) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (c->d_wide_scratch) (void)hipFree(c->d_wide_scratch);
+            c->d_wide_scratch = nullptr;
+            c->wide_scratch_cap = 0;
+            if (hipMalloc(&c->d_wide_scratch, per * (size_t)waves) != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(LCHD_EUNSUPPORTED, "%d categories need %zu bytes of sweep scratch on the device", C, per * (size_t)waves);
+            }
+            c->wide_scratch_cap = per * (size_t)waves;
+        }
+        c->wide_scratch_waves = waves;
+    }
     if (int rc = lchd_config_validate(C, C, cfg->category_weights, C)) return rc;
     if (cfg->n_weight_functions <= 0) return fail(LCHD_EVALUE, "at least one weight function is required");
     if (int rc = lchd_sd_validate(cfg->sd_kind, cfg->sd_n_params)) return rc;
@@ -911,6 +932,9 @@ static void fill_sweep_args(lchd_ctx* c, SweepArgs& sw) {
     sw.sqrt_tab = c->d_tabs;
     sw.rsqrt_tab = c->d_tabs + 65536;
     sw.done = c->d_done;
+    sw.wide_scratch = c->d_wide_scratch;
+    sw.wide_scratch_per_wave = (int64_t)wide_scratch_bytes_per_wave(c->h_cfg.n_categories);
+    sw.wide_scratch_waves = c->wide_scratch_waves;
 }
 
 // Everything of one from_primitives pass; no host synchronisation (the workspace only grows between passes).
@@ -2298,6 +2322,9 @@ extern "C" int lchd_from_anchors(lchd_ctx* c, const lchd_config* cfg, const int3
     if (!ascending) {
         // src/locohd.rs:97-221 on lists that do not ascend: no sort-based kernel computes what that loop computes; one lane walks it
         c->status_dirty = false;
+        if (cfg->n_categories > 2000)
+            return fail(LCHD_EUNSUPPORTED, "lists whose distances do not ascend are walked with the count vectors in LDS: at most 2000 categories (got %d)",
+                        cfg->n_categories);
         launch_anchors_literal(s, c->d_cfg, cfg->n_categories, ea, eb, (int)len_seq_a, (int)len_seq_b, wf_index, h_out);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(s));

@@ -7,6 +7,9 @@
 namespace lchd {
 
 constexpr int kMaxCategories = 255;   // categories travel as u8 on the device ...
+constexpr int kHugeCategories = 65534;  // ... beyond kWideCategories: the same 16-bit ids (0xFFFF = not in the map), the sweep's per-category state in global memory
+// scratch of one workgroup of k_sweep_wide<.., HUGE>: [C][64] u32 count columns | [C] u32 carry row | 2 x [64][C] f64 normalised vectors
+inline size_t wide_scratch_bytes_per_wave(int C) { return (((size_t)C * 65 * 4 + 15) & ~(size_t)15) + (size_t)C * 64 * 16; }
 constexpr int kWideCategories = 512;  // ... or, for 256 .. 512 categories, as u16 (CloudView::cat_hi, EnvStore::cat16): from_primitives and
                                       // from_anchors only, through k_env_cells<.., uint16_t> and k_sweep_wide<.., CAT16> (its per-lane
                                       // category counts, 256 bytes per category, must fit the LDS)
@@ -292,6 +295,9 @@ struct SweepArgs {
     const double* rsqrt_tab;  // [65536] 1/sqrt(k)
     int4* meta;               // [P] workspace: per-pair records written by k_pair_meta, read by the sweep kernels
     DoneState* done;          // context-owned, zero between kernels: "last workgroup" counters and accumulators
+    unsigned char* wide_scratch;      // more than kWideCategories categories (k_sweep_wide<.., HUGE>): context-owned global-memory block,
+    int64_t wide_scratch_per_wave;    //   bytes per workgroup (wide_scratch_bytes_per_wave(C)),
+    int32_t wide_scratch_waves;       //   workgroups it serves (= the grid of that launch)
     HostStatus* hst;          // host-mapped mirror (snapshot by k_pair_meta, error words by the sweep kernels)
     uint32_t seq;             // pass counter echoed into HostStatus::snapshot_seq
     int32_t duo_enabled;      // set by launch_sweep: k_sweep_duo was launched too and sweeps the small pairs when they are the majority

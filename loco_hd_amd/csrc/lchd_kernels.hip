@@ -3464,9 +3464,15 @@ constexpr int kWideMaxCat = kWideCategories;  // (512: the per-lane count column
 // but independent of the category count in registers.  WPB = anchor pairs (wavefronts) per workgroup.
 // BIG: environments of more than 65 535 points (the reference sorts and sweeps any length, utils.rs:25-39): the two counts of a
 // category are the halves of a 64-bit word instead of a 32-bit one, square roots beyond the 65 536-entry tables are computed.
-template <int MODE, int FMODE, int WPB, bool CAT16 = false, bool BIG = false>  // CAT16: 16-bit category ids in the environment store (EnvStore::cat16)
+// HUGE (more than kWideCategories categories, up to kHugeCategories): the per-lane count columns, the carry row and the generic
+// distances' normalised vectors live in a global-memory scratch block per workgroup (SweepArgs::wide_scratch) instead of LDS /
+// registers, the category weights are read from the configuration.  Nothing here is fast; it exists so that the reference's
+// arbitrary category map (src/locohd.rs:312-316) has no upper size short of the 16-bit ids of the store.
+template <int MODE, int FMODE, int WPB, bool CAT16 = false, bool BIG = false, bool HUGE = false>  // CAT16: 16-bit category ids in the environment store (EnvStore::cat16)
 __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
     static_assert(!(BIG && CAT16), "the pair record holds a 24-bit length next to an 8-bit category");
+    static_assert(!HUGE || (CAT16 && !BIG && WPB == 1), "the global-memory form: 16-bit ids, one wavefront per workgroup");
+    constexpr int kLdsCat = HUGE ? 1 : kWideMaxCat;
     using CT = typename std::conditional<CAT16, uint16_t, uint8_t>::type;
     using W = typename std::conditional<BIG, uint64_t, uint32_t>::type;  // count of side A | count of side B << SH
     constexpr int SH = BIG ? 32 : 16;
@@ -3479,8 +3485,8 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
     // ever touches its own column, and column-major placement makes every access conflict-free.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
     __shared__ double t_sqrt[NT], t_rsqrt[NT];
-    __shared__ double w_s[kWideMaxCat], sw_s[kWideMaxCat];
-    __shared__ W carry_[WPB][BIG ? 256 : kWideMaxCat];  // per category: counts before the current tile (A | B << SH)
+    __shared__ double w_s[kLdsCat], sw_s[kLdsCat];
+    __shared__ W carry_[WPB][BIG ? 256 : kLdsCat];  // per category: counts before the current tile (A | B << SH)
     __shared__ uint64_t sA_[WPB][TILE], sB_[WPB][TILE];
     __shared__ CT cA_[WPB][TILE], cB_[WPB][TILE];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -3494,8 +3500,8 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
             t_sqrt[k] = g_sqrt[k];
             t_rsqrt[k] = g_rsqrt[k];
         }
-    for (int c = tid; c < kWideMaxCat; c += 64 * WPB) {
-        const double wv_ = c < C ? cfgp->cat_w[c] : 0.0;
+    for (int c = tid; c < kLdsCat; c += 64 * WPB) {
+        const double wv_ = (!HUGE && c < C) ? cfgp->cat_w[c] : 0.0;
         w_s[c] = wv_;
         sw_s[c] = sqrt(wv_);
     }
@@ -3506,6 +3512,18 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
     CT* cB = cB_[wv];
     W* carry = carry_[wv];
     W* cnt = reinterpret_cast<W*>(smem_dyn) + (size_t)wv * C * 64 + lane;  // this lane's column: cnt[c * 64]
+    // HUGE: the same objects in this workgroup's scratch block: [C][64] count columns | [C] carry row | 2 x [64][C] doubles
+    unsigned char* const hbase = HUGE ? args.wide_scratch + (size_t)blockIdx.x * (size_t)args.wide_scratch_per_wave : nullptr;
+    W* const cnt_g = reinterpret_cast<W*>(hbase) + lane;
+    W* const carry_g = reinterpret_cast<W*>(hbase + (size_t)C * 64 * sizeof(W));
+    double* const pn_g = reinterpret_cast<double*>(hbase + (((size_t)C * 65 * sizeof(W) + 15) & ~(size_t)15)) + (size_t)lane * C;
+    double* const qn_g = pn_g + (size_t)64 * C;
+    auto cnt_at = [&](int c) -> W& { if constexpr (HUGE) return cnt_g[(size_t)c * 64]; else return cnt[c * 64]; };
+    auto carry_at = [&](int c) -> W& { if constexpr (HUGE) return carry_g[c]; else return carry[c]; };
+    auto wgt = [&](int c) -> double { if constexpr (HUGE) return cfgp->cat_w[c]; else return w_s[c]; };
+    auto swgt = [&](int c) -> double { if constexpr (HUGE) return sqrt(cfgp->cat_w[c]); else return sw_s[c]; };
+    // (HUGE: the carry row goes from lane 63 to lane 0 through global memory)
+    auto wsync = [&]() { if constexpr (HUGE) { __threadfence(); __builtin_amdgcn_wave_barrier(); } wave_sync_lds(); };
 
     auto sqrt_cnt = [&](int k) -> double {
         if constexpr (LDSTAB) return t_sqrt[k];
@@ -3593,9 +3611,9 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
         auto exact_h2 = [&]() -> double {
             double acc2 = 0.0;
             for (int c = 0; c < C; ++c) {
-                const W v = cnt[c * 64];
+                const W v = cnt_at(c);
                 double xa = sqrt_cnt((int)(v & kMaskA)), xb = sqrt_cnt((int)(v >> SH));
-                if constexpr (MODE == MODE_H2W) { xa *= sw_s[c]; xb *= sw_s[c]; }
+                if constexpr (MODE == MODE_H2W) { xa *= swgt(c); xb *= swgt(c); }
                 const double d = xa * ra - xb * rb;  // equal inputs cancel exactly
                 acc2 = fma(d, d, acc2);
             }
@@ -3610,12 +3628,14 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
                 if (h2 < kExactH2Below) h2 = exact_h2();
                 return sqrt_unit(h2);
             } else {
-                double pn[kWideMaxCat], qn[kWideMaxCat];
+                double pn_l[kLdsCat], qn_l[kLdsCat];
+                double* const pn = HUGE ? pn_g : pn_l;
+                double* const qn = HUGE ? qn_g : qn_l;
                 double sa_ = 0.0, sb_ = 0.0;  // pmf.rs:67-68: fresh sums
                 for (int c = 0; c < C; ++c) {
-                    const W v = cnt[c * 64];
-                    pn[c] = w_s[c] * (double)(v & kMaskA);
-                    qn[c] = w_s[c] * (double)(v >> SH);
+                    const W v = cnt_at(c);
+                    pn[c] = wgt(c) * (double)(v & kMaskA);
+                    qn[c] = wgt(c) * (double)(v >> SH);
                     sa_ += pn[c];
                     sb_ += qn[c];
                 }
@@ -3628,19 +3648,21 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
 
         // seed with the two anchors (:82-84): carry row and every lane's column
         if (c0a >= C || c0b >= C) bad_cat = true;
-        wave_sync_lds();
-        for (int c = lane; c < C; c += 64) carry[c] = (c == c0a ? kOneA : (W)0) | (c == c0b ? kOneB : (W)0);
-        for (int c = 0; c < C; ++c) cnt[c * 64] = (c == c0a ? kOneA : (W)0) | (c == c0b ? kOneB : (W)0);
+        wsync();
+        for (int c = lane; c < C; c += 64) carry_at(c) = (c == c0a ? kOneA : (W)0) | (c == c0b ? kOneB : (W)0);
+        for (int c = 0; c < C; ++c) cnt_at(c) = (c == c0a ? kOneA : (W)0) | (c == c0b ? kOneB : (W)0);
         if constexpr (H2) {
-            if (c0a == c0b && !bad_cat) D = (MODE == MODE_H2W) ? w_s[c0a & (kWideMaxCat - 1)] : 1.0;
+            // (a category outside the map: bad_cat, the score is NaN whatever is computed here)
+            const int w0a = HUGE ? (c0a < C ? c0a : 0) : (c0a & (kWideMaxCat - 1)), w0b = HUGE ? (c0b < C ? c0b : 0) : (c0b & (kWideMaxCat - 1));
+            if (c0a == c0b && !bad_cat) D = (MODE == MODE_H2W) ? wgt(w0a) : 1.0;
             if constexpr (MODE == MODE_H2W) {
-                na = w_s[c0a & (kWideMaxCat - 1)];
-                nb = w_s[c0b & (kWideMaxCat - 1)];
+                na = wgt(w0a);
+                nb = wgt(w0b);
                 ra = 1.0 / sqrt(na);
                 rb = 1.0 / sqrt(nb);
             }
         }
-        wave_sync_lds();
+        wsync();
         double F_carry = cdf_of_key(kA[0]);  // F(0): both anchors sit at distance 0
         double H_carry = bad_cat ? 0.0 : distance();
         double acc = 0.0;
@@ -3650,7 +3672,7 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
         for (int k0 = 0; k0 < M; k0 += TILE) {
             const int T = min(TILE, M - k0);
             const int nAt = min(TILE, mA - ia), nBt = min(TILE, mB - ib);
-            wave_sync_lds();  // previous tile fully consumed
+            wsync();  // previous tile fully consumed
             for (int t = lane; t < nAt; t += 64) { sA[t] = kA[1 + ia + t]; cA[t] = tA[1 + ia + t]; }
             for (int t = lane; t < nBt; t += 64) { sB[t] = kB[1 + ib + t]; cB[t] = tB[1 + ib + t]; }
             wave_sync_lds();
@@ -3664,14 +3686,14 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
             const int j0 = d0 - i0, j1 = d1 - i1;
 
             // pass 1: histogram of this lane's chunk into its LDS column
-            for (int c = 0; c < C; ++c) cnt[c * 64] = (W)0;
+            for (int c = 0; c < C; ++c) cnt_at(c) = (W)0;
             for (int i = i0; i < i1; ++i) {
                 const int ct = cA[i];
-                if (ct >= C) bad_cat = true; else cnt[ct * 64] += kOneA;
+                if (ct >= C) bad_cat = true; else cnt_at(ct) += kOneA;
             }
             for (int j = j0; j < j1; ++j) {
                 const int ct = cB[j];
-                if (ct >= C) bad_cat = true; else cnt[ct * 64] += kOneB;
+                if (ct >= C) bad_cat = true; else cnt_at(ct) += kOneB;
             }
             // per category: wave64 inclusive scan (the carry of earlier tiles enters through lane 0); the exclusive
             // prefix = counts at this lane's first event.  Both 16-bit halves scan at once (every count < 65536).
@@ -3680,17 +3702,17 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
             if constexpr (H2) D = 0.0;
             if constexpr (MODE == MODE_H2W) na = nb = 0.0;
             for (int c = 0; c < C; ++c) {
-                const W own = cnt[c * 64];
-                const W incl = scan_counts(own + (lane == 0 ? carry[c] : (W)0));
+                const W own = cnt_at(c);
+                const W incl = scan_counts(own + (lane == 0 ? carry_at(c) : (W)0));
                 const W excl = incl - own;
-                cnt[c * 64] = excl;
-                if (lane == 63) carry[c] = incl;
+                cnt_at(c) = excl;
+                if (lane == 63) carry_at(c) = incl;
                 if constexpr (H2) {
                     const int ca = (int)(excl & kMaskA), cb = (int)(excl >> SH);
                     if constexpr (MODE == MODE_H2W) {
-                        D += w_s[c] * (sqrt_cnt(ca) * sqrt_cnt(cb));
-                        na += w_s[c] * (double)ca;
-                        nb += w_s[c] * (double)cb;
+                        D += wgt(c) * (sqrt_cnt(ca) * sqrt_cnt(cb));
+                        na += wgt(c) * (double)ca;
+                        nb += wgt(c) * (double)cb;
                     } else {
                         D += sqrt_cnt(ca) * sqrt_cnt(cb);
                     }
@@ -3713,8 +3735,8 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
                 // pmf.rs:47-63: one more point of category ct on one side
                 const bool okc = ct < C;
                 const int cs = okc ? ct : 0;
-                const W old = cnt[cs * 64];
-                cnt[cs * 64] = old + (okc ? (takeA ? kOneA : kOneB) : (W)0);
+                const W old = cnt_at(cs);
+                cnt_at(cs) = old + (okc ? (takeA ? kOneA : kOneB) : (W)0);
                 totA += takeA ? 1 : 0;
                 totB += takeA ? 0 : 1;
                 if constexpr (H2) {
@@ -3722,7 +3744,7 @@ __global__ __launch_bounds__(64 * WPB) void k_sweep_wide(SweepArgs args) {
                     const int mine = takeA ? cntA_ : cntB_, other = takeA ? cntB_ : cntA_;
                     double delta = (sqrt_cnt(mine + 1) - sqrt_cnt(mine)) * sqrt_cnt(other);
                     if constexpr (MODE == MODE_H2W) {
-                        const double wv_ = w_s[cs];
+                        const double wv_ = wgt(cs);
                         delta *= wv_;
                         na += takeA ? wv_ : 0.0;
                         nb += takeA ? 0.0 : wv_;
@@ -3797,6 +3819,10 @@ static void launch_sweep_wide(hipStream_t s, int n_cat, int64_t n_pairs, int fmo
         const size_t dyn = (size_t)4 * n_cat * 256;
         if (fmode == F_KEY) k_sweep_wide<MODE, F_KEY, 4><<<grid, 256, dyn, s>>>(a);
         else k_sweep_wide<MODE, F_ANY, 4><<<grid, 256, dyn, s>>>(a);
+    } else if (n_cat > kWideCategories) {  // the global-memory form (the caller has checked that the scratch block exists)
+        const unsigned grid = (unsigned)std::min<int64_t>(n_pairs, a.wide_scratch_waves);
+        if (fmode == F_KEY) k_sweep_wide<MODE, F_KEY, 1, true, false, true><<<grid, 64, 0, s>>>(a);
+        else k_sweep_wide<MODE, F_ANY, 1, true, false, true><<<grid, 64, 0, s>>>(a);
     } else {
         const unsigned grid = (unsigned)(n_pairs < 8192 ? n_pairs : 8192);
         const size_t dyn = (size_t)n_cat * 256;  // (> 64 KB from 257 categories' worth on: init_device_kernels raised the limit)

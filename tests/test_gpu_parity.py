@@ -365,7 +365,7 @@ def test_three_hundred_categories(lh, oracle):
     """The reference's category map is an arbitrary HashMap (/root/reference/src/locohd.rs:312-316).  Beyond 255 categories
     the ids travel as 16 bits (k_env_cells<.., uint16_t>, k_sweep_wide<.., CAT16>): from_anchors and from_primitives, every
     statistical-distance family, category weights, a weight-function dictionary, both tag rules; from_coords / from_dmxs in
-    test_three_hundred_categories_dense below.  More than 512 categories stay a loud refusal."""
+    test_three_hundred_categories_dense below; more than 512: test_more_than_512_categories."""
     rng = np.random.default_rng(61)
     cats = [f"t{i}" for i in range(300)]
     n = 500
@@ -412,10 +412,63 @@ def test_three_hundred_categories(lh, oracle):
     lchd = lh.LoCoHD(cats, lh.WeightFunction("uniform", [0.0, 4.0]))
     with pytest.raises(ValueError):
         lchd.from_primitives(prims(lh, ["t1", "nope"], xa[:2] * 0.01), prims(lh, ["t1", "t2"], xb[:2] * 0.01), [(0, 0)], 8.0)
-    with pytest.raises(NotImplementedError):
-        lh.LoCoHD([f"c{i}" for i in range(513)]).from_anchors(["c0"], ["c0"], [0.0], [0.0])
-    with pytest.raises(NotImplementedError):
-        lh.LoCoHD([f"c{i}" for i in range(513)]).from_coords(["c0"], ["c0"], [[0.0, 0.0, 0.0]], [[0.0, 0.0, 0.0]])
+    with pytest.raises(NotImplementedError):  # (ids travel as 16 bits, 0xFFFF = not in the map)
+        lh.LoCoHD([f"c{i}" for i in range(65535)]).from_anchors(["c0"], ["c0"], [0.0], [0.0])
+
+
+@pytest.mark.parametrize("n_cat", [513, 1500, 5000])
+def test_more_than_512_categories(lh, oracle, n_cat):
+    """Beyond 512 categories the sweep's per-category state no longer fits LDS: k_sweep_wide<.., HUGE> keeps the per-lane count
+    columns, the carry row and the generic distances' normalised vectors in a global-memory block per workgroup (the reference's
+    category map has no size limit, src/locohd.rs:312-316).  from_primitives, from_anchors, from_coords and from_dmxs; every distance
+    family, category weights, a weight-function dictionary, a tag rule."""
+    rng = np.random.default_rng(n_cat)
+    cats = [f"t{i}" for i in range(n_cat)]
+    n = 400
+    sa, xa = rng.choice(cats, n).tolist(), rng.uniform(0, 20.0, (n, 3))
+    sb, xb = rng.choice(cats, n).tolist(), rng.uniform(0, 20.0, (n, 3))
+    sa[0], sb[0], sa[1], sb[1] = cats[-1], cats[-1], "t511", "t512"
+    tags = [f"r{i // 5}" for i in range(n)]
+    anchors = [(int(i), int(j)) for i, j in zip(rng.integers(0, n, 120), rng.integers(0, n, 120))] + [(0, 0), (1, 1), (0, 1)]
+    w = rng.uniform(0.5, 2.0, n_cat).tolist()
+    cases = [dict(), dict(category_weights=w), dict(rule={"accept_same": False}), dict(sd=("Kolmogorov-Smirnov", [])),
+             dict(sd=("Kullback-Leibler", [1e-3])), dict(sd=("Renyi", [1.7, 1e-9])), dict(sd=("Hellinger", [3.0]), category_weights=w)]
+    if n_cat > 2000:
+        cases = cases[:2] + cases[3:5]
+    for case in cases:
+
+        def run(mod):
+            kw = {}
+            if "category_weights" in case:
+                kw["category_weights"] = case["category_weights"]
+            if "sd" in case:
+                kw["statistical_distance"] = mod.StatisticalDistance(*case["sd"])
+            rule = mod.TagPairingRule(case["rule"]) if "rule" in case else None
+            lchd = mod.LoCoHD(cats, mod.WeightFunction("hyper_exp", [1.0, 0.15]), rule, **kw)
+            out = [np.asarray(lchd.from_primitives(prims(mod, sa, xa, tags), prims(mod, sb, xb, tags), anchors, 8.0)) for _ in range(2)]
+            da, db = np.sort(rng_d.uniform(0, 9, 40)), np.sort(rng_d.uniform(0, 9, 55))
+            da[0] = db[0] = 0.0
+            one = lchd.from_anchors(sa[:40], sb[:55], da.tolist(), db.tolist())
+            dense = np.asarray(lchd.from_coords(sa[:150], sb[:150], xa[:150], xb[:150]))
+            return out, one, dense
+
+        rng_d = np.random.default_rng(7)
+        got, got1, gotd = run(lh)
+        rng_d = np.random.default_rng(7)
+        want, want1, wantd = run(oracle)
+        for g in got:
+            assert np.max(np.abs(g - want[0])) < TIGHT, case
+        assert abs(got1 - want1) < TIGHT, case
+        assert np.max(np.abs(gotd - wantd)) < TIGHT, case
+
+    def run_multi(mod):
+        lchd = mod.LoCoHD(cats, {"a": mod.WeightFunction("uniform", [2.0, 8.0]), "b": mod.WeightFunction("kumaraswamy", [1.0, 9.0, 2.0, 3.0])})
+        keyed = [(i, j, "a" if (i + j) % 2 else "b") for i, j in anchors]
+        return np.asarray(lchd.from_primitives(prims(mod, sa, xa), prims(mod, sb, xb), keyed, 8.0))
+    assert np.max(np.abs(run_multi(lh) - run_multi(oracle))) < TIGHT
+    lchd = lh.LoCoHD(cats, lh.WeightFunction("uniform", [0.0, 4.0]))
+    with pytest.raises(ValueError):  # a label outside the map is still an error
+        lchd.from_primitives(prims(lh, ["t1", "nope"], xa[:2] * 0.01), prims(lh, ["t1", "t2"], xb[:2] * 0.01), [(0, 0)], 8.0)
 
 
 @pytest.mark.parametrize("n", [1, 7, 300, 1100, 9000])
