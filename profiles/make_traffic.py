@@ -15,8 +15,8 @@ import sys
 
 # (c4: since round 3 the sweep is the longer phase; `c4_env`, `c5_env` describe the environment kernel of those workloads; the small-pair
 # sweeps are k_sweep_duo<slots, lanes per pair, events per pair>: four pairs per wavefront for C3 / C4, two for C2a / C5)
-DOMINANT = {"c2a": "k_sweep_duo<12, 32, 480, false>", "c5": "k_sweep_duo<28, 32, 480, false>", "c4": "k_sweep_duo<8, 16, 240, false>",
-            "c3": "k_sweep_duo<8, 16, 240, false>",
+DOMINANT = {"c2a": "k_sweep_duo<12, 32, 480, false, false>", "c5": "k_sweep_duo<28, 32, 480, false, false>", "c4": "k_sweep_duo<8, 16, 240, false, false>",
+            "c3": "k_sweep_duo<8, 16, 240, false, false>",
             "c2b": "k_dense_fused<12, false>",
             "c4_env": "k_env_group<false, 320", "c5_env": "k_env_group<false, 320"}
 
