@@ -257,7 +257,8 @@ def _cluster_in_sparse_cloud(seed, n_sparse, n_cluster, n_cat):
     return xyz, cat, tag
 
 
-@pytest.mark.parametrize("variant", ["two_structures", "same_object", "weight_function_dictionary", "tag_rule", "one_environment_per_workgroup"])
+@pytest.mark.parametrize("variant", ["two_structures", "same_object", "weight_function_dictionary", "tag_rule", "one_environment_per_workgroup",
+                                     "cluster_of_20000"])
 def test_a_dense_cluster_in_a_sparse_cloud_rescoring_only_its_pairs(lh, oracle, variant, monkeypatch):
     """Environments have no capacity in the reference (src/locohd.rs:514-542: a Vec per anchor, utils.rs:25-39 sorts whatever
     it holds); here they live in fixed-stride slots of 512 points.  One 3 000-point cluster inside a sparse 60 000-point cloud: the
@@ -267,7 +268,8 @@ def test_a_dense_cluster_in_a_sparse_cloud_rescoring_only_its_pairs(lh, oracle, 
     import torch
     from loco_hd_amd.device import DeviceSession
 
-    n_sparse, n_cluster, n_cat = 60_000, 3_000, 7
+    # (cluster_of_20000: the second pass takes the slots beyond 16 384 points -- unsorted collection + the global-memory row sort)
+    n_sparse, n_cluster, n_cat = 60_000, (20_000 if variant == "cluster_of_20000" else 3_000), 7
     xa, ca, ta = _cluster_in_sparse_cloud(1, n_sparse, n_cluster, n_cat)
     xb, cb, tb = _cluster_in_sparse_cloud(2, n_sparse, n_cluster, n_cat)
     rng = np.random.default_rng(3)
@@ -337,5 +339,5 @@ def test_a_dense_cluster_in_a_sparse_cloud_rescoring_only_its_pairs(lh, oracle, 
     # (slots for min(atoms, pairs) anchors per side -- one side with twice as many when the sides are one object --, 8-byte keys + a
     #  category byte per point; a dictionary of two weight functions: the distances + one set of F keys per function)
     first_pass_store = 2 * n_pairs * 512 * (1 + 8 * (3 if variant == "weight_function_dictionary" else 1))
-    assert counts[0]["store_bytes"] <= 1.3 * first_pass_store
+    assert counts[0]["store_bytes"] <= (2.5 if variant == "cluster_of_20000" else 1.3) * first_pass_store
     assert wcounts[0]["store_bytes"] >= 4 * counts[0]["store_bytes"]
