@@ -338,12 +338,27 @@ def run_c4(args, torch, dist, dev, rank, world, use_dist):
     sess = DeviceSession(lchd, device=dev.index)
     sess.enable_timing(True)
     ref = sess.upload(centroids(ref_atoms), cat, tag)
+    # --c4-sessions 2 (default): the chunks of a step alternate between TWO sessions (contexts) with a frames buffer each, enqueued
+    # asynchronously (from_primitives_async; a session is waited for when its turn comes again): chunk k + 1's conversion runs on a
+    # side stream while chunk k is scored, so the host's grid planning (it needs the chunk's bounding box) does not wait for the
+    # scoring stream and the device never idles between chunks.  1: one session, every chunk waited for before the next is enqueued.
+    n_sess = max(1, min(2, args.c4_sessions))
+    sessions = [sess] + [DeviceSession(lchd, device=dev.index) for _ in range(n_sess - 1)]
+    for s_ in sessions[1:]:
+        s_.enable_timing(True)
+    refs = [ref] + [s_.upload(centroids(ref_atoms), cat, tag) for s_ in sessions[1:]]
+    side_stream = torch.cuda.Stream(device=dev) if n_sess > 1 else None
     gen = torch.Generator(device=dev).manual_seed(4 + rank)
     d_ref = torch.from_numpy(ref_atoms).to(dev)
     frames = (d_ref[None] + 0.5 * torch.randn((n_frames, n_src, 3), generator=gen, device=dev, dtype=torch.float32)).contiguous()
     chunk = min(chunk, n_frames)
     buf = sess.frames_buffer(ref, chunk)
     sess.set_frame_sources(buf, topo)
+    bufs = [buf]
+    for s_, r_ in zip(sessions[1:], refs[1:]):
+        b_ = s_.frames_buffer(r_, chunk)
+        s_.set_frame_sources(b_, topo)
+        bufs.append(b_)
     la = torch.arange(0, n_prim, 3, dtype=torch.int64, device=dev)
     offs = torch.arange(chunk, dtype=torch.int64, device=dev).repeat_interleave(len(la)) * n_prim
     anchors = torch.stack([la.repeat(chunk), la.repeat(chunk) + offs], 1).contiguous()
@@ -354,15 +369,38 @@ def run_c4(args, torch, dist, dev, rank, world, use_dist):
     collect = [False]
     env_points = [0]
 
+    busy = [False] * n_sess
+
+    def drain(i):  # wait for session i's chunk (if one is in flight) and book its phase times
+        if not busy[i]:
+            return
+        sessions[i].finish()
+        busy[i] = False
+        if collect[0]:
+            phase["convert"] += sessions[i].last_convert_ms(bufs[i])
+            for k, v in sessions[i].last_ms().items():
+                phase[k] += v
+
     def step():
-        for f0 in starts:
+        if n_sess == 1:
+            for f0 in starts:
+                nf = min(chunk, n_frames - f0)
+                sess.load_atom_frames_dev(buf, frames[f0:f0 + nf])
+                sess.from_primitives(ref, buf, anchors[: nf * len(la)], 10.0, out=out[f0 * len(la):(f0 + nf) * len(la)])
+                if collect[0]:
+                    phase["convert"] += sess.last_convert_ms(buf)
+                    for k, v in sess.last_ms().items():
+                        phase[k] += v
+            return
+        for c, f0 in enumerate(starts):
+            i = c % n_sess
             nf = min(chunk, n_frames - f0)
-            sess.load_atom_frames_dev(buf, frames[f0:f0 + nf])
-            sess.from_primitives(ref, buf, anchors[: nf * len(la)], 10.0, out=out[f0 * len(la):(f0 + nf) * len(la)])
-            if collect[0]:
-                phase["convert"] += sess.last_convert_ms(buf)
-                for k, v in sess.last_ms().items():
-                    phase[k] += v
+            drain(i)
+            sessions[i].load_atom_frames_dev(bufs[i], frames[f0:f0 + nf], side_stream)
+            sessions[i].from_primitives_async(refs[i], bufs[i], anchors[: nf * len(la)], 10.0, out[f0 * len(la):(f0 + nf) * len(la)])
+            busy[i] = True
+        for i in range(n_sess):  # (a step ends with every chunk scored)
+            drain(i)
 
     def start_collect():
         collect[0] = True
@@ -385,7 +423,8 @@ def run_c4(args, torch, dist, dev, rank, world, use_dist):
                  f"converted on the device), {len(la)} per-residue anchors/frame, accept_same=False, uniform[3,10], thr 10 A, "
                  f"chunks of {chunk} frames")
         result = base_result(args, world, p * world, elapsed, label, {"pairs_per_gpu": p, "mean_env_points_per_pair": env_points[0] / p,
-                                                                      "sharding": "frames across ranks, no exchange step, scores stay on their rank"})
+                                                                      "sharding": "frames across ranks, no exchange step, scores stay on their rank",
+                                                                      "sessions": n_sess})
         result["roofline"] = roofline_block("c4", {"env": "k_env_group (side A + side B)", "sweep": "k_sweep_duo<8, 16 lanes, 240 events> (four pairs per wavefront)"}[dom], algo / len(starts),
                                             phase[dom] / len(starts), len(starts), step_ms=result["ms_per_step"])
         result["kernel_ms"] = phase
@@ -414,6 +453,8 @@ def run_c4(args, torch, dist, dev, rank, world, use_dist):
             result["parity_sample_pairs"] = len(sample) * len(pairs)
             if not (err <= 1e-6):
                 result["parity_failed"] = True
+    for s_ in sessions[1:]:
+        s_.close()
     sess.close()
     return result
 
@@ -898,6 +939,8 @@ def main():
                          "is '>= 6x at 8 GPUs') = the named workload in total, sharded across the GPUs; weak = the named workload per GPU")
     ap.add_argument("--frames", type=int, default=5000, help="c4: frames of the trajectory")
     ap.add_argument("--chunk", type=int, default=1250, help="c4: frames per scoring pass")
+    ap.add_argument("--c4-sessions", type=int, default=2, choices=[1, 2],
+                    help="c4: sessions the chunks of a step alternate between (2: asynchronous passes, the next chunk converted on a side stream)")
     ap.add_argument("--pairs", type=int, default=1_000_000, help="c2a / c5: anchor pairs (per GPU when weak, in total when strong)")
     ap.add_argument("--gather", default=None, choices=["end", "step"],
                     help="multi-GPU: RCCL gather of the scores to rank 0 inside every timed step (default for N > 1) or once behind the timed region")
