@@ -3054,6 +3054,9 @@ __device__ __forceinline__ double team_sum_f64(double v) {  // the last lane of 
 // KSM: the Kolmogorov-Smirnov distance max_c |a_c / N_a - b_c / N_b| (statistical_distances.rs:12-21) with unit weights instead of
 // Hellinger-2: every event needs all categories, but as INTEGERS -- max_c |a_c N_b - b_c N_a| over the 8-bit count fields (two 24-bit
 // multiplies, one v_sad_u32, one max per category), scaled once by 1 / (N_a N_b) from the reciprocal-root table; no square root.
+#ifndef LCHD_STAGE_PAIRS
+#define LCHD_STAGE_PAIRS 1   // the team sweeps stage two buffer entries per lane and round (0: one)
+#endif
 #ifndef LCHD_WGT_LDSCNT
 #define LCHD_WGT_LDSCNT 1   // 1: the weighted instantiations with 9 .. 16 slots keep their per-lane counts in LDS bytes too
 #endif
@@ -3130,8 +3133,16 @@ __global__ __launch_bounds__(64 * kSweepWaves, ((CMAX <= 16 && !(WGT && CMAX > 8
         const uint8_t* __restrict__ tB = args.env_b.cat + (int64_t)m.y * args.env_b.stride;
         const double F0 = valid ? u2d(kA[0]) : 0.0;            // F(0): both anchors sit at distance 0
         const double H0 = (c0a == c0b) ? 0.0 : 1.0;            // two point masses
+#if LCHD_STAGE_PAIRS
+        // list B starts at an EVEN entry of the buffer (one unused entry behind an odd list A): the staging below moves two entries per
+        // lane and round -- one 16-byte key load, one 16-byte LDS write -- and no pair of entries straddles the two lists
+        const int mAe = (mA + 1) & ~1, Tb = mAe + mB;  // <= TILE + 1: the buffers hold TILE + 2 entries
+        uint64_t* sB = sA + mAe;
+        uint8_t* cB = cA + mAe;
+#else
         uint64_t* sB = sA + mA;
         uint8_t* cB = cA + mA;
+#endif
 
         // lane tl of a team owns merged events [d0, d1) of its pair
         const int epl = (T + TL - 1) / TL;  // <= EPL
@@ -3140,6 +3151,49 @@ __global__ __launch_bounds__(64 * kSweepWaves, ((CMAX <= 16 && !(WGT && CMAX > 8
         for (int k = 1; k < TEAMS; ++k) epl_w = max(epl_w, __builtin_amdgcn_readlane(epl, k * TL));
 
         wave_sync_lds();  // the previous pairs' tiles are fully consumed
+#if LCHD_STAGE_PAIRS
+        {   // stage [A's points | pad | B's points]: entries 2 q and 2 q + 1 of the buffer by lane q % TL in round q / TL; all loads before
+            // the first LDS write.  A pair's second entry may lie one past its list's last point (still inside the environment's slot or,
+            // for the last slot, the workspace's slack): it lands in the pad entry or behind the buffer's used part and is never read.
+            constexpr int EPL2 = (EPL + 1) / 2;
+            static_assert(2 * TL * EPL2 >= TILE_ + 1, "the rounds cover the buffer's used part (pad entry included)");
+            typedef unsigned long long __attribute__((ext_vector_type(2), aligned(8))) key2_t;
+            const int epl2 = (Tb + 2 * TL - 1) / (2 * TL);
+            int epl2_w = __builtin_amdgcn_readlane(epl2, 0);
+#pragma unroll
+            for (int k = 1; k < TEAMS; ++k) epl2_w = max(epl2_w, __builtin_amdgcn_readlane(epl2, k * TL));
+            key2_t rk[EPL2];
+            uint32_t rc[EPL2];
+            const uint64_t* kBs = kB - mAe;
+            const uint8_t* tBs = tB - mAe;
+#pragma unroll
+            for (int u = 0; u < EPL2; ++u) { rk[u] = key2_t{0ull, 0ull}; rc[u] = 0u; }
+            if (valid) {
+#pragma unroll
+                for (int u = 0; u < EPL2; ++u) {
+                    if (u < epl2_w) {  // (wave-uniform: rounds no team of this wavefront needs are skipped)
+                        const int t0 = 2 * (tl + TL * u);
+                        const int tt = t0 < Tb ? t0 : 0;  // (beyond the used part: re-read the row's first pair, nothing is written)
+                        const bool isA = tt < mAe;
+                        const uint64_t* src = (isA ? kA : kBs) + 1 + tt;
+                        const uint8_t* csrc = (isA ? tA : tBs) + 1 + tt;
+                        rk[u] = *reinterpret_cast<const key2_t*>(src);
+                        rc[u] = (uint32_t)csrc[0] | ((uint32_t)csrc[1] << 8);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < EPL2; ++u) {
+                if (u < epl2_w) {
+                    const int t0 = 2 * (tl + TL * u);
+                    if (t0 < Tb) {
+                        *reinterpret_cast<ulonglong2*>(sA + t0) = ulonglong2{rk[u].x, rk[u].y};
+                        *reinterpret_cast<uint16_t*>(cA + t0) = (uint16_t)rc[u];
+                    }
+                }
+            }
+        }
+#else
         {   // stage [A's points | B's points]: entry t of the buffer is A[1 + t] or B[1 + t - mA]; all loads before the first LDS write.
             // One predicate for the whole team (the pair is swept here), none per entry: an entry beyond T re-reads the pair's last
             // point (index clamped: inside the row) and lands in the buffer's unused tail (t < TILE).
@@ -3169,6 +3223,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, ((CMAX <= 16 && !(WGT && CMAX > 8
                 }
             }
         }
+#endif
         wave_sync_lds();
 
         const int d0 = min(tl * epl, T), d1 = min(d0 + epl, T);
