@@ -3245,7 +3245,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, ((CMAX <= 16 && !(WGT && CMAX > 8
             for (int w = 0; w < NH; ++w) hT[w] = 0;
 #pragma unroll
             for (int m = 0; m < EPL; ++m) {
-                if (m < epl) {  // wave-uniform? no: epl differs between the teams -- the test is per lane, the reads stay in range
+                if (m < epl_w) {  // wave-uniform (the longest chunk of the wavefront's teams): whole rounds are skipped; a lane's own bound is m < nl
                     const bool isA = m < nAl;
                     const int ct = (isA ? pa_ : pb_)[m < nl ? m : 0];
                     const H4 inc = (m < nl) ? ((H4)1 << ((ct & 15) * 4)) : (H4)0;
