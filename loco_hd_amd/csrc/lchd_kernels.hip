@@ -3125,12 +3125,18 @@ __global__ __launch_bounds__(64 * kSweepWaves, ((CMAX <= 16 && !(WGT && CMAX > 8
         const int mA = valid ? (m.z & 0xFFFFFF) - 1 : 0, mB = valid ? (m.w & 0xFFFFFF) - 1 : 0, T = mA + mB;  // non-anchor events
         const int c0a = (m.z >> 24) & 255, c0b = (m.w >> 24) & 255;
         // (a dictionary's key sets: the set of this pair's weight function -- k_pair_meta has checked the index of every usable pair)
-        int64_t kset = 0;
-        if (args.wf_index) kset = valid ? args.wf_index[p] : 0;
-        const uint64_t* __restrict__ kA = args.env_a.key + (int64_t)m.x * args.env_a.stride + kset * args.env_a.set_stride;
-        const uint64_t* __restrict__ kB = args.env_b.key + (int64_t)m.y * args.env_b.stride + kset * args.env_b.set_stride;
-        const uint8_t* __restrict__ tA = args.env_a.cat + (int64_t)m.x * args.env_a.stride;
-        const uint8_t* __restrict__ tB = args.env_b.cat + (int64_t)m.y * args.env_b.stride;
+        int64_t ksetA = 0, ksetB = 0;
+        if (args.wf_index) {  // (wave-uniform: configurations with one weight function never multiply)
+            const int64_t kset = valid ? args.wf_index[p] : 0;
+            ksetA = kset * args.env_a.set_stride;
+            ksetB = kset * args.env_b.set_stride;
+        }
+        // (slot x stride as ONE 32 x 32 -> 64-bit multiply: slots and strides are below 2^31)
+        const uint64_t offA = (uint64_t)(uint32_t)m.x * (uint32_t)args.env_a.stride, offB = (uint64_t)(uint32_t)m.y * (uint32_t)args.env_b.stride;
+        const uint64_t* __restrict__ kA = args.env_a.key + offA + ksetA;
+        const uint64_t* __restrict__ kB = args.env_b.key + offB + ksetB;
+        const uint8_t* __restrict__ tA = args.env_a.cat + offA;
+        const uint8_t* __restrict__ tB = args.env_b.cat + offB;
         const double F0 = valid ? u2d(kA[0]) : 0.0;            // F(0): both anchors sit at distance 0
         const double H0 = (c0a == c0b) ? 0.0 : 1.0;            // two point masses
 #if LCHD_STAGE_PAIRS
@@ -3287,7 +3293,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, ((CMAX <= 16 && !(WGT && CMAX > 8
                         na = fma(w_s[c], (double)fa, na);
                         nb = fma(w_s[c], (double)fb, nb);
                     } else {
-                        D += t_sqrt[field(exA, c)] * t_sqrt[field(exB, c)];
+                        D = fma(t_sqrt[field(exA, c)], t_sqrt[field(exB, c)], D);
                     }
                 }
                 if ((f & 3) == 3) __builtin_amdgcn_sched_barrier(0);
