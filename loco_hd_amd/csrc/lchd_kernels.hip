@@ -3054,6 +3054,9 @@ __device__ __forceinline__ double team_sum_f64(double v) {  // the last lane of 
 // KSM: the Kolmogorov-Smirnov distance max_c |a_c / N_a - b_c / N_b| (statistical_distances.rs:12-21) with unit weights instead of
 // Hellinger-2: every event needs all categories, but as INTEGERS -- max_c |a_c N_b - b_c N_a| over the 8-bit count fields (two 24-bit
 // multiplies, one v_sad_u32, one max per category), scaled once by 1 / (N_a N_b) from the reciprocal-root table; no square root.
+#ifndef LCHD_LCNT_HIST
+#define LCHD_LCNT_HIST 1     // the instantiations with per-lane counts in LDS bytes build the chunk histogram there too (LDS adds) when that takes two 4-bit words (17 and more slots; with one word the register form is as fast); 0: always in registers
+#endif
 #ifndef LCHD_STAGE_PAIRS
 #define LCHD_STAGE_PAIRS 1   // the team sweeps stage two buffer entries per lane and round (0: one)
 #endif
@@ -3242,6 +3245,29 @@ __global__ __launch_bounds__(64 * kSweepWaves, ((CMAX <= 16 && !(WGT && CMAX > 8
         H4 hA[NH], hB[NH];
 #pragma unroll
         for (int w = 0; w < NH; ++w) hA[w] = hB[w] = 0;
+        // ... LCNT: in the lane's LDS row instead -- the row the event loop keeps its running counts in is zeroed, every point of the chunk
+        // is ONE non-returning 32-bit LDS add of 1 << (8 x byte) (a chunk holds at most 15 points: no byte overflows into its neighbour),
+        // and the row read back IS the chunk's counts as 8-bit fields, A's CMAX bytes then B's: five instructions per point instead of the
+        // 24 of the two-word 4-bit form, and no 4-bit -> 8-bit spreading afterwards
+        uint64_t hw[LW];
+        if constexpr (LCNT && NH > 1 && (LCHD_LCNT_HIST != 0)) {
+#pragma unroll
+            for (int k = 0; k < LW; ++k) *reinterpret_cast<uint64_t*>(lcl + k * 512) = 0ull;
+            const int nAl = i1 - i0, nl = d1 - d0;
+            const uint8_t* pa_ = cA + i0;
+            const uint8_t* pb_ = cB + (j0 - nAl);
+#pragma unroll
+            for (int m = 0; m < EPL; ++m) {
+                if (m < epl_w) {
+                    const bool isA = m < nAl;
+                    const unsigned ct = (isA ? pa_ : pb_)[m < nl ? m : 0];
+                    const unsigned b = ct + (isA ? 0u : (unsigned)CMAX);
+                    if (m < nl) atomicAdd(reinterpret_cast<unsigned*>(lcl + ((b >> 3) << 9) + (b & 4u)), 1u << ((b & 3u) * 8u));
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < LW; ++k) hw[k] = *reinterpret_cast<const uint64_t*>(lcl + k * 512);
+        } else
         {   // one fixed-trip loop over the chunk's points, A's run first (see k_sweep)
             const int nAl = i1 - i0, nl = d1 - d0;
             const uint8_t* pa_ = cA + i0;
@@ -3274,7 +3300,17 @@ __global__ __launch_bounds__(64 * kSweepWaves, ((CMAX <= 16 && !(WGT && CMAX > 8
         uint64_t exA[NW], exB[NW];
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
-            const uint64_t va_ = spread8((uint64_t)hA[(k * 8) / 16] >> (((k * 8) % 16) * 4)), vb_ = spread8((uint64_t)hB[(k * 8) / 16] >> (((k * 8) % 16) * 4));
+            uint64_t va_, vb_;
+            if constexpr (LCNT && NH > 1 && (LCHD_LCNT_HIST != 0)) {
+                // count word k of a side = its bytes [8 k, 8 k + 8) in the row (A's CMAX bytes | B's CMAX bytes, CMAX a multiple of 4)
+                va_ = hw[k];
+                if (8 * k + 8 > CMAX) va_ &= 0xFFFFFFFFull;  // (A's last four categories; the upper half is B's first)
+                if constexpr (CMAX % 8 == 0) vb_ = hw[CMAX / 8 + k];
+                else vb_ = (hw[CMAX / 8 + k] >> 32) | ((CMAX / 8 + k + 1 < LW) ? (hw[CMAX / 8 + k + 1] << 32) : 0ull);
+            } else {
+                va_ = spread8((uint64_t)hA[(k * 8) / 16] >> (((k * 8) % 16) * 4));
+                vb_ = spread8((uint64_t)hB[(k * 8) / 16] >> (((k * 8) % 16) * 4));
+            }
             const uint64_t sa_ = team_incl_scan_fields<TL>(va_), sb_ = team_incl_scan_fields<TL>(vb_);
             exA[k] = (((c0a / FPW) == k) ? (1ull << ((c0a % FPW) * FB)) : 0ull) + sa_ - va_;
             exB[k] = (((c0b / FPW) == k) ? (1ull << ((c0b % FPW) * FB)) : 0ull) + sb_ - vb_;
