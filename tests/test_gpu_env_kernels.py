@@ -341,3 +341,66 @@ def test_a_dense_cluster_in_a_sparse_cloud_rescoring_only_its_pairs(lh, oracle, 
     first_pass_store = 2 * n_pairs * 512 * (1 + 8 * (3 if variant == "weight_function_dictionary" else 1))
     assert counts[0]["store_bytes"] <= (2.5 if variant == "cluster_of_20000" else 1.3) * first_pass_store
     assert wcounts[0]["store_bytes"] >= 4 * counts[0]["store_bytes"]
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("LCHD_OVERFLOW_SEEDS", "6"))))  # (a one-off campaign: LCHD_OVERFLOW_SEEDS=200)
+def test_overflowed_environments_random_configurations(lh, oracle, seed):
+    """Random clouds with one to three dense clusters (600 ... 5000 points) in a sparse background, random thresholds, pair lists that
+    touch the clusters on either side, category weights / Kolmogorov-Smirnov / a weight-function dictionary / a tag rule at random:
+    whatever mixture of first pass, second pass over the overflowed environments' pairs and whole-pass retry the call takes, the scores
+    are the oracle's."""
+    import torch
+    from loco_hd_amd.device import DeviceSession
+
+    rng = np.random.default_rng(900 + seed)
+    n_cat = int(rng.choice([4, 9, 14, 23]))
+    cats = [f"c{i}" for i in range(n_cat)]
+
+    def cloud():
+        n_sparse = int(rng.integers(8000, 20000))
+        side = (n_sparse / 0.003) ** (1 / 3)
+        parts = [rng.uniform(0.0, side, (n_sparse, 3))]
+        for _ in range(int(rng.integers(1, 4))):
+            m = int(rng.integers(600, 5000))
+            v = rng.normal(0.0, 1.0, (m, 3))
+            parts.append(rng.uniform(0.2 * side, 0.8 * side, 3) + v / np.linalg.norm(v, axis=1)[:, None] * (rng.uniform(3.0, 7.0) * rng.uniform(0, 1, (m, 1)) ** (1 / 3)))
+        xyz = np.concatenate(parts)
+        return xyz, rng.integers(0, n_cat, len(xyz)).astype(np.int32), rng.integers(0, 30, len(xyz)).astype(np.int32), n_sparse
+
+    xa, ca, ta, sa_ = cloud()
+    xb, cb, tb, sb_ = cloud()
+    n_pairs = 3000
+    pairs = np.stack([rng.integers(0, len(xa), n_pairs), rng.integers(0, len(xb), n_pairs)], 1).astype(np.int64)
+    k = int(rng.integers(5, 200))
+    pairs[:k, 0] = rng.integers(sa_, len(xa), k)       # cluster anchors on side A
+    pairs[k:2 * k, 1] = rng.integers(sb_, len(xb), k)  # ... on side B
+    rng.shuffle(pairs)
+    thr = float(rng.uniform(6.0, 12.0))
+    kind = int(rng.integers(0, 5))
+    kw = {}
+    if kind == 1:
+        kw["category_weights"] = rng.uniform(0.3, 2.5, n_cat).tolist()
+    use_rule = kind == 3
+    if not use_rule:
+        ta, tb = np.zeros_like(ta), np.zeros_like(tb)
+
+    def build(mod):
+        wf = mod.WeightFunction("hyper_exp", [1.0, 0.12])
+        if kind == 4:
+            wf = {"a": wf, "b": mod.WeightFunction("uniform", [2.0, 9.0]), "c": mod.WeightFunction("kumaraswamy", [1.0, 11.0, 1.5, 2.5])}
+        if kind == 2:
+            kw["statistical_distance"] = mod.StatisticalDistance("Kolmogorov-Smirnov", [])
+        return mod.LoCoHD(cats, wf, mod.TagPairingRule({"accept_same": False}) if use_rule else None, **kw)
+
+    wf_idx = rng.integers(0, 3, n_pairs).astype(np.int32) if kind == 4 else None
+    lo = build(oracle)
+    extra = lo._wfs(["abc"[i] for i in wf_idx], n_pairs) if kind == 4 else ()
+    want = np.asarray(lo.from_arrays(xa, ca, ta, xb, cb, tb, pairs, thr, *extra))
+    sess = DeviceSession(build(lh))
+    a, b = sess.upload(xa, ca, ta), sess.upload(xb, cb, tb)
+    anchors = torch.from_numpy(pairs).cuda()
+    wfi = None if wf_idx is None else torch.from_numpy(wf_idx).cuda()
+    for _ in range(2):
+        got = sess.from_primitives(a, b, anchors, thr, wf_index=wfi).cpu().numpy()
+        assert np.max(np.abs(got - want)) < 1e-11, (seed, kind, thr)
+    sess.close()
