@@ -3311,7 +3311,14 @@ __global__ __launch_bounds__(64 * kSweepWaves, ((CMAX <= 16 && !(WGT && CMAX > 8
                 va_ = spread8((uint64_t)hA[(k * 8) / 16] >> (((k * 8) % 16) * 4));
                 vb_ = spread8((uint64_t)hB[(k * 8) / 16] >> (((k * 8) % 16) * 4));
             }
-            const uint64_t sa_ = team_incl_scan_fields<TL>(va_), sb_ = team_incl_scan_fields<TL>(vb_);
+            uint64_t sa_, sb_;
+            if (FPW * k + FPW / 2 >= CMAX) {  // (compile-time after unrolling: the side's last count word holds four categories: its upper half stays zero)
+                sa_ = team_incl_scan_u32<TL>((uint32_t)va_);
+                sb_ = team_incl_scan_u32<TL>((uint32_t)vb_);
+            } else {
+                sa_ = team_incl_scan_fields<TL>(va_);
+                sb_ = team_incl_scan_fields<TL>(vb_);
+            }
             exA[k] = (((c0a / FPW) == k) ? (1ull << ((c0a % FPW) * FB)) : 0ull) + sa_ - va_;
             exB[k] = (((c0b / FPW) == k) ? (1ull << ((c0b % FPW) * FB)) : 0ull) + sb_ - vb_;
         }
