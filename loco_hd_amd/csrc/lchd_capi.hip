@@ -894,6 +894,7 @@ static void carve_pass(Arena& ar, int64_t n_a, int cells_a, int64_t envs_a, int6
         b.env.set_stride = (int64_t)(ne * (size_t)cap);
         b.env.cat = ar.take<uint8_t>(ne * (size_t)cap * (cat16 ? 2 : 1));
         b.env.len = ar.take<int32_t>(ne);
+        b.env.cat0 = (cap == kEnvGroupCap && !cat16) ? ar.take<uint8_t>(ne) : nullptr;  // (written by k_env_group only: prims_enqueue drops it otherwise)
         b.env.stride = cap;
         b.env.cdf_keys = 0;
         b.env.cat16 = cat16 ? 1 : 0;
@@ -978,6 +979,7 @@ static int prims_enqueue(lchd_ctx* c) {
     carve_pass(ar, a->n, ga.n_cells, max_env_a, b->n, gb.n_cells, max_env_b, cap, n_pairs, pb, cat16, key_sets);
     SideBufs &sa = pb.a, &sb = pb.b;
     sa.env.cdf_keys = sb.env.cdf_keys = dict_sets ? 0 : key_sets;  // (what the environment kernels write into set 0)
+    if (!group) sa.env.cat0 = sb.env.cat0 = nullptr;
 
     auto grid_view = [](const GridPlan& g, const SideBufs& s) {
         GridView v{};

@@ -165,6 +165,8 @@ struct EnvStore {
                        // sweep needs no CDF evaluation: a pair reads the set of its weight function); 0: keys are the distances
     int32_t cat16;     // 1: `cat` holds 16-bit category ids (more than 255 categories): two bytes per point
     int64_t set_stride;  // elements between two key sets (slots x stride); categories and lengths exist once
+    uint8_t* cat0;       // [slots] category of every environment's first (sorted) point, or null: what k_pair_meta puts into the pair records -- one
+                         // gather into a small array instead of one into the store itself (k_env_group writes it; the other environment kernels do not)
 };
 constexpr int kMaxKeySets = 4;  // weight-function dictionaries of up to 4 entries get one key set each (k_env_group); larger ones keep distance keys
 

@@ -108,8 +108,12 @@ void env_group_overflow(const LCHD_AS4 EnvSide* p, DeviceStatus* st, int side, i
     p->env.len[e] = 1;
     p->env.key[(uint32_t)e << 9] = 0ull;  // distance 0 = F(0) bits for the weight functions of cdfs.rs (all start at 0)
     p->env.cat[(uint32_t)e << 9] = (int)cat < n_cat ? (uint8_t)cat : (uint8_t)0;
+    if (p->env.cat0) p->env.cat0[e] = (int)cat < n_cat ? (uint8_t)cat : (uint8_t)0;
 }
 
+#ifndef LCHD_CAT0_STORE
+#define LCHD_CAT0_STORE 1
+#endif
 #ifndef LCHD_GROUP_WPB
 #define LCHD_GROUP_WPB 1   // independent wavefronts per workgroup (each with its own LDS block; no workgroup barrier anywhere)
 #endif
@@ -478,7 +482,13 @@ __global__ __launch_bounds__(64 * LCHD_GROUP_WPB) __attribute__((amdgpu_waves_pe
                     okey[(uint32_t)(((e_first + (int)q) << 9) + (i - (int)lds.gstart[q]))] = lds.key[i];
                 }
             }
-            if (lf < G) p->env.len[e_first + lf] = (int32_t)lds.gcount[lf];
+            if (lf < G) {
+                p->env.len[e_first + lf] = (int32_t)lds.gcount[lf];
+#if LCHD_CAT0_STORE
+                const uint32_t c0 = (uint32_t)lds.val[lds.gstart[lf]] & 0xFFu;  // (the sorted first point's category, as it was stored)
+                if (p->env.cat0) p->env.cat0[e_first + lf] = (int)c0 < n_cat ? (uint8_t)c0 : (uint8_t)0;
+#endif
+            }
         }
         wave_sync_lds();  // (gstart / gcount / key are rewritten by the next group)
         fill = 0;

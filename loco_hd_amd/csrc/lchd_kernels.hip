@@ -3965,6 +3965,9 @@ __global__ void k_pair_meta(SweepArgs args) {
                 if (args.env_a.cat16) {
                     c0a = reinterpret_cast<const uint16_t*>(args.env_a.cat)[ea * args.env_a.stride];
                     c0b = reinterpret_cast<const uint16_t*>(args.env_b.cat)[eb * args.env_b.stride];
+                } else if (args.env_a.cat0 && args.env_b.cat0) {  // (the grouped environment kernel's header array: L2-resident, unlike the store)
+                    c0a = args.env_a.cat0[ea];
+                    c0b = args.env_b.cat0[eb];
                 } else {
                     c0a = args.env_a.cat[ea * args.env_a.stride];
                     c0b = args.env_b.cat[eb * args.env_b.stride];
