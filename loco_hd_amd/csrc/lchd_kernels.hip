@@ -510,6 +510,9 @@ static bool fits_struct_path(const PrepSide& P, const Tuning& t, CloudView& cs) 
            (int64_t)cs.n_struct * cs.struct_size == P.c.n && (cs.n_struct >= 8 || cs.struct_size <= 4096);
 }
 
+#ifndef LCHD_STRUCT_NT
+#define LCHD_STRUCT_NT 512   // (measured, C4 cell lists: 128 0.506, 256 0.466, 512 0.445 ms per step) threads of the per-structure cell-list workgroups of a batch of more than 16 structures
+#endif
 int launch_prologue(hipStream_t s, const Tuning& t, const int64_t* anchors, int64_t n_pairs, const PrepSide& a_in, const PrepSide& b_in,
                     void* zero_base, size_t zero_bytes, DeviceStatus* st, bool same) {
     PrepSide a = a_in, b = b_in;
@@ -546,7 +549,7 @@ int launch_prologue(hipStream_t s, const Tuning& t, const int64_t* anchors, int6
             k_cells_struct2<1024><<<nsa + nsb + nz, 1024, lds, s>>>(sa_, sb_, nsa, nsb, zb, zw);
         } else {
             const int nz = fold_zero ? (int)std::min<int64_t>(1024, (zw + 1023) / 1024) : 0;
-            k_cells_struct2<256><<<nsa + nsb + nz, 256, lds, s>>>(sa_, sb_, nsa, nsb, zb, zw);
+            k_cells_struct2<LCHD_STRUCT_NT><<<nsa + nsb + nz, LCHD_STRUCT_NT, lds, s>>>(sa_, sb_, nsa, nsb, zb, zw);
         }
         ++ops;
     }
