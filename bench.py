@@ -895,6 +895,17 @@ def run_pairs(args, torch, dist, dev, rank, world, use_dist):
                               **collective_note(args, world, use_dist)})
         result["roofline"] = roofline_block(args.workload, dom_name, algo_bytes, phase_ms[dom], step_ms=result["ms_per_step"])
         result["kernel_ms"] = phase_ms
+        if strong:
+            # what the plan cache keeps OUT of the timed steps: one uncached plan + select of this rank's share (two partition kernels and
+            # the host's wait for the counts), timed once here so that cached and uncached (--no-plan-cache) lines can be compared
+            torch.cuda.synchronize()
+            t_plan = time.perf_counter()
+            select_shard(anchors, w["n"], world, rank, session=sess, n_atoms_b=w["n"], cache=False)
+            torch.cuda.synchronize()
+            result["config"]["plan_cache"] = not args.no_plan_cache
+            result["config"]["plan_ms"] = (time.perf_counter() - t_plan) * 1e3
+            result["config"]["plan_note"] = ("the partition of the unchanged pair list is planned once and reused (dist.select_shard(cache=True)): "
+                                             "plan_ms is NOT inside ms_per_step" if not args.no_plan_cache else "planned in every timed step")
         result["extras"] = extras
         if value_incl is not None:
             result["value_incl_h2d_d2h"] = value_incl

@@ -48,7 +48,7 @@ typedef struct {
 
 /* The fields of `struct LoCoHD` (src/locohd.rs:42-55) that the scoring path reads. */
 typedef struct {
-    int32_t n_categories;            /* categories.len() (:312-316); this build: 1..512 */
+    int32_t n_categories;            /* categories.len() (:312-316); this build: 1..65534 (16-bit ids on the device) */
     const double *category_weights;  /* [n_categories], all > 0 (:319-346) */
     int32_t n_weight_functions;      /* 1 for WeightFunctionOptions::Single, dict size for ::Multiple (:27-32) */
     const lchd_weight_function *weight_functions;

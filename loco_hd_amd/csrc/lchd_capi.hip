@@ -1198,9 +1198,27 @@ static int finish_passes(lchd_ctx* c, uint32_t* flags_out) {
                 c->group_small = false;  // the small instantiation of k_env_group overflowed: the same capacity with the regular one
                 c->last_biggest = std::max<int64_t>(biggest, kEnvGroupCapSmall + 1);  // (also when LCHD_ENV_GROUP_SMALL=1 forces the small one)
             } else {
+                // The companion sweep for the larger pairs was left out (the previous pass of this context had none): if this pass has
+                // some, their scores were never written -- the whole pass again with the full launch set BEFORE the second pass over
+                // the overflowed environments' pairs keeps the first pass's scores of everything else.
+                if ((P.sweep_info & 2) && c->h_status->n_small != ~0ull) {
+                    const unsigned long long taken = (P.sweep_info & 1) ? c->h_status->n_c8 : c->h_status->n_duo;
+                    if (taken < (unsigned long long)P.n_pairs) {
+                        c->sweep_hint &= ~(8 | 16);
+                        if (int rc = prims_enqueue(c)) return rc;
+                        continue;
+                    }
+                }
+                // what the pairs of THIS pass looked like (the second pass overwrites the mirror with its selection's numbers)
+                const HostStatus first = *c->h_status;
                 bool handled = false;
                 if (int rc = rescore_overflow_pairs(c, f, biggest, &handled, flags_out)) return rc;
-                if (handled) return LCHD_OK;
+                if (handled) {
+                    if (!P.subset && first.n_small != ~0ull)  // the next call of this configuration starts from the first pass's launch set
+                        c->sweep_hint = 4 | (2 * first.n_duo >= (unsigned long long)P.n_pairs ? 1 : 0) |
+                                        (2 * first.n_c8 >= (unsigned long long)P.n_pairs ? 2 : 0);
+                    return LCHD_OK;
+                }
                 // (candidate-table overflows reported an upper bound -- candidates, ~2.4 environments' worth on a uniform cloud --: the whole
                 //  pass tries the slot size that would fit a typical share of them first; a subset's few slots take the bound itself)
                 const int64_t bound = c->h_status->max_bound;
@@ -2027,7 +2045,7 @@ static int dense_pass(lchd_ctx* c, const lchd_cloud& a, const lchd_cloud& b, con
         return s2 * (1.0 + 1e-9) + 1e-300;
     };
     c->last_dense_fused = false;
-    // The common configuration (Hellinger-2, unit category weights, <= 16 categories, rows of 1025 .. 32768 points): sort and
+    // The common configuration (Hellinger-2, unit category weights, <= 16 categories, rows of 1025 .. 20480 points = kDenseFusedMaxRow): sort and
     // sweep in ONE kernel per row pair, nothing but the score is written (lchd_dense_fused.hip).  No environment store.
     if (!old_rows && !c->tune.no_dense_fused && !cat16 && c->hellinger2 && unit_weights_for_dense(c) &&
         dense_fused_applies(c->h_cfg.n_categories, cols_a, cols_b)) {

@@ -4228,7 +4228,7 @@ void init_device_kernels() {
     raise(reinterpret_cast<const void*>(&k_sweep_wide<MODE_H2W, F_ANY, 1, true>), kWideCategories * 256);
     raise(reinterpret_cast<const void*>(&k_prologue_fused), kStructCellsMax * 4 + kStructAtomsMax * 4);  // + ~3 KB static: above 64 KB in total
     raise(reinterpret_cast<const void*>(&k_cells_struct2<1024>), kStructCellsMax * 4 + kStructAtomsMax * 4);
-    raise(reinterpret_cast<const void*>(&k_cells_struct2<256>), kStructCellsMax * 4 + kStructAtomsMax * 4);
+    raise(reinterpret_cast<const void*>(&k_cells_struct2<LCHD_STRUCT_NT>), kStructCellsMax * 4 + kStructAtomsMax * 4);
     (void)hipGetLastError();
 }
 

@@ -236,6 +236,9 @@ class DeviceSession:
 
     def close(self):
         if self._ctx:
+            from .dist import clear_shard_cache
+
+            clear_shard_cache(self)  # remembered partitions made with this session pin device tensors
             for h in self._clouds:
                 N.lib().lchd_cloud_destroy(self._ctx, h)
             self._clouds = []

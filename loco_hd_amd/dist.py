@@ -66,28 +66,42 @@ def shard_rule(anchors, n_atoms_a: int, world: int, n_atoms_b: Optional[int] = N
 # Partitions of pair lists that were seen before (select_shard(..., cache=True)).  The rule is a pure function of the list, so a
 # caller that scores the SAME list again -- the frames of a trajectory, the rounds of a permutation test, the steps of bench.py --
 # neither reads it twice per call nor launches the two partition kernels again.  An entry is valid for the very tensor object it
-# was made from (kept alive by the entry) and only while that tensor has not been written to (torch's version counter).
-_PLAN_CACHE: dict = {}
-_PLAN_CACHE_MAX = 16
+# was made from (kept alive by the entry) and only while that tensor has not been written to THROUGH TORCH (its version counter).
+# Limits, by construction: a write that bypasses torch's versioning -- a kernel writing through data_ptr() (this library's own
+# ctypes calls do), NumPy memory shared with a CPU tensor -- is NOT seen and the stale partition would put scores at the wrong
+# positions: callers that fill pair lists that way pass cache=False (the default) or call clear_shard_cache().  Entries pin their
+# tensors (the list, the selection, the positions) until they are evicted, cleared, or their session is closed
+# (DeviceSession.close drops the entries of that session); eviction is least-recently-used with room for
+# max(16, 2 x world) entries (one per emulated rank and session of bench.py --emulate-world).
+_PLAN_CACHE: "dict" = {}
+_PLAN_CACHE_MIN = 16
 
 
-def clear_shard_cache() -> None:
-    _PLAN_CACHE.clear()
+def clear_shard_cache(session=None) -> None:
+    """Drop every remembered partition (session=None) or those made with one DeviceSession."""
+    if session is None:
+        _PLAN_CACHE.clear()
+        return
+    for key in [k for k in _PLAN_CACHE if k[5] == id(session)]:
+        del _PLAN_CACHE[key]
 
 
 def select_shard(anchors, n_atoms_a: int, world: int, rank: int, session=None, n_atoms_b: Optional[int] = None, cache: bool = False):
     """This rank's pairs: (sel_anchors [n][2], sel_index [n] = positions in the full list, counts of every rank).
 
     cache=True: the result is remembered per (tensor object, its version, world, rank, structure sizes, session) and returned
-    again -- the same tensors, do not modify them -- while `anchors` is unchanged."""
+    again -- the same tensors, do not modify them -- while `anchors` is unchanged AS FAR AS TORCH CAN TELL (see the note above
+    _PLAN_CACHE: writes through raw pointers are not detected)."""
     if cache:
         key = (id(anchors), world, rank, int(n_atoms_a), int(n_atoms_b or 0), id(session))
         hit = _PLAN_CACHE.get(key)
         if hit is not None and hit[0] is anchors and hit[1] == anchors._version:
+            _PLAN_CACHE[key] = _PLAN_CACHE.pop(key)  # most recently used last
             return hit[2]
         res = select_shard(anchors, n_atoms_a, world, rank, session, n_atoms_b, cache=False)
-        if len(_PLAN_CACHE) >= _PLAN_CACHE_MAX:
-            _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
+        _PLAN_CACHE.pop(key, None)
+        while len(_PLAN_CACHE) >= max(_PLAN_CACHE_MIN, 2 * world):
+            _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))  # least recently used first
         _PLAN_CACHE[key] = (anchors, anchors._version, res)
         return res
     import torch

@@ -162,3 +162,19 @@ def test_partition_cache_follows_the_tensor():
     assert torch.equal(changed[0], want[0]) and torch.equal(changed[1], want[1])
     clone = anchors.clone()
     assert D.select_shard(clone, 5000, 4, 1, n_atoms_b=5000, cache=True)[0] is not changed[0]
+    # least-recently-used eviction with room for max(16, 2 x world) entries: 40 emulated ranks all stay cached ...
+    D.clear_shard_cache()
+    small = torch.randint(0, 500, (4000, 2), generator=g, dtype=torch.int64)
+    firsts = [D.select_shard(small, 500, 40, r, n_atoms_b=500, cache=True) for r in range(40)]
+    assert all(D.select_shard(small, 500, 40, r, n_atoms_b=500, cache=True)[0] is firsts[r][0] for r in range(40))
+    # ... a recently used entry survives newcomers that evict older ones, and a session's entries go with clear_shard_cache(session)
+    D.clear_shard_cache()
+    keep = D.select_shard(small, 500, 4, 0, n_atoms_b=500, cache=True)
+    for k in range(20):
+        D.select_shard(small.clone(), 500, 4, 0, n_atoms_b=500, cache=True)
+        assert D.select_shard(small, 500, 4, 0, n_atoms_b=500, cache=True)[0] is keep[0]
+    assert len(D._PLAN_CACHE) <= 16
+    D.clear_shard_cache(session=object())  # (no entry belongs to it)
+    assert D.select_shard(small, 500, 4, 0, n_atoms_b=500, cache=True)[0] is keep[0]
+    D.clear_shard_cache(session=None)
+    assert D.select_shard(small, 500, 4, 0, n_atoms_b=500, cache=True)[0] is not keep[0]

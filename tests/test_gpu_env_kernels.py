@@ -343,6 +343,56 @@ def test_a_dense_cluster_in_a_sparse_cloud_rescoring_only_its_pairs(lh, oracle, 
     assert wcounts[0]["store_bytes"] >= 4 * counts[0]["store_bytes"]
 
 
+def test_overflow_after_an_all_small_call_keeps_the_larger_pairs(lh, oracle):
+    """A session whose previous call had only small pairs (sparse cloud: every pair fits the four-pairs-per-wavefront sweep) launches
+    the next pass without the companion sweep for larger pairs.  When that next call has BOTH an overflowed cluster (second pass over
+    its pairs) and medium environments (~170 points per side: more merged events than the team tile), the medium pairs must still be
+    scored: the whole pass is repeated with the full launch set before the cluster's pairs are scored again (the reference has one
+    code path for every environment size, src/locohd.rs:514-557)."""
+    import torch
+    from loco_hd_amd.device import DeviceSession
+
+    n_cat = 6
+    cats = [f"c{i}" for i in range(n_cat)]
+
+    def cloud(seed):
+        rng = np.random.default_rng(seed)
+        n_sparse, n_medium, n_cluster = 40_000, 3_000, 2_500
+        side = (n_sparse / 0.0025) ** (1 / 3)
+        sparse = rng.uniform(0.0, side, (n_sparse, 3))
+        medium = rng.uniform(0.0, 42.0, (n_medium, 3)) + np.array([-120.0, 0.0, 0.0])
+        v = rng.normal(0.0, 1.0, (n_cluster, 3))
+        cluster = np.array([0.0, -120.0, 0.0]) + v / np.linalg.norm(v, axis=1)[:, None] * (4.5 * rng.uniform(0, 1, (n_cluster, 1)) ** (1 / 3))
+        xyz = np.concatenate([sparse, medium, cluster])
+        return xyz, rng.integers(0, n_cat, len(xyz)).astype(np.int32), np.zeros(len(xyz), np.int32), n_sparse, n_medium, n_cluster
+
+    xa, ca, ta, ns, nm, nc = cloud(11)
+    xb, cb, tb, _, _, _ = cloud(12)
+    rng = np.random.default_rng(13)
+    n_pairs = 6000
+    small = np.stack([rng.integers(0, ns, n_pairs), rng.integers(0, ns, n_pairs)], 1).astype(np.int64)
+    mixed = small.copy()
+    mixed[:800] = ns + rng.integers(0, nm, (800, 2))                     # medium environments on both sides
+    mixed[800:860, 0] = ns + nm + rng.integers(0, nc, 60)                # cluster anchors (overflow their 512-point slots)
+    mixed[860:900, 1] = ns + nm + rng.integers(0, nc, 40)
+    rng.shuffle(mixed)
+    lo = oracle.LoCoHD(cats, oracle.WeightFunction("hyper_exp", [1.0, 0.1]))
+    want_small = np.asarray(lo.from_arrays(xa, ca, ta, xb, cb, tb, small, 10.0))
+    want_mixed = np.asarray(lo.from_arrays(xa, ca, ta, xb, cb, tb, mixed, 10.0))
+    sess = DeviceSession(lh.LoCoHD(cats, lh.WeightFunction("hyper_exp", [1.0, 0.1])))
+    a, b = sess.upload(xa, ca, ta), sess.upload(xb, cb, tb)
+    d_small, d_mixed = torch.from_numpy(small).cuda(), torch.from_numpy(mixed).cuda()
+    for _ in range(2):  # the second call runs on the hint of the first: no companion sweep
+        assert np.max(np.abs(sess.from_primitives(a, b, d_small, 10.0).cpu().numpy() - want_small)) < TIGHT
+    out = torch.full((n_pairs,), -7.0, dtype=torch.float64, device="cuda")  # (a stale value would show)
+    got = sess.from_primitives(a, b, d_mixed, 10.0, out=out).cpu().numpy()
+    assert np.max(np.abs(got - want_mixed)) < TIGHT
+    for _ in range(2):  # and the steady state of the mixed workload
+        assert np.max(np.abs(sess.from_primitives(a, b, d_mixed, 10.0).cpu().numpy() - want_mixed)) < TIGHT
+    assert np.max(np.abs(sess.from_primitives(a, b, d_small, 10.0).cpu().numpy() - want_small)) < TIGHT
+    sess.close()
+
+
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("LCHD_OVERFLOW_SEEDS", "6"))))  # (a one-off campaign: LCHD_OVERFLOW_SEEDS=200)
 def test_overflowed_environments_random_configurations(lh, oracle, seed):
     """Random clouds with one to three dense clusters (600 ... 5000 points) in a sparse background, random thresholds, pair lists that
