@@ -239,6 +239,16 @@ int64_t lchd_ctx_last_env_points(lchd_ctx *ctx);
  * call, nothing but the scores written: Hellinger-2, unit category weights, at most 16 categories, rows of 1 025 .. 20 480
  * points), 0 if it ran the row sort followed by the sweep (src/locohd.rs:410-476 either way). */
 int32_t lchd_ctx_last_dense_fused(lchd_ctx *ctx);
+/* Determinism switch.  The reference is ONE code path (src/locohd.rs:61-226): the same anchor pair gives the same bits whatever
+ * else the call holds.  By default this library picks among several sweep kernels per call -- from the call's size, from what the
+ * majority of its pairs look like and from the statistics of the context's previous pass -- and they sum a pair's intervals in
+ * different per-lane orders: the same pair can differ by <= 1e-13 between calls of different shape or history.
+ * on != 0 pins ONE sweep family (one pair per wavefront, global-memory tables; dense rows through the row sort + that sweep) and
+ * switches every history-dependent choice off: a pair's score is then a function of the pair and the configuration alone --
+ * bitwise equal across batch composition, call order, sharding and second passes -- at roughly half the default throughput.
+ * on == 0 returns to the default selection.  Not allowed while an asynchronous call is pending. */
+int lchd_ctx_set_deterministic(lchd_ctx *ctx, int32_t on);
+int32_t lchd_ctx_get_deterministic(lchd_ctx *ctx);
 /* from_primitives passes the context has enqueued since it was created.  A call is one pass in the steady state; a pass is
  * repeated when an environment overflowed the capacity tried (src/locohd.rs:514-542 has no capacity) or when the sweep launch
  * set picked from the previous call's pair statistics did not cover this call's pairs. */

@@ -97,6 +97,8 @@ _PROTOS = {
     "lchd_ctx_last_ms": (C.c_double, [_VP, C.c_char_p]),
     "lchd_ctx_last_env_points": (C.c_int64, [_VP]),
     "lchd_ctx_last_dense_fused": (C.c_int32, [_VP]),
+    "lchd_ctx_set_deterministic": (C.c_int, [_VP, _i32]),
+    "lchd_ctx_get_deterministic": (C.c_int32, [_VP]),
     "lchd_ctx_pass_count": (C.c_int64, [_VP]),
     "lchd_ctx_subset_pass_count": (C.c_int64, [_VP]),
     "lchd_ctx_last_store_bytes": (C.c_int64, [_VP]),

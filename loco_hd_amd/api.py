@@ -211,13 +211,16 @@ class LoCoHD:
     ``devices`` (keyword-only, additive): a list of HIP device ordinals -- the counterpart of the reference's thread pool,
     which is a field of the instance (src/locohd.rs:53,373-383): ``from_primitives`` then spreads the anchor pairs of every
     call over these GPUs inside the C library (lchd_group_from_primitives), results in anchor-pair order as always.
+    ``deterministic`` (keyword-only, additive): pin ONE sweep kernel family (lchd_ctx_set_deterministic) -- like the reference's
+    single code path (src/locohd.rs:61-226) a pair's score is then bitwise independent of the other pairs of the call and of what
+    the instance scored before, at about half the default throughput; the default picks kernels per call (<= 1e-13 apart).
     """
 
     def __init__(self, categories: Sequence[str], w_func: Union[None, WeightFunction, Dict[str, WeightFunction]] = None,
                  tag_pairing_rule: Optional[TagPairingRule] = None, n_of_threads: Optional[int] = None,
                  category_weights: Optional[Sequence[float]] = None,
                  statistical_distance: Optional[StatisticalDistance] = None, *, device: Optional[int] = None,
-                 devices: Optional[Sequence[int]] = None) -> None:
+                 devices: Optional[Sequence[int]] = None, deterministic: bool = False) -> None:
         names = [str(c) for c in categories]
         cat_map: Dict[str, int] = {}
         for i, nm in enumerate(names):  # :312-316 HashMap collect: a repeated name keeps its last index
@@ -247,6 +250,9 @@ class LoCoHD:
             raise ValueError("devices must name at least one HIP device")
         if self._devices is not None and device is None:
             self._device = self._devices[0]  # the single-device entry points (from_anchors, from_dmxs, from_coords)
+        self._deterministic = bool(deterministic)
+        if self._deterministic and self._devices is not None and len(self._devices) > 1:
+            raise ValueError("deterministic=True applies to one device (the device group picks kernels per share)")
         self._ctx = None
         self._group = None
         self._pack_cache: List[Any] = []   # most recent first: (list, its items, mutation stamp, parent entry, packed, interner)
@@ -276,6 +282,8 @@ class LoCoHD:
             h = C.c_void_p()
             N.check(N.lib().lchd_ctx_create(self._device, C.byref(h)))
             self._ctx = h
+            if self._deterministic:
+                N.check(N.lib().lchd_ctx_set_deterministic(h, 1))
         return self._ctx
 
     def _device_group(self):

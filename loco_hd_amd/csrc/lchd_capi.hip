@@ -164,6 +164,8 @@ struct lchd_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     Tuning tune{};  // LCHD_* test / tuning hooks, read once in lchd_ctx_create
+    Tuning tune_env{};  // ... as read from the environment (lchd_ctx_set_deterministic(0) returns to them)
+    bool deterministic = false;
     // configuration
     bool cfg_set = false;
     bool hellinger2 = false, unit_weights = false, wf_pow = false;  // which sweep kernel variant applies
@@ -345,7 +347,7 @@ extern "C" int lchd_ctx_create(int32_t device, lchd_ctx** out) {
     HIP_TRY(hipGetDevice(&cur));
     lchd_ctx* c = new lchd_ctx();
     c->device = device >= 0 ? device : cur;
-    c->tune = tuning_from_env();
+    c->tune = c->tune_env = tuning_from_env();
     if (c->tune.cap_hint > 0) c->cap_hint = c->tune.cap_hint;
     CTX_GUARD(c);  // the caller's current device is restored on every path out of here
     auto bail = [&](hipError_t err, const char* what) {
@@ -430,6 +432,27 @@ extern "C" int64_t lchd_ctx_last_env_points(lchd_ctx* c) {
     if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
     return (int64_t)v;
 }
+
+// One sweep family for every pair: the one-pair-per-wavefront k_sweep that reads its square-root tables from global memory (tiles
+// and per-lane chunks are functions of the pair alone), behind the row-sort kernels for dense rows.  No team sweeps, no
+// one-launch small-call sweep, no launch-set hints from earlier passes, no fused dense kernel, no O(1) Kullback-Leibler / Renyi
+// form: a pair's score then depends on the pair and the configuration only -- not on the other pairs of the call, on what the
+// context scored before, or on whether the pair was reached through a second pass.  (Environments of more than 65 535 points
+// still take the 64-bit-count sweep, whatever the mode.)
+extern "C" int lchd_ctx_set_deterministic(lchd_ctx* c, int32_t on) {
+    if (!c) return fail(LCHD_EVALUE, "null context");
+    if (c->pend.active) return fail(LCHD_EVALUE, "an asynchronous call has not been finished (lchd_ctx_finish)");
+    c->deterministic = on != 0;
+    c->tune = c->tune_env;
+    if (c->deterministic) {
+        Tuning& t = c->tune;
+        t.no_duo = t.no_count8 = t.no_c8_team = t.no_inline_meta = t.force_bigenv = t.no_dense_fused = t.no_sd_inc = t.no_sweep_hint = true;
+        t.sweep_grid = 0;
+    }
+    c->sweep_hint = 0;
+    return LCHD_OK;
+}
+extern "C" int32_t lchd_ctx_get_deterministic(lchd_ctx* c) { return (c && c->deterministic) ? 1 : 0; }
 
 extern "C" int32_t lchd_ctx_last_dense_fused(lchd_ctx* c) { return (c && c->last_dense_fused) ? 1 : 0; }
 extern "C" int64_t lchd_ctx_pass_count(lchd_ctx* c) { return c ? c->n_passes : -1; }

@@ -30,12 +30,19 @@ class DeviceSession:
         N.check(N.lib().lchd_ctx_create(self.device, C.byref(self._ctx)))
         self._cfg, self._keep = lchd._config(interner)
         N.check(N.lib().lchd_ctx_set_config(self._ctx, C.byref(self._cfg)))
+        if getattr(lchd, "_deterministic", False):
+            self.set_deterministic(True)
         self.use_current_stream()
         self._clouds = []
 
     def use_current_stream(self):
         s = self.torch.cuda.current_stream(self.device).cuda_stream
         N.check(N.lib().lchd_ctx_set_stream(self._ctx, C.c_void_p(s)))
+
+    def set_deterministic(self, on: bool = True):
+        """Pin one sweep kernel family (lchd_ctx_set_deterministic): a pair's score then depends on the pair and the configuration
+        only, bit for bit, whatever the batch, the call history or the sharding -- at about half the default throughput."""
+        N.check(N.lib().lchd_ctx_set_deterministic(self._ctx, int(bool(on))))
 
     def enable_timing(self, on: bool = True):
         N.lib().lchd_ctx_enable_timing(self._ctx, int(on))

@@ -774,3 +774,71 @@ def test_weight_function_dictionary_through_the_team_sweeps(lh, oracle, density,
     bad[777] = -1
     with pytest.raises(ValueError):
         run(bad)
+
+
+def test_deterministic_switch_makes_a_pairs_score_independent_of_batch_and_history(lh, oracle):
+    """lchd_ctx_set_deterministic (LoCoHD(..., deterministic=True), DeviceSession.set_deterministic): the reference is one code
+    path (src/locohd.rs:61-226), so a pair's score cannot depend on the other pairs of the call.  With the switch on, the same
+    probe pairs give the SAME BITS inside a list of small pairs, inside a list of large pairs, alone in a small call, after a
+    different call history, reached through a second pass over overflowed environments, and from from_anchors-style single calls
+    of the host API; with it off the calls still agree to 1e-13 and both match the oracle."""
+    import torch
+    from loco_hd_amd.device import DeviceSession
+
+    rng = np.random.default_rng(2024)
+    n_cat = 9
+    cats = [f"c{i}" for i in range(n_cat)]
+    n_sparse, n_dense, n_cluster = 30_000, 6_000, 1_500
+    side = (n_sparse / 0.0025) ** (1 / 3)
+
+    def cloud():
+        v = rng.normal(0.0, 1.0, (n_cluster, 3))
+        xyz = np.concatenate([rng.uniform(0.0, side, (n_sparse, 3)),                                   # ~10 points per environment
+                              rng.uniform(0.0, 53.0, (n_dense, 3)) + np.array([-150.0, 0.0, 0.0]),    # ~170 points per environment
+                              np.array([0.0, -150.0, 0.0]) + v / np.linalg.norm(v, axis=1)[:, None] * (4.0 * rng.uniform(0, 1, (n_cluster, 1)) ** (1 / 3))])
+        return xyz, rng.integers(0, n_cat, len(xyz)).astype(np.int32), np.zeros(len(xyz), np.int32)
+
+    xa, ca, ta = cloud()
+    xb, cb, tb = cloud()
+    n = 6000
+    sparse_pairs = np.stack([rng.integers(0, n_sparse, n), rng.integers(0, n_sparse, n)], 1).astype(np.int64)
+    dense_pairs = n_sparse + np.stack([rng.integers(0, n_dense, n), rng.integers(0, n_dense, n)], 1).astype(np.int64)
+    probes = np.concatenate([sparse_pairs[:40], dense_pairs[:40],
+                             np.stack([n_sparse + rng.integers(0, n_dense, 10), rng.integers(0, n_sparse, 10)], 1)]).astype(np.int64)
+    cluster_pairs = np.stack([n_sparse + n_dense + rng.integers(0, n_cluster, 25), rng.integers(0, n_sparse, 25)], 1).astype(np.int64)
+    want = np.asarray(oracle.LoCoHD(cats, oracle.WeightFunction("hyper_exp", [1.0, 0.1])).from_arrays(xa, ca, ta, xb, cb, tb, probes, 10.0))
+
+    def lists():
+        k = len(probes)
+        in_sparse = sparse_pairs.copy(); in_sparse[100:100 + k] = probes
+        in_dense = dense_pairs.copy(); in_dense[2000:2000 + k] = probes
+        with_cluster = sparse_pairs.copy(); with_cluster[300:300 + k] = probes; with_cluster[1000:1025] = cluster_pairs
+        return [(in_sparse, 100), (in_dense, 2000), (probes.copy(), 0), (with_cluster, 300), (in_sparse, 100)]
+
+    results = {}
+    for det in (True, False):
+        sess = DeviceSession(lh.LoCoHD(cats, lh.WeightFunction("hyper_exp", [1.0, 0.1]), deterministic=det))
+        a, b = sess.upload(xa, ca, ta), sess.upload(xb, cb, tb)
+        got = []
+        for pairs, at in lists():
+            out = sess.from_primitives(a, b, torch.from_numpy(pairs).cuda(), 10.0).cpu().numpy()
+            got.append(out[at:at + len(probes)])
+        if det:
+            assert sess.pass_counts()["subset_passes"] >= 1  # (the cluster's pairs went through a second pass)
+        sess.close()
+        results[det] = got
+        for g in got:
+            assert np.max(np.abs(g - want)) < 1e-11
+    for g in results[True][1:]:
+        assert np.array_equal(g, results[True][0])  # bit for bit, whatever surrounded the probes
+    for g in results[False]:
+        assert np.max(np.abs(g - results[True][0])) < 1e-13
+    # the host API (lists of PrimitiveAtom in, list of floats out) on a sub-structure: two different call shapes, same bits
+    sub = np.arange(n_sparse, n_sparse + 1500)
+    pa = [lh.PrimitiveAtom(cats[c], "", x) for c, x in zip(ca[sub], xa[sub])]
+    pb = [lh.PrimitiveAtom(cats[c], "", x) for c, x in zip(cb[sub], xb[sub])]
+    det = lh.LoCoHD(cats, lh.WeightFunction("hyper_exp", [1.0, 0.1]), deterministic=True)
+    all_pairs = [(i, i) for i in range(1500)]
+    whole = np.asarray(det.from_primitives(pa, pb, all_pairs * 4, 10.0))[:1500]  # 6000 pairs: the regular pass
+    few = np.asarray(det.from_primitives(pa, pb, all_pairs[:64], 10.0))          # 64 pairs: would be the one-launch sweep by default
+    assert np.array_equal(whole[:64], few)

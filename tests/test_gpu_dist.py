@@ -152,3 +152,31 @@ def test_device_group_of_the_c_abi(setup, oracle):
     got = lh.LoCoHD(s["cats"], multi, devices=[0, 0]).from_primitives(prims(lh, s["xa"], s["ca"]), prims(lh, s["xb"], s["cb"]), keyed, 9.0)
     want = oracle.LoCoHD(s["cats"], omulti).from_primitives(prims(oracle, s["xa"], s["ca"]), prims(oracle, s["xb"], s["cb"]), keyed, 9.0)
     assert np.max(np.abs(np.asarray(got) - np.asarray(want))) < TIGHT
+
+
+@pytest.mark.parametrize("workload,extra", [("c2a", ["--pairs", "200000"]), ("c5", ["--pairs", "200000"]), ("c3", [])])
+def test_bench_strong_scaling_line_under_a_forced_process_group(workload, extra):
+    """The first real multi-GPU run of bench.py must not die on plumbing: `--scaling strong` with the RCCL process group, the
+    per-step asynchronous gather and the restore of anchor-pair order forced on ONE rank (LCHD_BENCH_FORCE_DIST=1).  The JSON line
+    carries the collective, the roofline block and the plan-cache note; bench.py itself asserts that the gathered + restored
+    scores equal a single pass over the whole list (src/locohd.rs:545-557: results in pair order)."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, LCHD_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29800 + os.getpid() % 150),
+               WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    cmd = [sys.executable, str(root / "bench.py"), "--workload", workload, "--scaling", "strong", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", *extra]
+    run = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stderr[-3000:]
+    line = json.loads(run.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert "RCCL gather" in line["config"]["collective"]
+    for key in ("bound", "achieved", "peak", "frac", "unit"):
+        assert key in line["roofline"], key
+    assert 0 < line["roofline"]["frac"] < 1.5
+    if workload != "c3":
+        assert line["config"]["plan_cache"] is True and line["config"]["plan_ms"] > 0
