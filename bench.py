@@ -949,7 +949,7 @@ def main():
                     help="multi-GPU: strong (default for --gpus N > 1: BASELINE.json's 8-GPU configurations are fixed-size jobs and its target "
                          "is '>= 6x at 8 GPUs') = the named workload in total, sharded across the GPUs; weak = the named workload per GPU")
     ap.add_argument("--frames", type=int, default=5000, help="c4: frames of the trajectory")
-    ap.add_argument("--chunk", type=int, default=1250, help="c4: frames per scoring pass")
+    ap.add_argument("--chunk", type=int, default=2500, help="c4: frames per scoring pass (measured, ms per step of 5000 frames: 1250 6.26, 2500 5.88, 5000 5.81 -- one pass, nothing streamed)")
     ap.add_argument("--c4-sessions", type=int, default=2, choices=[1, 2],
                     help="c4: sessions the chunks of a step alternate between (2: asynchronous passes, the next chunk converted on a side stream)")
     ap.add_argument("--pairs", type=int, default=1_000_000, help="c2a / c5: anchor pairs (per GPU when weak, in total when strong)")

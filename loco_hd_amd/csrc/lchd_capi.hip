@@ -200,6 +200,15 @@ struct lchd_ctx {
     int64_t last_biggest = 0;  // largest environment of the last pass (0: unknown): anchors per wavefront of k_env_group
     int shrink_votes = 0;  // consecutive passes whose largest environment would fit half of cap_hint
     bool last_dense_fused = false;  // the most recent dense pass ran the fused sort + sweep kernel (lchd_dense_fused.hip)
+    // environment build + sweep in one kernel for side-B environments that are used once (lchd_env_fused.hip): taken when the last
+    // REGULAR pass of the configuration found (almost) every side-B anchor unique; every kFusedRemeasure-th pass is a regular one again
+    // (a fused pass does not de-duplicate side B, so it cannot see the anchors becoming shared)
+    bool b_use_once = false;        // the last regular pass: n_unique[1] >= 0.8 n_pairs
+    int fused_streak = 0;           // fused passes since the last regular one
+    bool fused_companion = true;    // the last fused pass left pairs to the INDIRECT sweep (or nothing is known): launch it
+    bool fused_blocked = false;     // a fused pass of this configuration met an environment beyond its group buffer: the regular pipeline from now on
+    int64_t n_fused_passes = 0;
+    int64_t n_per_pair_passes = 0;  // regular passes whose side B was not de-duplicated
     // second pass over the pairs of overflowed environments (lchd_ctx_finish): grow-only device blocks outside the arena
     char *d_ovf_bits = nullptr, *d_ovf_lists = nullptr;
     size_t ovf_bits_cap = 0, ovf_lists_cap = 0;
@@ -226,6 +235,10 @@ struct lchd_ctx {
         const uint32_t *ovf_a = nullptr, *ovf_b = nullptr;  // overflow lists of the enqueued pass (null: its kernels keep none)
         int64_t n_slots_a = 0, n_slots_b = 0;               // environment slots per side
         bool subset = false;                                // the enqueued pass IS a second pass over the pairs of overflowed environments
+        bool fused = false;                                 // the enqueued pass ran k_env_sweep for side B (no side-B slots, no k_pair_meta)
+        bool fused_no_comp = false;                         // ... without the INDIRECT sweep behind it
+        bool no_fused = false;                              // this call: the regular pipeline only (a fused pass met an overflow)
+        bool per_pair = false;                              // the enqueued pass did not de-duplicate side B (slot p = pair p)
     } pend;
     // multi-GPU sharding helpers (lchd_shard_*): device state, host-mapped counts, the plan they belong to
     ShardState* d_shard = nullptr;
@@ -305,6 +318,9 @@ static Tuning tuning_from_env() {  // the ONLY place that reads LCHD_* hooks (te
     t.no_sd_inc = getenv("LCHD_NO_SD_INC") != nullptr;
     t.force_cmax = env_int("LCHD_FORCE_CMAX", 0);
     t.cap_hint = env_int("LCHD_CAP_HINT", 0);
+    t.fused = env_int("LCHD_FUSED", 0);
+    t.per_pair = env_int("LCHD_PER_PAIR", 0);
+    t.fused_grid = env_int("LCHD_FUSED_GRID", 0);
     return t;
 }
 
@@ -544,6 +560,9 @@ extern "C" int lchd_ctx_set_config(lchd_ctx* c, const lchd_config* cfg) {
     HIP_TRY(hipMemcpy(c->d_blob, blob.data(), total, hipMemcpyHostToDevice));
     c->cfg_set = false;
     c->sweep_hint = 0;  // another configuration: what the last pass looked like says nothing about the next
+    c->b_use_once = false;
+    c->fused_companion = true;
+    c->fused_blocked = false;
     c->cfg_blob_host.swap(sig);
     DevConfig h{};
     h.n_categories = C;
@@ -977,13 +996,37 @@ static int prims_enqueue(lchd_ctx* c) {
     // list and every environment are built once -- the anchors of both columns share side A's flags, slots and store.
     const bool same = (a == b) && !c->tune.no_share;
     const int64_t max_env_a = same ? std::min<int64_t>(a->n, 2 * n_pairs) : std::min<int64_t>(a->n, n_pairs);
-    const int64_t max_env_b = same ? 0 : std::min<int64_t>(b->n, n_pairs);
+    int64_t max_env_b = same ? 0 : std::min<int64_t>(b->n, n_pairs);  // (a fused pass: one slot per PAIR, below)
     // (the grouped kernel addresses environment slots and records with 32-bit offsets: the limits of launch_env_group; larger
     //  calls take k_env_cells, which has none)
     const bool group = cap == kEnvGroupCap && !c->tune.no_env_group && a->n < ((int64_t)1 << 27) && b->n < ((int64_t)1 << 27) &&
                        max_env_a < ((int64_t)1 << 22) && max_env_b < ((int64_t)1 << 22) && !cat16;
     P.group = group;
     P.group_small = false;
+    // Side B used once -- (almost) every side-B anchor of the last regular pass of this context was unique: the frames of a trajectory,
+    // (i, i) lists, a rank's partners under strong scaling.  Such a side is not de-duplicated: environment slot p belongs to pair p
+    // and its anchor record comes straight from the pair list (launch_pair_anchor_recs) -- no flags, bit set, scan and scatter over
+    // the side's atoms.  Any choice is correct for any input: an anchor that occurs in several pairs is built once per pair, as the
+    // reference does (src/locohd.rs:514-554).  Every 64th pass is a regular one again (this mode does not count unique anchors).
+    const bool per_pair_ok = group && !same && !P.subset && !c->deterministic && c->tune.per_pair >= 0 && n_pairs < ((int64_t)1 << 22) && n_pairs > 0;
+    bool per_pair = per_pair_ok && (c->tune.per_pair > 0 || (c->b_use_once && !c->fused_blocked && n_pairs > 4096 && c->fused_streak < 64));
+    // ... and, opt-in (LCHD_FUSED=1 / 3: measured SLOWER than the two kernels on every named workload), side B's
+    // environments built, sorted and swept inside ONE kernel (lchd_env_fused.hip): the default configuration only (Hellinger-2, unit
+    // weights, one weight function, CDF keys)
+    int frule = -1;
+    {
+        const int hint = c->tune.no_sweep_hint ? 0 : c->sweep_hint;
+        const bool applies = per_pair_ok && !P.no_fused && c->tune.fused > 0 && c->hellinger2 && c->unit_weights &&
+                             c->h_cfg.n_wf == 1 && !c->tune.no_cdf_keys && !c->tune.no_duo && !c->tune.no_count8 && !c->tune.force_generic &&
+                             !c->tune.force_wide && !c->tune.force_bigenv && fused_applies(std::max(c->h_cfg.n_categories, c->tune.force_cmax));
+        if (applies) frule = c->tune.fused == 3 ? 2 : ((hint & 4) && !(hint & 1) && (hint & 2) ? 2 : 0);
+    }
+    const bool fused = frule >= 0;
+    if (fused) per_pair = true;
+    P.fused = fused;
+    P.per_pair = per_pair;
+    P.fused_no_comp = false;
+    if (per_pair) max_env_b = n_pairs;  // (one slot per PAIR)
     const GridPlan ga = plan_grid(a, thr, group ? 2 : 1), gb = plan_grid(b, thr, group ? 2 : 1);
     // Keys of the store: F(distance) whenever the sweep can use them without evaluating a CDF -- one weight function, or a
     // dictionary of up to kMaxKeySets (src/locohd.rs:230-283: every pair names its function): k_env_group writes one key set per
@@ -1030,13 +1073,17 @@ static int prims_enqueue(lchd_ctx* c) {
         ps.flag8 = sbuf.flag8; ps.bits = sbuf.bits; ps.wpre = sbuf.wpre; ps.chunk_base = sbuf.chunk_base; ps.slot = sbuf.slot; ps.uniq = sbuf.uniq;
         return ps;
     };
-    (void)launch_prologue(s, c->tune, P.anchors, n_pairs, prep_side(cva, gva, sa), prep_side(cvb, gvb, sb), pb.zero_base, pb.zero_bytes,
-                          c->d_status, same);
+    {
+        PrepSide psa = prep_side(cva, gva, sa), psb = prep_side(cvb, gvb, sb);
+        psb.no_anchors = per_pair ? 1 : 0;  // (side B without de-duplication: no flags, no slots -- one environment per pair)
+        (void)launch_prologue(s, c->tune, P.anchors, n_pairs, psa, psb, pb.zero_base, pb.zero_bytes, c->d_status, same);
+        if (per_pair && !fused) launch_pair_anchor_recs(s, P.anchors, n_pairs, psb, c->d_status);  // (k_env_sweep reads the pair list itself)
+    }
     mark(c, 1);
     mark(c, 2);  // (cell lists and anchor de-duplication are one phase now; "anchors" reads 0)
     const bool tag_list = c->h_cfg.tag_mode != 0;
     const EnvSide esa{cva, gva, sa.uniq, sa.env, max_env_a, sa.raw_key, sa.raw_cat, sa.ovf_list},
-                  esb{cvb, gvb, sb.uniq, sb.env, max_env_b, sb.raw_key, sb.raw_cat, sb.ovf_list};
+                  esb{cvb, gvb, sb.uniq, sb.env, fused ? 0 : max_env_b, sb.raw_key, sb.raw_cat, sb.ovf_list};
     P.ovf_a = sa.ovf_list;
     P.ovf_b = sb.ovf_list;
     P.n_slots_a = max_env_a;
@@ -1071,14 +1118,39 @@ static int prims_enqueue(lchd_ctx* c) {
     sw.env_b = same ? sa.env : sb.env;
     sw.anchors = P.anchors;
     sw.slot_a = sa.slot;
-    sw.slot_b = same ? sa.slot : sb.slot;
+    sw.slot_b = same ? sa.slot : (per_pair ? nullptr : sb.slot);  // (nullptr: side B's slot of pair p is p)
     sw.n_slot_a = a->n;
     sw.n_slot_b = b->n;
     sw.wf_index = P.wf;
     sw.n_pairs = n_pairs;
     sw.out = P.out;
     sw.meta = pb.pair_meta;
-    P.sweep_info = launch_sweep(s, c->tune, c->h_cfg.n_categories, c->hellinger2, c->unit_weights, c->wf_pow, c->sweep_hint, sw);
+    if (fused) {
+        FusedArgs fa{};
+        fa.cfg = c->d_cfg;
+        fa.b = EnvSide{cvb, gvb, nullptr, sb.env, n_pairs, nullptr, nullptr, nullptr};
+        fa.env_a = sa.env;
+        fa.slot_a = sa.slot;
+        fa.anchors = P.anchors;
+        fa.n_pairs = n_pairs; fa.n_atoms_a = a->n; fa.n_atoms_b = b->n;
+        fa.thr = thr;
+        fa.out = P.out;
+        fa.meta = pb.pair_meta;
+        fa.st = c->d_status;
+        fa.done = c->d_done;
+        fa.sqrt_tab = c->d_tabs;
+        fa.rsqrt_tab = c->d_tabs + 65536;
+        const int cm = std::max(c->h_cfg.n_categories, c->tune.force_cmax);
+        if (!launch_env_sweep(s, cm, tag_list, frule, fa, c->h_status, c->seq, c->tune.fused_grid))
+            return fail(LCHD_EDEVICE, "the fused environment + sweep kernel rejected its launch configuration");
+        P.fused_no_comp = !c->fused_companion && c->tune.fused <= 0;
+        if (!P.fused_no_comp) launch_sweep_companion(s, c->tune, c->h_cfg.n_categories, frule, sw);
+        launch_fused_publish(s, fa, c->h_status, c->seq);
+        P.sweep_info = frule == 2 ? 1 : 0;
+        ++c->n_fused_passes;
+    } else {
+        P.sweep_info = launch_sweep(s, c->tune, c->h_cfg.n_categories, c->hellinger2, c->unit_weights, c->wf_pow, c->sweep_hint, sw);
+    }
     mark(c, 4);
     if (a->ev_used) { HIP_TRY(hipEventRecord(a->ev_used, s)); a->used_valid = true; }
     if (b->ev_used) { HIP_TRY(hipEventRecord(b->ev_used, s)); b->used_valid = true; }
@@ -1108,6 +1180,7 @@ extern "C" int lchd_from_primitives_dev_async(lchd_ctx* c, lchd_cloud* a, lchd_c
     P.a = a; P.b = b; P.anchors = d_anchors; P.wf = d_wf_index; P.n_pairs = n_pairs; P.thr = thr; P.out = d_out;
     P.cap = c->cap_hint;
     P.subset = false;
+    P.no_fused = false;
     c->last_store_bytes = 0;
     if (int rc = prims_enqueue(c)) return rc;
     P.active = true;
@@ -1143,7 +1216,7 @@ static int rescore_overflow_pairs(lchd_ctx* c, uint32_t f1, int64_t biggest, boo
     const HostStatus* h = c->h_status;
     const uint32_t na = h->n_overflow[0], nb = h->n_overflow[1];
     const uint64_t n_uniq = (uint64_t)h->n_unique[0] + h->n_unique[1];
-    if (P.subset || c->tune.no_overflow_subset || !P.ovf_a || na + nb == 0 || (f1 & ST_EMPTY_ENV)) return LCHD_OK;
+    if (P.subset || P.per_pair || c->tune.no_overflow_subset || !P.ovf_a || na + nb == 0 || (f1 & ST_EMPTY_ENV)) return LCHD_OK;  // (per_pair: the selection kernels read side B's slot map)
     if ((uint64_t)(na + nb) * 8 > n_uniq) return LCHD_OK;  // not a minority: larger slots for everything
     hipStream_t s = c->stream;
     const SweepArgs sw = P.sw;  // the finished pass's arrays (the arena stays as it is until the second pass is enqueued)
@@ -1213,6 +1286,29 @@ static int finish_passes(lchd_ctx* c, uint32_t* flags_out) {
         collect_times(c, 0, 4);
         if (f & ST_BAD_ANCHOR) { *flags_out = f; return LCHD_OK; }
         const int64_t biggest = c->h_status->max_env;  // largest environment of the pass (k_pair_meta), or what overflowed
+        if (P.fused) {
+            // A pass of k_env_sweep.  An environment that did not fit (its group buffer, a side-A slot): the regular pipeline takes the
+            // call (its kernels grow).  Pairs left without the INDIRECT sweep having been launched: the pass again, with it.
+            if (f & ST_ENV_OVERFLOW) {
+                P.no_fused = true;
+                c->fused_blocked = true;
+                if (int rc = prims_enqueue(c)) return rc;
+                continue;
+            }
+            const unsigned long long taken = c->h_status->n_small;
+            if (f == 0 && P.fused_no_comp && taken < (unsigned long long)P.n_pairs) {
+                c->fused_companion = true;
+                if (int rc = prims_enqueue(c)) return rc;
+                continue;
+            }
+            c->fused_companion = taken < (unsigned long long)P.n_pairs;
+            ++c->fused_streak;
+            if (biggest > 0) { c->group_small = biggest <= kEnvGroupSmallUpTo; c->last_biggest = biggest; }
+            c->last = P.sw;
+            c->last_valid = true;
+            *flags_out = f;
+            return LCHD_OK;
+        }
         if (f & ST_ENV_OVERFLOW) {  // an environment did not fit its slot: its pairs again with larger slots, or the whole pass
             if (biggest > 65535 && (c->h_cfg.n_categories > kMaxCategories || biggest > (1 << 23)))
                 return fail(LCHD_EUNSUPPORTED, "an environment holds %lld points; beyond 65535 per environment this build handles at most %d "
@@ -1270,6 +1366,16 @@ static int finish_passes(lchd_ctx* c, uint32_t* flags_out) {
             }
         }
         if (biggest > 0) { c->group_small = biggest <= kEnvGroupSmallUpTo; c->last_biggest = biggest; }
+        if (!P.subset) {
+            if (P.per_pair) {
+                ++c->fused_streak;  // (this pass did not count side B's unique anchors: the hint stands)
+                ++c->n_per_pair_passes;
+            } else {  // (almost) every side-B anchor unique: the next passes of this context do not de-duplicate side B
+                const bool same_obj = P.sw.slot_a == P.sw.slot_b;
+                c->b_use_once = !same_obj && (unsigned long long)c->h_status->n_unique[1] * 5ull >= (unsigned long long)P.n_pairs * 4ull;
+                c->fused_streak = 0;
+            }
+        }
         if (c->h_status->n_small != ~0ull)  // what the pairs looked like this time picks the sweep kernels of the next pass of this configuration
             c->sweep_hint = 4 | (2 * c->h_status->n_duo >= (unsigned long long)P.n_pairs ? 1 : 0) |
                             (2 * c->h_status->n_c8 >= (unsigned long long)P.n_pairs ? 2 : 0) |
@@ -1294,6 +1400,8 @@ extern "C" int lchd_ctx_finish(lchd_ctx* c) {
 }
 
 extern "C" int64_t lchd_ctx_subset_pass_count(lchd_ctx* c) { return c ? c->n_subset_passes : -1; }
+extern "C" int64_t lchd_ctx_fused_pass_count(lchd_ctx* c) { return c ? c->n_fused_passes : -1; }
+extern "C" int64_t lchd_ctx_per_pair_pass_count(lchd_ctx* c) { return c ? c->n_per_pair_passes : -1; }
 extern "C" int64_t lchd_ctx_last_store_bytes(lchd_ctx* c) { return c ? (int64_t)c->last_store_bytes : -1; }
 
 extern "C" int lchd_from_primitives_dev(lchd_ctx* c, lchd_cloud* a, lchd_cloud* b, const int64_t* d_anchors,

@@ -90,6 +90,9 @@ struct Tuning {
     int env_apw = 0;                // LCHD_ENV_APW: anchors per wavefront of k_env_group (0: chosen from the number of anchors)
     int force_cmax = 0;             // LCHD_FORCE_CMAX: at least this many category slots
     int cap_hint = 0;               // LCHD_CAP_HINT: first environment capacity to try
+    int fused = 0;                  // LCHD_FUSED: 1 / 3 the fused environment + sweep kernel (lchd_env_fused.hip) whenever it applies, with the 240-event / the 480-event team rule (default 0: never -- measured slower than the two kernels)
+    int per_pair = 0;               // LCHD_PER_PAIR: -1 never a side B without de-duplication, 1 whenever it applies, 0: from the previous pass (side-B anchors (almost) all unique)
+    int fused_grid = 0;             // LCHD_FUSED_GRID: workgroups of the fused kernel (0: 4096)
 };
 
 struct WfEntry {
@@ -186,6 +189,7 @@ struct PrepSide {
     uint32_t* chunk_base;    // [(n >> 18) + 2] anchors before each chunk
     uint32_t* slot;          // [n + 1] atom -> environment slot (anchors only)
     AnchorRec* uniq;         // [max_envs]
+    int32_t no_anchors;      // 1: this side's anchors are neither flagged nor de-duplicated (k_env_sweep builds an environment per PAIR): cell list only
 };
 // Cell lists of both sides + anchor de-duplication (see lchd_kernels.hip).  [zero_base, zero_base + zero_bytes) is the
 // contiguous region holding cell_count of both sides followed by flag8_a, flag8_b (in this order, flag8_b last): the prologue
@@ -194,6 +198,9 @@ struct PrepSide {
 // de-duplicated together into side A's flags / slots / records and n_unique[1] = 0.
 int launch_prologue(hipStream_t s, const Tuning& t, const int64_t* anchors, int64_t n_pairs, const PrepSide& a, const PrepSide& b,
                     void* zero_base, size_t zero_bytes, DeviceStatus* st, bool same = false);
+// Anchor records of a side without de-duplication (PrepSide::no_anchors), one per PAIR: record p = the side-B anchor of pair p; sets
+// DeviceStatus::n_unique[1] = n_pairs.  Behind launch_prologue (reads the side's atom -> position map).
+void launch_pair_anchor_recs(hipStream_t s, const int64_t* anchors, int64_t n_pairs, const PrepSide& b, DeviceStatus* st);
 // Per-device function attributes (dynamic LDS above 64 KB): called by lchd_ctx_create with the context's device current.
 void init_device_kernels();
 
@@ -282,12 +289,37 @@ bool dense_fused_applies(int n_categories, int64_t len_a, int64_t len_b);
 bool launch_dense_fused(hipStream_t s, int n_categories, const DenseArgs& a, HostStatus* hst, uint32_t seq);
 void init_dense_fused_kernels();  // per device (dynamic LDS above 64 KB), called by lchd_ctx_create
 
+// Environment build + sweep in one kernel for side-B environments that are used once (lchd_env_fused.hip).  Side A's environments
+// come from the store (k_env_group ran before); side B needs its cell list only (PrepSide::no_anchors).  Slot p of side B's store
+// and record p of `meta` belong to pair p: the kernel writes the record of every pair, the length of every slot, and the
+// environment itself for the pairs it leaves to the INDIRECT sweep behind it.
+struct FusedArgs {
+    const DevConfig* cfg;
+    EnvSide b;                 // side B: structure, grid, the store's slots [n_pairs] (uniq / ovf_list unused)
+    EnvStore env_a;
+    const uint32_t* slot_a;    // side A: atom -> environment slot
+    const int64_t* anchors;    // [P][2]
+    int64_t n_pairs, n_atoms_a, n_atoms_b;
+    double thr;
+    double* out;
+    int4* meta;
+    DeviceStatus* st;
+    DoneState* done;           // context-owned, zero between kernels: the pass's totals (pairs swept here, largest environment)
+    const double* sqrt_tab;
+    const double* rsqrt_tab;
+};
+bool fused_applies(int n_categories);
+// rule: 0 = teams of 16 lanes, pairs of at most 240 merged events; 2 = teams of 32, 8-bit-count pairs of at most 480.  Returns false
+// (nothing launched) when the kernel does not apply.
+bool launch_env_sweep(hipStream_t s, int n_categories, bool tag_list, int rule, const FusedArgs& fa, HostStatus* hst, uint32_t seq, int grid_cap);
+void launch_fused_publish(hipStream_t s, const FusedArgs& fa, HostStatus* hst, uint32_t seq);
+
 struct SweepArgs {
     const DevConfig* cfg;
     EnvStore env_a, env_b;
     const int64_t* anchors;   // [P][2] or nullptr => pair p uses env (p, p)
     const uint32_t* slot_a;   // anchor index -> env slot (nullptr with anchors == nullptr)
-    const uint32_t* slot_b;
+    const uint32_t* slot_b;   // (nullptr with anchors != nullptr: side B's slot of pair p is p -- a pass of k_env_sweep)
     int64_t n_slot_a, n_slot_b;  // atoms per side (bounds for the anchor indices)
     const int32_t* wf_index;  // [P] or nullptr => 0
     int64_t n_pairs;
@@ -321,6 +353,9 @@ struct SweepArgs {
 // launch was left out: the caller must check this pass's counts, HostStatus::n_duo / n_c8 against the number of pairs).
 int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinger2, bool unit_weights, bool wf_pow, int sweep_hint,
                  const SweepArgs& a);
+// The INDIRECT one-pair-per-wavefront sweep alone, over the pair records somebody else wrote (k_env_sweep): the pairs that are not
+// small under `rule`.  Hellinger-2, unit weights, CDF-keyed stores of the default capacity.
+void launch_sweep_companion(hipStream_t s, const Tuning& t, int n_categories, int rule, const SweepArgs& a);
 // Kullback-Leibler / Renyi in O(1) per event (lchd_sweep_inc.hip): unit weights, CDF-keyed environments of at most 512 points, tiny eps;
 // reads the pair records of k_pair_meta.  kind: SweepArgs::sd_fast.
 void launch_sweep_inc(hipStream_t s, int kind, int cmax, const SweepArgs& a);

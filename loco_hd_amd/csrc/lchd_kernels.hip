@@ -283,6 +283,10 @@ __global__ __launch_bounds__(1024) void k_prologue_fused(const int64_t* __restri
     const int n = c.n, cps = P.g.dim[0] * P.g.dim[1] * P.g.dim[2], nw = (n + 31) >> 5;
     for (int w = tid; w <= kBitWordsMax; w += 1024) bits[w] = 0u;
     cell_build_wg<1024>(c, P.g, cps, 0, n, 0, true, P.rec, P.pos_of, P.cell_start, smem_pf, wsum);  // (its barriers order the clear above)
+    if (P.no_anchors) {  // (k_env_sweep validates this side's anchor indices itself)
+        if (tid == 0) st->n_unique[side] = 0u;
+        return;
+    }
     bool bad = false;
     for (int64_t p0 = tid; p0 < n_pairs; p0 += 4 * 1024) {
         int64_t av[4];
@@ -360,7 +364,7 @@ __global__ void k_prep_count(const int64_t* __restrict__ anchors, int64_t n_pair
     for (int64_t p = g0; p < n_pairs; p += gsz) {
         const longlong2 ab = reinterpret_cast<const longlong2*>(anchors)[p];
         if (ab.x < 0 || ab.x >= n_a) bad = true; else pa.flag8[ab.x] = 1;
-        if (ab.y < 0 || ab.y >= n_b) bad = true; else pb.flag8[ab.y] = 1;
+        if (ab.y < 0 || ab.y >= n_b) bad = true; else if (!pb.no_anchors) pb.flag8[ab.y] = 1;
     }
     if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(&st->flags, ST_BAD_ANCHOR);
 }
@@ -450,6 +454,10 @@ __global__ __launch_bounds__(1024) void k_prep_scan(PrepSide pa, PrepSide pb, in
     const PrepSide& P = side ? pb : pa;
     const int cells = side ? cells_b : cells_a;
     if (cells > 0 && cells <= kPrepScanCells) scan_wg_1024(P.cell_count, P.cell_start, cells, false, wsum);
+    if (P.no_anchors) {
+        if (threadIdx.x == 0) st->n_unique[side] = 0u;
+        return;
+    }
     const int64_t nw = ((int64_t)P.c.n + 31) >> 5;
     if (bits_ready) {  // k_prep_bits has done the words and the scans inside the chunks: only the chunk totals are left
         const int64_t n_chunks = (nw + kChunkWords - 1) / kChunkWords;
@@ -472,7 +480,7 @@ __global__ void k_prep_scatter(PrepSide pa, PrepSide pb, int cells_a, int cells_
         const int64_t i = sb_ ? t - na : t;
         const CloudView& c = P.c;
         const bool general = (sb_ ? cells_b : cells_a) != 0;
-        const uint32_t w = P.bits[i >> 5];
+        const uint32_t w = P.no_anchors ? 0u : P.bits[i >> 5];
         const bool anchor = (w >> (i & 31)) & 1u;
         if (!general && !anchor) continue;  // (struct path, not an anchor: nothing to do -- most atoms of a trajectory batch)
         const double x = c.x[i], y = c.y[i], z = c.z[i];
@@ -499,6 +507,31 @@ __global__ void k_prep_scatter(PrepSide pa, PrepSide pb, int cells_a, int cells_
             P.uniq[sl] = r;
         }
     }
+}
+
+// Side B without de-duplication (PrepSide::no_anchors: (almost) every anchor of the side occurs in ONE pair -- the frames of a
+// trajectory, (i, i) lists, a rank's partners under strong scaling): environment slot p belongs to pair p, and its anchor record is
+// written straight from the pair list -- no byte flags, no bit set, no scan, no scatter over the side's atoms (C4: 54 -> ~10 us per
+// pass).  An anchor that does occur in several pairs is built once per pair, as the reference does (src/locohd.rs:514-554).
+__global__ void k_pair_anchor_recs(const int64_t* __restrict__ anchors, int64_t n_pairs, PrepSide pb, DeviceStatus* st) {
+    const CloudView& c = pb.c;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n_pairs; p += (int64_t)gridDim.x * blockDim.x) {
+        int64_t i = anchors[2 * p + 1];
+        if (i < 0 || i >= c.n) i = 0;  // (flagged by k_prep_count; the pair record marks the pair unusable)
+        AnchorRec r;
+        r.x = c.x[i]; r.y = c.y[i]; r.z = c.z[i];
+        r.tag = (uint32_t)c.tag[i];
+        r.apos = pb.pos_of[i];
+        r.sid = c.sid ? c.sid[i] : 0;
+        r.atom = (uint32_t)i;
+        pb.uniq[p] = r;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->n_unique[1] = (uint32_t)n_pairs;
+}
+void launch_pair_anchor_recs(hipStream_t s, const int64_t* anchors, int64_t n_pairs, const PrepSide& b, DeviceStatus* st) {
+    if (n_pairs <= 0) return;
+    const int64_t nb = (n_pairs + 255) / 256;
+    k_pair_anchor_recs<<<(unsigned)std::min<int64_t>(nb, 4096), 256, 0, s>>>(anchors, n_pairs, b, st);
 }
 
 static bool fits_struct_path(const PrepSide& P, const Tuning& t, CloudView& cs) {
@@ -565,13 +598,15 @@ int launch_prologue(hipStream_t s, const Tuning& t, const int64_t* anchors, int6
         const int cells = side ? cells_b : cells_a;
         if (cells > kPrepScanCells) { launch_exclusive_scan(s, P.cell_count, P.cell_start, cells, nullptr, P.scan_tmp); ops += 3; }
     }
-    const bool big = a.c.n > kPrepScanAtoms || b.c.n > kPrepScanAtoms;
+    const bool big = a.c.n > kPrepScanAtoms || (!b.no_anchors && b.c.n > kPrepScanAtoms);
     if (big) {
-        const int ca = (int)((((int64_t)a.c.n + 31) / 32 + kChunkWords - 1) / kChunkWords), cb = (int)((((int64_t)b.c.n + 31) / 32 + kChunkWords - 1) / kChunkWords);
+        const int ca = (int)((((int64_t)a.c.n + 31) / 32 + kChunkWords - 1) / kChunkWords),
+                  cb = b.no_anchors ? 0 : (int)((((int64_t)b.c.n + 31) / 32 + kChunkWords - 1) / kChunkWords);
         k_prep_bits<<<ca + cb, 1024, 0, s>>>(a, b, ca);
         ++ops;
     }
     k_prep_scan<<<2, 1024, 0, s>>>(a, b, cells_a, cells_b, big ? 1 : 0, st);
+    if (b.no_anchors && cells_b == 0) b.c.n = 0;  // (side B: no anchors, and the struct path has built its cell list: nothing left to scatter)
     const int64_t nba = ((int64_t)a.c.n + b.c.n + 255) / 256;
     k_prep_scatter<<<(unsigned)std::max<int64_t>(1, std::min<int64_t>(nba, 8192)), 256, 0, s>>>(a, b, cells_a, cells_b);
     return ops + 2;
@@ -2355,7 +2390,7 @@ __global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? (CMAX <= LCHD
             if (args.anchors) {
                 const int64_t ia_ = args.anchors[2 * pp], ib_ = args.anchors[2 * pp + 1];
                 ok = !(ia_ < 0 || ib_ < 0 || ia_ >= args.n_slot_a || ib_ >= args.n_slot_b);
-                if (ok) { ea = args.slot_a[ia_]; eb = args.slot_b[ib_]; }
+                if (ok) { ea = args.slot_a[ia_]; eb = args.slot_b ? args.slot_b[ib_] : pp; }
             }
             int nA_ = 0, nB_ = 0, c0a_ = 0, c0b_ = 0;
             if (ok) {
@@ -3525,7 +3560,7 @@ __global__ void k_pair_meta(SweepArgs args) {
         if (args.anchors) {
             const int64_t ia_ = args.anchors[2 * p], ib_ = args.anchors[2 * p + 1];
             ok = !(ia_ < 0 || ib_ < 0 || ia_ >= args.n_slot_a || ib_ >= args.n_slot_b);
-            if (ok) { ea = args.slot_a[ia_]; eb = args.slot_b[ib_]; }
+            if (ok) { ea = args.slot_a[ia_]; eb = args.slot_b ? args.slot_b[ib_] : p; }
         }
         if (args.wf_index && args.env_a.cdf_keys > 1) {
             // key sets: the pair's weight-function index picks the set its sweep reads -- an index outside the dictionary is reported
@@ -3759,6 +3794,28 @@ int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinge
     return info & 1;
 }
 
+void launch_sweep_companion(hipStream_t s, const Tuning& t, int n_categories, int rule, const SweepArgs& a_in) {
+    if (a_in.n_pairs <= 0) return;
+    SweepArgs a = a_in;
+    a.duo_enabled = 1;
+    a.forced = 1;
+    a.small_rule = rule;
+    a.c8_rule = 2;
+    a.second_rule = 0;
+    a.gen_tab = 0;
+    const int64_t blocks = (a.n_pairs + kSweepWaves - 1) / kSweepWaves;
+    const unsigned bgrid = (unsigned)std::min<int64_t>(blocks, LCHD_COMPANION_GRID);
+    constexpr int NTH = 64 * kSweepWaves;
+    const int cmax = std::max(n_categories, t.force_cmax);
+    if (cmax <= 8) k_sweep<8, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a);
+    else if (cmax <= 12) k_sweep<12, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a);
+    else if (cmax <= 16) k_sweep<16, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a);
+    else if (cmax <= 20) k_sweep<20, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a);
+    else if (cmax <= 24) k_sweep<24, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a);
+    else if (cmax <= 28) k_sweep<28, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a);
+    else k_sweep<32, MODE_H2U, F_KEY, true, true><<<bgrid, NTH, 0, s>>>(a);
+}
+
 // Kernels that may be launched with more than 64 KB of dynamic LDS need the limit raised per DEVICE: lchd_ctx_create calls this
 // with the context's device current (a process-wide "done once" flag would leave a second device without the attribute).
 void init_device_kernels() {
@@ -3811,7 +3868,7 @@ __global__ void k_env_points(SweepArgs args, unsigned long long* out) {
             const int64_t ia_ = args.anchors[2 * p], ib_ = args.anchors[2 * p + 1];
             if (ia_ < 0 || ib_ < 0 || ia_ >= args.n_slot_a || ib_ >= args.n_slot_b) continue;
             ea = args.slot_a[ia_];
-            eb = args.slot_b[ib_];
+            eb = args.slot_b ? args.slot_b[ib_] : p;
         }
         local += (unsigned long long)max(args.env_a.len[ea], 0) + (unsigned long long)max(args.env_b.len[eb], 0);
     }
