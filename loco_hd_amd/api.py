@@ -82,10 +82,38 @@ class WeightFunction:
 _ATOM_MUTATIONS = [0]
 
 
+# Process-wide string tables of PrimitiveAtom: every atom interns its two strings ONCE, when it is constructed or changed, and carries
+# the ids (slots _pid / _tid) -- packing a list for a from_primitives call is then a gather of three doubles and two integers per
+# atom in native code (_fastpack.pack_atoms), whatever list object the atoms arrive in.  The reference's PyO3 extraction clones
+# both Strings of every atom on every call instead (primitive_atom.rs:4-16, src/locohd.rs:479-485).  Ids are never re-used; the
+# tables grow with the number of DISTINCT strings the process has seen (residue tags, primitive type names).
+_TYPE_IDS: Dict[Any, int] = {}
+_TYPE_NAMES: List[Any] = []
+_TAG_IDS: Dict[Any, int] = {}
+
+
+def _type_id(value) -> int:
+    try:
+        i = _TYPE_IDS.get(value)
+    except TypeError:  # unhashable: no id (the general packing path looks str(value) up)
+        return -1
+    if i is None:
+        i = _TYPE_IDS[value] = len(_TYPE_NAMES)
+        _TYPE_NAMES.append(value)
+    return i
+
+
+def _tag_id(value) -> int:
+    try:
+        return _TAG_IDS.setdefault(value, len(_TAG_IDS))
+    except TypeError:
+        return -1
+
+
 class PrimitiveAtom:
     """primitive_atom.rs:4-25: a record with get+set attributes."""
 
-    __slots__ = ("_primitive_type", "_tag", "_coordinates")
+    __slots__ = ("_primitive_type", "_tag", "_coordinates", "_pid", "_tid")
 
     def __init__(self, primitive_type: str, tag: str, coordinates: Sequence[float]) -> None:
         self._primitive_type = primitive_type
@@ -94,6 +122,8 @@ class PrimitiveAtom:
         if len(v) != 3:
             raise ValueError(f"expected a sequence of length 3 (got {len(v)})")
         self._coordinates = v
+        self._pid = _type_id(primitive_type)
+        self._tid = _tag_id(tag)
 
     @property
     def primitive_type(self) -> str:
@@ -103,6 +133,7 @@ class PrimitiveAtom:
     def primitive_type(self, value: str) -> None:
         _ATOM_MUTATIONS[0] += 1
         self._primitive_type = value
+        self._pid = _type_id(value)
 
     @property
     def tag(self) -> str:
@@ -112,6 +143,7 @@ class PrimitiveAtom:
     def tag(self, value: str) -> None:
         _ATOM_MUTATIONS[0] += 1
         self._tag = value
+        self._tid = _tag_id(value)
 
     @property
     def coordinates(self) -> List[float]:
@@ -130,6 +162,7 @@ class PrimitiveAtom:
 
     def __setstate__(self, state):
         self._primitive_type, self._tag, self._coordinates = state
+        self._pid, self._tid = _type_id(self._primitive_type), _tag_id(self._tag)
 
     def __repr__(self) -> str:
         return f"PrimitiveAtom({self._primitive_type!r}, {self._tag!r}, {self._coordinates!r})"
@@ -255,7 +288,8 @@ class LoCoHD:
             raise ValueError("deterministic=True applies to one device (the device group picks kernels per share)")
         self._ctx = None
         self._group = None
-        self._pack_cache: List[Any] = []   # most recent first: (list, its items, mutation stamp, parent entry, packed, interner)
+        self._pack_cache: List[Any] = []   # most recent first: (list, its items, mutation stamp, None, packed, interner)
+        self._pid_map = np.empty(0, dtype=np.int32)  # PrimitiveAtom type id -> category index (_type_map)
         self._anchor_cache = None
         self._wf_names = list(self._w_func) if isinstance(self._w_func, dict) else None
 
@@ -435,37 +469,56 @@ class LoCoHD:
                 return e
         return None
 
+    def _type_map(self) -> np.ndarray:
+        """primitive-type id (the process-wide table of PrimitiveAtom) -> category index of THIS instance, -1: not in its map"""
+        m = self._pid_map
+        if len(m) < len(_TYPE_NAMES):
+            get = self._categories.get
+            ext = [get(nm if type(nm) is str else str(nm), -1) for nm in _TYPE_NAMES[len(m):]]
+            m = self._pid_map = np.concatenate([m, np.asarray(ext, dtype=np.int32)])
+        return m
+
+    def _pack_global(self, prims) -> _Packed:
+        """Packed form with tags from the process-wide table: the gather over interned ids when the list holds exactly PrimitiveAtom
+        objects, else the general extraction (strings looked up per atom) into the same id space."""
+        n = len(prims)
+        if _fastpack is not None and hasattr(_fastpack, "pack_atoms"):
+            xyz, cat, tag = np.empty((n, 3), dtype=np.float64), np.empty(n, dtype=np.int32), np.empty(n, dtype=np.int32)
+            if _fastpack.pack_atoms(prims, PrimitiveAtom, self._type_map(), xyz, cat, tag):
+                return _Packed(xyz, cat, tag)
+        return self.pack(prims, _TAG_IDS)
+
     def _packed_lists(self, prim_a, prim_b):
-        """(packed A, packed B, interner): tags are interned over A, then B, like one fresh interner per call."""
+        """(packed A, packed B, interner): tags of both lists (and of the tag rule, _config) are ids of ONE table, the process-wide
+        one of PrimitiveAtom -- only their equality matters (tag_pairing_rule.rs:49-75)."""
         if _fastpack is None or not hasattr(_fastpack, "same_items"):
-            interner: Dict[str, int] = {}
-            return self.pack(prim_a, interner), self.pack(prim_b, interner), interner
+            return self.pack(prim_a, _TAG_IDS), self.pack(prim_b, _TAG_IDS), _TAG_IDS
         entries = []
-        parent, parent_cached = None, True
         for prims in (prim_a, prim_b):
-            e = self._cache_lookup(prims, parent) if parent_cached else None
+            e = self._cache_lookup(prims, None)
             if e is None:
-                interner = dict(parent[5]) if parent is not None else {}
-                packed = self.pack(prims, interner)
-                items = _fastpack.items_tuple(prims, PrimitiveAtom) if parent_cached else None
-                e = (prims, items, _ATOM_MUTATIONS[0], parent, packed, interner)
-                parent_cached = items is not None
-                if parent_cached:
+                packed = self._pack_global(prims)
+                items = _fastpack.items_tuple(prims, PrimitiveAtom)
+                e = (prims, items, _ATOM_MUTATIONS[0], None, packed, _TAG_IDS)
+                if items is not None:
                     self._pack_cache.insert(0, e)
                     del self._pack_cache[self._CACHE_ENTRIES:]
             entries.append(e)
-            parent = e
-        interner = entries[1][5]
-        return entries[0][4], entries[1][4], (dict(interner) if self._tpr._pairs else interner)  # (_config interns the rule's tags)
+        return entries[0][4], entries[1][4], _TAG_IDS
 
     def _anchor_arrays(self, anchor_pairs):
         """([P][2] int64 anchors, weight-function indices or None); the conversion of an unchanged list of tuples is kept."""
         c = self._anchor_cache
         if c is not None and c[0] is anchor_pairs and _fastpack is not None and hasattr(_fastpack, "same_items") and _fastpack.same_items(anchor_pairs, c[1]):
             return c[2], c[3]
-        pairs, keys = self._split_anchor_pairs(anchor_pairs)
-        idx = self._wf_indices(keys, len(pairs))
-        arr = np.ascontiguousarray(pairs, dtype=np.int64).reshape(-1, 2)
+        if _fastpack is not None and hasattr(_fastpack, "pairs_into") and hasattr(anchor_pairs, "__len__"):
+            arr = np.empty((len(anchor_pairs), 2), dtype=np.int64)
+            keys = _fastpack.pairs_into(anchor_pairs, arr)  # (AnchorPairSpecifier in native code, like the PyO3 derive)
+            idx = self._wf_indices(keys, len(arr))
+        else:
+            pairs, keys = self._split_anchor_pairs(anchor_pairs)
+            idx = self._wf_indices(keys, len(pairs))
+            arr = np.ascontiguousarray(pairs, dtype=np.int64).reshape(-1, 2)
         items = _fastpack.items_tuple(anchor_pairs, tuple) if (_fastpack is not None and hasattr(_fastpack, "items_tuple")) else None
         self._anchor_cache = (anchor_pairs, items, arr, idx) if items is not None else None
         return arr, idx

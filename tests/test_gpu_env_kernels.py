@@ -184,6 +184,32 @@ def test_packed_list_cache_sees_every_change(lh, oracle):
     ducks[3].coordinates = [9.0, 9.0, 9.0]
     d2 = np.asarray(lchd.from_primitives(tuple(pa), ducks, [(i, i) for i in range(50)], 9.0))
     assert d2[3] > 0.0
+    # NEW list objects on every call (no cache entry can serve them): the atoms carry the ids of their strings (interned when an atom
+    # is constructed or changed, primitive_atom.rs:4-25 has get + set), so a setter between two calls must show in the next call
+    for mod, st in state.items():
+        st["pa2"], st["pb2"] = list(st["pa"]), list(st["pb"])
+
+    def fresh():
+        got = {mod: np.asarray(st["lchd"].from_primitives(list(st["pa2"]), list(st["pb2"]), list(st["anchors"]), 9.0)) for mod, st in state.items()}
+        assert np.max(np.abs(got[lh] - got[oracle])) < TIGHT
+        return got[lh]
+
+    f1 = fresh()
+    assert np.array_equal(fresh(), f1)
+    for mod, st in state.items():
+        st["pa2"][30].tag = "a tag nobody else has"          # leaves its residue: it is no longer filtered out of its neighbours' environments
+        st["pb2"][31].primitive_type = "A" if st["pb2"][31].primitive_type != "A" else "B"
+        st["pb2"][32].coordinates = (0.5, 0.25, 0.125)
+    f2 = fresh()
+    assert not np.array_equal(f2, f1)
+    for mod, st in state.items():  # a type that is not in this instance's category map: "Category not found!" (pmf.rs:38-42)
+        st["pa2"][33].primitive_type = "not a category"
+    for mod, st in state.items():
+        with pytest.raises(ValueError):
+            st["lchd"].from_primitives(list(st["pa2"]), list(st["pb2"]), list(st["anchors"]), 9.0)
+    for mod, st in state.items():
+        st["pa2"][33].primitive_type = "C"
+    fresh()  # (the scores follow the oracle again: asserted inside)
 
 
 def test_category_ids_beyond_the_map_raise_under_a_narrow_configuration():

@@ -197,3 +197,67 @@ def test_primitive_atom_record_and_native_identity_helpers():
         assert api._fastpack.items_tuple(items + ["x"], lh.PrimitiveAtom) is None
         assert api._fastpack.items_tuple(np.asarray(items, dtype=object), lh.PrimitiveAtom) is None  # lists / tuples only
         assert api._fastpack.items_tuple([(1, 2), (3, 4)], tuple) is not None and api._fastpack.items_tuple([(1, 2), [3, 4]], tuple) is None
+
+
+def test_interned_ids_pack_like_the_general_path():
+    """_fastpack.pack_atoms (a gather over the ids every PrimitiveAtom interns when it is constructed or changed) against pack_into (the
+    strings looked up per atom): same arrays for plain lists and tuples, after setters, after pickling, with labels that are not str;
+    lists that hold anything but exactly PrimitiveAtom fall back to the general path (primitive_atom.rs:4-25: get + set attributes)."""
+    import pickle
+
+    from loco_hd_amd import api
+
+    cats = ["A", "B", "C", "7"]
+    lchd = lh.LoCoHD(cats)
+    rng = np.random.default_rng(3)
+    atoms = [lh.PrimitiveAtom(cats[i % 4], f"r{i // 3}", rng.uniform(0, 9, 3)) for i in range(50)]
+    atoms[5] = lh.PrimitiveAtom(np.str_("B"), np.str_("r1"), (1, 2, 3))      # NumPy strings, integer coordinates
+    atoms[6] = lh.PrimitiveAtom(7, "r2", [0.0, 0.0, 0.0])                      # a label that is not a str: str(label) is looked up
+    atoms[7] = lh.PrimitiveAtom("nowhere", "r2", [0.0, 0.0, 0.0])              # not in the map: -1 (raises when the environment is used)
+
+    def both(seq):
+        fast, general = lchd._pack_global(seq), lchd.pack(seq, api._TAG_IDS)
+        assert np.array_equal(fast.xyz, general.xyz) and np.array_equal(fast.cat, general.cat) and np.array_equal(fast.tag, general.tag)
+        return fast
+
+    first = both(atoms)
+    assert first.cat[5] == 1 and first.cat[6] == 3 and first.cat[7] == -1 and first.tag[5] == first.tag[4]
+    both(tuple(atoms))
+    atoms[0].tag, atoms[1].primitive_type, atoms[2].coordinates = "elsewhere", "C", [9.0, 8.0, 7.0]
+    second = both(atoms)
+    assert second.tag[0] != first.tag[0] and second.cat[1] == 2 and second.xyz[2].tolist() == [9.0, 8.0, 7.0]
+    both(pickle.loads(pickle.dumps(atoms)))
+    other = lh.LoCoHD(["C", "B"])   # another instance, another category map over the same type ids
+    assert other._pack_global(atoms).cat[:8].tolist() == [-1 if c not in ("B", "C") else ["C", "B"].index(c) for c in
+                                                          [str(a.primitive_type) for a in atoms[:8]]]
+
+    class Sub(lh.PrimitiveAtom):
+        pass
+
+    mixed = atoms[:10] + [Sub("A", "r0", [1.0, 1.0, 1.0])]
+    xyz, cat, tag = np.empty((11, 3)), np.empty(11, np.int32), np.empty(11, np.int32)
+    assert api._fastpack.pack_atoms(mixed, lh.PrimitiveAtom, lchd._type_map(), xyz, cat, tag) is False
+    both(mixed)  # ... and the fall-back gives the same ids
+
+
+def test_native_anchor_pair_extraction():
+    """_fastpack.pairs_into = AnchorPairSpecifier (src/locohd.rs:34-40): 3-tuples first (an empty list is that variant), then 2-tuples;
+    mixed lengths are a TypeError, negative indices an OverflowError (usize)."""
+    from loco_hd_amd import api
+
+    lchd = lh.LoCoHD(["A"], {"u": lh.WeightFunction("uniform", [1.0, 2.0]), "v": lh.WeightFunction("uniform", [1.0, 3.0])})
+    arr, idx = lchd._anchor_arrays([(1, 2, "v"), (np.int64(3), 4, "u")])
+    assert arr.tolist() == [[1, 2], [3, 4]] and idx.tolist() == [1, 0]
+    single = lh.LoCoHD(["A"])
+    arr, idx = single._anchor_arrays(((5, 6), [7, 8]))
+    assert arr.tolist() == [[5, 6], [7, 8]] and idx is None
+    with pytest.raises(ValueError):
+        single._anchor_arrays([])  # the with-key variant against a single weight function (src/locohd.rs:276-281)
+    with pytest.raises(TypeError):
+        single._anchor_arrays([(1, 2), (1, 2, "u")])
+    with pytest.raises(TypeError):
+        single._anchor_arrays([(1, 2, 3, 4)])
+    with pytest.raises(OverflowError):
+        single._anchor_arrays([(1, -2)])
+    with pytest.raises(TypeError):
+        single._anchor_arrays([(1.5, 2)])  # usize extraction does not take floats
