@@ -3,7 +3,7 @@
 // Owns: validation (the reference's PyValueError sites), packing of caller buffers into SoA device
 // arrays, the device workspace, kernel sequencing on one HIP stream, the status read-back and its
 // translation into the reference's error classes.  No scoring arithmetic happens on the host: every
-// from_* entry point launches the gfx950 kernels of lchd_kernels.hip and fails with LCHD_EDEVICE when
+// from_* entry point launches the gfx950 kernels of lchd_*.hip and fails with LCHD_EDEVICE when
 // no GPU is usable.
 #include <hip/hip_runtime.h>
 
@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/loco_hd_hip.h"
@@ -1690,6 +1691,32 @@ static int grow_io(lchd_ctx* c, size_t total) {
 
 // One host-pointer from_primitives call on one context, split so that a device group can have every device's pass in flight
 // at the same time.  `subset` (or nullptr = all pairs) lists the positions in anchors / wf_index / out this context scores.
+// Large host-pointer calls (a million pairs: 16 MB of anchors in, 8 MB of scores out) spend more time copying between the caller's
+// pageable arrays and the pinned staging block than the GPU spends scoring them.  Above kPipePairs the pair list therefore travels
+// in chunks -- chunk k + 1 is copied into the staging block (by up to four threads: one core moves ~10 GB/s, the host link ~50) while
+// the DMA engine sends chunk k -- and the scores come back the same way.
+constexpr int64_t kPipePairs = (int64_t)1 << 18;
+static void parallel_copy(void* dst, const void* src, size_t bytes) {
+    const int nt = bytes >= ((size_t)6 << 20) ? 4 : (bytes >= ((size_t)2 << 20) ? 2 : 1);
+    if (nt == 1) { memcpy(dst, src, bytes); return; }
+    const size_t part = ((bytes / nt) + 4095) & ~(size_t)4095;
+    std::thread th[3];
+    int started = 0;
+    for (int k = 1; k < nt; ++k) {
+        const size_t o = (size_t)k * part;
+        if (o >= bytes) break;
+        const size_t len = std::min(part, bytes - o);
+        try {
+            th[started] = std::thread([=] { memcpy(static_cast<char*>(dst) + o, static_cast<const char*>(src) + o, len); });
+            ++started;
+        } catch (...) {  // no thread to be had: this part on the calling thread
+            memcpy(static_cast<char*>(dst) + o, static_cast<const char*>(src) + o, len);
+        }
+    }
+    memcpy(dst, src, std::min(part, bytes));
+    for (int k = 0; k < started; ++k) th[k].join();
+}
+
 struct HostCall {
     lchd_cloud a, b;  // point into the context's device I/O block; referenced by the pending pass until it is finished
     size_t o_out = 0;
@@ -1726,7 +1753,23 @@ static int host_call_enqueue(lchd_ctx* c, const lchd_config* cfg, const double* 
     }
     int64_t* ha = reinterpret_cast<int64_t*>(c->h_io + o_anchors);
     int32_t* hw = reinterpret_cast<int32_t*>(c->h_io + o_wf);
-    if (!subset) {
+    bool piped = false;
+    if (!subset && n >= kPipePairs) {
+        // the structures (and whatever lies in front of the pair list) first, then the list chunk by chunk: the copy of chunk k + 1
+        // into the staging block overlaps the DMA of chunk k
+        HIP_TRY(hipMemcpyAsync(c->d_io, c->h_io, o_anchors, hipMemcpyHostToDevice, c->stream));
+        const int64_t chunk = std::max<int64_t>(kPipePairs, (n + 3) / 4);
+        for (int64_t p0 = 0; p0 < n; p0 += chunk) {
+            const size_t o = o_anchors + sizeof(int64_t) * 2 * (size_t)p0, len = sizeof(int64_t) * 2 * (size_t)std::min<int64_t>(chunk, n - p0);
+            parallel_copy(c->h_io + o, reinterpret_cast<const char*>(anchors) + (o - o_anchors), len);
+            HIP_TRY(hipMemcpyAsync(c->d_io + o, c->h_io + o, len, hipMemcpyHostToDevice, c->stream));
+        }
+        if (wf_index) {
+            parallel_copy(hw, wf_index, sizeof(int32_t) * (size_t)n);
+            HIP_TRY(hipMemcpyAsync(c->d_io + o_wf, c->h_io + o_wf, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        }
+        piped = true;
+    } else if (!subset) {
         memcpy(ha, anchors, sizeof(int64_t) * 2 * (size_t)n);
         if (wf_index) memcpy(hw, wf_index, sizeof(int32_t) * (size_t)n);
     } else {
@@ -1736,7 +1779,7 @@ static int host_call_enqueue(lchd_ctx* c, const lchd_config* cfg, const double* 
             if (wf_index) hw[k] = wf_index[subset[k]];
         }
     }
-    HIP_TRY(hipMemcpyAsync(c->d_io, c->h_io, in_bytes, hipMemcpyHostToDevice, c->stream));
+    if (!piped) HIP_TRY(hipMemcpyAsync(c->d_io, c->h_io, in_bytes, hipMemcpyHostToDevice, c->stream));
     const int64_t* d_anchors = reinterpret_cast<const int64_t*>(c->d_io + o_anchors);
     const int32_t* d_wf = wf_index ? reinterpret_cast<const int32_t*>(c->d_io + o_wf) : nullptr;
     hc.direct = n <= kDirectOutPairs;
@@ -1750,6 +1793,31 @@ static int host_call_finish(lchd_ctx* c, HostCall& hc, const int64_t* subset, do
     hc.enqueued = false;
     CTX_GUARD(c);
     int rc = lchd_ctx_finish(c);
+    if (!rc && !hc.direct && !subset && hc.n >= kPipePairs) {
+        // the scores come back in chunks: chunk k is copied out to the caller's array while the DMA engine fetches chunk k + 1
+        const int64_t chunk = std::max<int64_t>(kPipePairs, (hc.n + 3) / 4);
+        hipError_t e = hipSuccess;
+        int n_ev = 0;
+        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int64_t p0 = 0; p0 < hc.n && e == hipSuccess; p0 += chunk, ++n_ev) {
+            const size_t o = hc.o_out + sizeof(double) * (size_t)p0, len = sizeof(double) * (size_t)std::min<int64_t>(chunk, hc.n - p0);
+            e = hipMemcpyAsync(c->h_io + o, c->d_io + o, len, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[n_ev], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventRecord(ev[n_ev], c->stream);
+        }
+        int k = 0;
+        for (int64_t p0 = 0; p0 < hc.n && e == hipSuccess; p0 += chunk, ++k) {
+            e = hipEventSynchronize(ev[k]);
+            if (e == hipSuccess)
+                parallel_copy(out + p0, c->h_io + hc.o_out + sizeof(double) * (size_t)p0, sizeof(double) * (size_t)std::min<int64_t>(chunk, hc.n - p0));
+        }
+        for (int q = 0; q < 4; ++q)
+            if (ev[q]) (void)hipEventDestroy(ev[q]);
+        if (e != hipSuccess) { (void)hipStreamSynchronize(c->stream); rc = fail(LCHD_EDEVICE, "HIP error %d in D2H scores", (int)e); }
+        c->last_valid = false;
+        c->pend.a = c->pend.b = nullptr;
+        return rc;
+    }
     if (!rc && !hc.direct) {
         hipError_t e = hipMemcpyAsync(c->h_io + hc.o_out, c->d_io + hc.o_out, sizeof(double) * (size_t)hc.n, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

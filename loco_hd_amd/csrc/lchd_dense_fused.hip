@@ -2,7 +2,7 @@
 //
 // Replaces, for the common configuration (Hellinger-2, unit category weights, at most 16 categories, rows of 1 025 .. 20 480
 // points), the pair  k_env_rows2 (sort every row of both structures, write 9 bytes per point to the environment store)  +
-// k_sweep (read them back, merge, integrate)  of lchd_kernels.hip:
+// k_sweep (read them back, merge, integrate)  of lchd_env_rows.hip / lchd_sweep.hip:
 //
 //   reference                                     here
 //   calculate_distance_matrix  utils.rs:10-22     the distance images of a row are recomputed per distance segment
@@ -70,7 +70,7 @@ constexpr int kBuckets = LCHD_DF_BUCKETS;  // buckets of a segment's sort, two 1
 constexpr int kBucketLimit = 64;      // a fuller bucket sends the call to the two-kernel path
 constexpr int kPart = 1024;           // sqrt(k) for k < kPart from LDS, larger counts are computed
 constexpr int kMaxSeg = 16;
-constexpr double kExactBelow = 1e-6;  // as lchd_kernels.hip: below this H^2 the literal difference-of-roots form
+constexpr double kExactBelow = 1e-6;  // as lchd_team_tile.h (kExactH2Below): below this H^2 the literal difference-of-roots form
 static_assert(kEpt <= 15 && kCap % kNT == 0, "chunk-local counters are 4-bit fields");
 static_assert(kBuckets / 2 == 4 * kNT, "the bucket scan gives every thread four histogram words");
 static_assert(kBuckets * 2 >= kPart * 8, "histogram and sqrt table share their bytes");

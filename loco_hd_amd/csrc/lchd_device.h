@@ -1,5 +1,5 @@
 // lchd_device.h -- internal interface between the C-ABI host layer (lchd_capi.hip) and the gfx950
-// kernels (lchd_kernels.hip).  Plain-old-data argument blocks + launcher prototypes.
+// kernels (lchd_*.hip, one kernel family per translation unit).  Plain-old-data argument blocks + launcher prototypes.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -191,7 +191,7 @@ struct PrepSide {
     AnchorRec* uniq;         // [max_envs]
     int32_t no_anchors;      // 1: this side's anchors are neither flagged nor de-duplicated (k_env_sweep builds an environment per PAIR): cell list only
 };
-// Cell lists of both sides + anchor de-duplication (see lchd_kernels.hip).  [zero_base, zero_base + zero_bytes) is the
+// Cell lists of both sides + anchor de-duplication (see lchd_prologue.hip).  [zero_base, zero_base + zero_bytes) is the
 // contiguous region holding cell_count of both sides followed by flag8_a, flag8_b (in this order, flag8_b last): the prologue
 // zeroes what its launch tier needs with at most one operation.  Returns the number of stream operations enqueued.
 // `same`: both sides are one device object -- side B's cell list and slots are not built, the anchors of both columns are
@@ -242,13 +242,13 @@ bool launch_env_rows(hipStream_t s, int cap, const DevConfig* cfg, const CloudVi
                      int64_t n_rows, int64_t row_len, double image_bound /* coords: >= largest squared distance, or 0 */, EnvStore env,
                      DeviceStatus* st, const RowExtras& ex = RowExtras{nullptr, nullptr, nullptr});
 
-// "last workgroup" detection + hand-over through memory-side atomics (lchd_kernels.hip: last_workgroup_done)
+// "last workgroup" detection + hand-over through memory-side atomics (lchd_sweep_common.h: last_workgroup_done)
 struct DoneState {
     uint32_t ctr[65 * 32];
     uint32_t acc_max[64 * 32];
     unsigned long long acc_sum[64 * 16];
 };
-// one side of a dense-row launch (lchd_kernels.hip: k_env_rows2 builds both structures' rows in one launch)
+// one side of a dense-row launch (lchd_env_rows.hip: k_env_rows2 builds both structures' rows in one launch)
 struct RowSide {
     CloudView c;           // categories (and coordinates when dmx == nullptr)
     const double* dmx;     // given distance rows [n_rows][ld], or nullptr: distances from the coordinates of c
@@ -414,7 +414,7 @@ void launch_scatter_scores(hipStream_t s, const double* scores, const int64_t* i
 void launch_unshard_scores(hipStream_t s, const double* gathered, const ShardCounts& counts, int world, int64_t stride, double* out,
                            int64_t n_pairs, uint32_t* bad);
 void launch_env_points(hipStream_t s, const SweepArgs& a, unsigned long long* out);
-// from_anchors on lists whose distances do not ascend: the reference's loop walked literally by one lane (lchd_kernels.hip)
+// from_anchors on lists whose distances do not ascend: the reference's loop walked literally by one lane (lchd_sweep.hip)
 void launch_anchors_literal(hipStream_t s, const DevConfig* cfg, int n_categories, const EnvStore& ea, const EnvStore& eb, int nA, int nB, int wfi,
                             double* out);
 

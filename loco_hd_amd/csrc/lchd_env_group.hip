@@ -1,6 +1,6 @@
 // lchd_env_group.hip -- K1 (thresholded), the common case: environments of at most 512 points, SEVERAL per wavefront.
 //
-// Replaces, for the default capacity, the one-environment-per-wavefront kernel k_env_cells (lchd_kernels.hip), which spent
+// Replaces, for the default capacity, the one-environment-per-wavefront kernel k_env_cells (lchd_env_cells.hip), which spent
 // most of its vector instructions outside the distance arithmetic (reference: env_from_idx, /root/reference/src/locohd.rs:514-542;
 // utils::sort_together, utils.rs:25-39; euclidean_distance, utils.rs:1-8; KdTree::within_radius, :521):
 //

@@ -1,4 +1,4 @@
-// lchd_kcommon.h -- device helpers shared by the kernel translation units (lchd_kernels.hip, lchd_env_group.hip):
+// lchd_kcommon.h -- device helpers shared by every kernel translation unit (lchd_prologue / _env_* / _sweep* / _dense_fused / _kernels .hip):
 // lane shuffles / DPP scans, the table-driven exp / log / pow, the lean CDF evaluation and the tag pairing rule.
 #pragma once
 #include "lchd_device.h"
@@ -252,6 +252,13 @@ __device__ __forceinline__ double cdf_lean(int kind, const double* __restrict__ 
         return (x - p[0]) * inv;
     }
     return cdf_pow_based(kind, p, np, x);
+}
+
+// category id of atom i: low byte | high byte, or -- a structure without high bytes -- the byte itself, its "not in the map" value
+// 255 widened to 0xFFFF (a configuration with more than 255 categories has a category 255)
+__device__ __forceinline__ uint32_t cat_of_atom(const CloudView& c, int64_t i) {
+    const uint32_t lo = c.cat[i];
+    return c.cat_hi ? (lo | ((uint32_t)c.cat_hi[i] << 8)) : (lo == 255u ? 0xFFFFu : lo);
 }
 
 __device__ __forceinline__ void wave_sync_lds() {

@@ -1,6 +1,6 @@
 // lchd_sweep_inc.hip -- K2 for Kullback-Leibler and Renyi divergences in O(1) per event (the common configuration).
 //
-// The generic sweep (k_sweep<.., MODE_GEN, ..>, lchd_kernels.hip) evaluates these distances from scratch at every breakpoint:
+// The generic sweep (k_sweep<.., MODE_GEN, ..>, lchd_sweep.hip) evaluates these distances from scratch at every breakpoint:
 // one logarithm (KL) or one logarithm and one exponential (Renyi) per CATEGORY and event -- 12 and 20 ms per 10^6 C2a pairs
 // against 1.5 ms for the default Hellinger distance, which is updated in O(1).  With unit category weights the PMFs are
 // ratios of small integers (p_c = a_c / N_a, counts <= 512 here), and for a tiny smoothing constant eps the divergences

@@ -1,5 +1,5 @@
 """The thresholded environment build has two kernels and a fall-back chain between them (loco_hd_amd/csrc/lchd_env_group.hip,
-lchd_kernels.hip): k_env_group (several environments per wavefront, 320- and 512-point instantiations, half-threshold grid)
+lchd_env_cells.hip): k_env_group (several environments per wavefront, 320- and 512-point instantiations, half-threshold grid)
 and k_env_cells / k_env_collect (one environment per workgroup, growing capacity).  Every link of the chain is forced here onto
 inputs the CPU oracle can follow (reference: env_from_idx, /root/reference/src/locohd.rs:514-542)."""
 import numpy as np

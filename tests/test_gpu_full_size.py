@@ -64,6 +64,17 @@ def test_c5_full_size(lh, oracle):
     want = np.asarray(lo.from_arrays(w["xyz_a"], w["cat_a"], tag, w["xyz_b"], w["cat_b"], tag, w["pairs"][pick], w["thr"]))
     got = s1.cpu().numpy()[pick]
     assert np.max(np.abs(got - want)) < TIGHT
+    # the host-pointer call on the same job (staging + H2D + pass + D2H inside the call): above 2^18 pairs the
+    # pair list goes out and the scores come back in pipelined chunks copied by several threads -- bit for bit the device-resident scores,
+    # for a count that is not a multiple of the chunk size and with per-pair weight-function indices travelling as well
+    tag = np.zeros(n, dtype=np.int32)
+    pa, pb = lh.api._Packed(w["xyz_a"], w["cat_a"], tag), lh.api._Packed(w["xyz_b"], w["cat_b"], tag)
+    host = lchd.from_packed(pa, pb, w["pairs"][:777_777], w["thr"])
+    assert np.array_equal(host, s1.cpu().numpy()[:777_777])
+    two = lh.LoCoHD(cats, {"a": lh.WeightFunction(*w["wf"]), "b": lh.WeightFunction("uniform", [3.0, 10.0])})
+    wfi = (np.arange(300_001) % 2).astype(np.int32)
+    mixed = two.from_packed(pa, pb, w["pairs"][:300_001], w["thr"], wf_index=wfi)
+    assert np.max(np.abs(mixed[::2] - s1.cpu().numpy()[:300_001:2])) < 1e-13  # (the pairs of function "a")
     sess.close()
 
 
