@@ -663,11 +663,10 @@ bool launch_env_sweep(hipStream_t s, int n_categories, bool tag_list, int rule, 
     const unsigned grid = (unsigned)std::min<int64_t>(blocks, grid_cap > 0 ? grid_cap : 4096);
     const int cm = n_categories;
 #define LCHD_FUSED_CASE(C) (tag_list ? launch_fused_c<true, C>(s, rule, grid, fa) : launch_fused_c<false, C>(s, rule, grid, fa))
+    // (an opt-in path: four slot counts instead of the team sweeps' seven -- 17 .. 28 categories share the 28-slot instantiation)
     if (cm <= 8) LCHD_FUSED_CASE(8);
     else if (cm <= 12) LCHD_FUSED_CASE(12);
     else if (cm <= 16) LCHD_FUSED_CASE(16);
-    else if (cm <= 20) LCHD_FUSED_CASE(20);
-    else if (cm <= 24) LCHD_FUSED_CASE(24);
     else LCHD_FUSED_CASE(28);
 #undef LCHD_FUSED_CASE
     (void)hst; (void)seq;
