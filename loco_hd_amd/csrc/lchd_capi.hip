@@ -321,6 +321,7 @@ static Tuning tuning_from_env() {  // the ONLY place that reads LCHD_* hooks (te
     t.cap_hint = env_int("LCHD_CAP_HINT", 0);
     t.fused = env_int("LCHD_FUSED", 0);
     t.per_pair = env_int("LCHD_PER_PAIR", 0);
+    t.pre_rows = env_int("LCHD_PRE_ROWS", 0);
     t.fused_grid = env_int("LCHD_FUSED_GRID", 0);
     return t;
 }
@@ -908,7 +909,7 @@ struct PassBufs {
     size_t zero_bytes;
 };
 static void carve_pass(Arena& ar, int64_t n_a, int cells_a, int64_t envs_a, int64_t n_b, int cells_b, int64_t envs_b, int cap, int64_t n_pairs,
-                       PassBufs& pb, bool cat16 = false, int key_sets = 1) {
+                       PassBufs& pb, bool cat16 = false, int key_sets = 1, int pre_words_a = 0, int pre_words_b = 0) {
     const size_t ma = (size_t)std::max<int64_t>(n_a, 1), mb = (size_t)std::max<int64_t>(n_b, 1);
     ar.off = (ar.off + 255) & ~size_t(255);
     const size_t z0 = ar.off;
@@ -938,6 +939,9 @@ static void carve_pass(Arena& ar, int64_t n_a, int cells_a, int64_t envs_a, int6
         b.env.cat = ar.take<uint8_t>(ne * (size_t)cap * (cat16 ? 2 : 1));
         b.env.len = ar.take<int32_t>(ne);
         b.env.cat0 = (cap == kEnvGroupCap && !cat16) ? ar.take<uint8_t>(ne) : nullptr;  // (written by k_env_group only: prims_enqueue drops it otherwise)
+        const int pw = side ? pre_words_b : pre_words_a;  // prefix-count rows (k_env_group, configurations of at most 16 categories)
+        b.env.pre = pw > 0 ? ar.take<uint64_t>(ne * (size_t)cap * (size_t)pw) : nullptr;
+        b.env.pre_words = pw;
         b.env.stride = cap;
         b.env.cdf_keys = 0;
         b.env.cat16 = cat16 ? 1 : 0;
@@ -1036,14 +1040,26 @@ static int prims_enqueue(lchd_ctx* c) {
     // (dictionary: set 0 keeps the distances k_env_group writes, k_env_key_sets fills sets 1 .. n_wf; the sweeps' view starts at set 1)
     const bool dict_sets = n_wf > 1 && group && n_wf <= kMaxKeySets && P.wf && !c->tune.no_key_sets && !c->tune.no_cdf_keys && !c->finf_differ;
     const int key_sets = c->tune.no_cdf_keys ? 0 : (n_wf == 1 ? 1 : (dict_sets ? n_wf + 1 : 0));
+    // Prefix-count rows next to the environments (EnvStore::pre, 8 or 16 bytes per point): the team sweeps of up to 16 category slots
+    // read a chunk's start counts from them instead of building a histogram and a scan per tile.  Worth their write when environments
+    // are swept more than once: not for a side without de-duplication (one pair per environment), not for small calls (one pair per
+    // wavefront: the one-launch sweep), only where the team sweeps exist (Hellinger-2 / Kolmogorov-Smirnov on unit weights).
+    int pre_words = 0;
+    {
+        const int cm = std::max(c->h_cfg.n_categories, c->tune.force_cmax);
+        const bool team_cfg = (c->hellinger2 || c->sd_fast == 3) && c->unit_weights && key_sets >= 1 && !c->tune.no_duo && !c->tune.no_count8 &&
+                              !c->tune.no_c8_team && !c->tune.force_generic && !c->tune.force_wide && !c->tune.force_bigenv;
+        if (group && team_cfg && cm <= 16 && !per_pair && !c->deterministic && c->tune.pre_rows >= 0 && (n_pairs > 4096 || c->tune.no_inline_meta || c->tune.pre_rows > 0))
+            pre_words = cm <= 8 ? 1 : 2;
+    }
     PassBufs pb{};
     {
         Arena dry(nullptr, 0, true);
-        carve_pass(dry, a->n, ga.n_cells, max_env_a, b->n, gb.n_cells, max_env_b, cap, n_pairs, pb, cat16, key_sets);
+        carve_pass(dry, a->n, ga.n_cells, max_env_a, b->n, gb.n_cells, max_env_b, cap, n_pairs, pb, cat16, key_sets, pre_words, pre_words);
         if (int rc = ensure_ws(c, dry.off + 4096)) return rc;
     }
     Arena ar(c->ws, c->ws_cap, false);
-    carve_pass(ar, a->n, ga.n_cells, max_env_a, b->n, gb.n_cells, max_env_b, cap, n_pairs, pb, cat16, key_sets);
+    carve_pass(ar, a->n, ga.n_cells, max_env_a, b->n, gb.n_cells, max_env_b, cap, n_pairs, pb, cat16, key_sets, pre_words, pre_words);
     SideBufs &sa = pb.a, &sb = pb.b;
     sa.env.cdf_keys = sb.env.cdf_keys = dict_sets ? 0 : key_sets;  // (what the environment kernels write into set 0)
     if (!group) sa.env.cat0 = sb.env.cat0 = nullptr;

@@ -93,6 +93,7 @@ struct Tuning {
     int fused = 0;                  // LCHD_FUSED: 1 / 3 the fused environment + sweep kernel (lchd_env_fused.hip) whenever it applies, with the 240-event / the 480-event team rule (default 0: never -- measured slower than the two kernels)
     int per_pair = 0;               // LCHD_PER_PAIR: -1 never a side B without de-duplication, 1 whenever it applies, 0: from the previous pass (side-B anchors (almost) all unique)
     int fused_grid = 0;             // LCHD_FUSED_GRID: workgroups of the fused kernel (0: 4096)
+    int pre_rows = 0;               // LCHD_PRE_ROWS: -1 never prefix-count rows next to the environments (the team sweeps build their chunk-start counts per tile), 1 also for small calls, 0: by the rule of prims_enqueue
 };
 
 struct WfEntry {
@@ -168,6 +169,12 @@ struct EnvStore {
                        // sweep needs no CDF evaluation: a pair reads the set of its weight function); 0: keys are the distances
     int32_t cat16;     // 1: `cat` holds 16-bit category ids (more than 255 categories): two bytes per point
     int64_t set_stride;  // elements between two key sets (slots x stride); categories and lengths exist once
+    uint64_t* pre;       // prefix-count rows, or null: row i of environment e = pre[(e * stride + i) * pre_words ...] = the category counts of the
+                         // environment's first i + 1 sorted points as 8-bit fields (slot c in byte c % 8 of word c / 8), written by
+                         // k_env_group for configurations of at most 16 categories: the team sweeps read a chunk's start counts
+                         // from them instead of building a histogram and a scan per tile (lchd_team_tile.h, PRE)
+    int32_t pre_words;   // u64 words per row (1: up to 8 categories, 2: up to 16)
+    int32_t pad_pre;
     uint8_t* cat0;       // [slots] category of every environment's first (sorted) point, or null: what k_pair_meta puts into the pair records -- one
                          // gather into a small array instead of one into the store itself (k_env_group writes it; the other environment kernels do not)
 };

@@ -109,6 +109,12 @@ void env_group_overflow(const LCHD_AS4 EnvSide* p, DeviceStatus* st, int side, i
     p->env.key[(uint32_t)e << 9] = 0ull;  // distance 0 = F(0) bits for the weight functions of cdfs.rs (all start at 0)
     p->env.cat[(uint32_t)e << 9] = (int)cat < n_cat ? (uint8_t)cat : (uint8_t)0;
     if (p->env.cat0) p->env.cat0[e] = (int)cat < n_cat ? (uint8_t)cat : (uint8_t)0;
+    if (p->env.pre) {  // (row 0 of the one-point environment)
+        const uint32_t cs = (int)cat < n_cat ? cat : 0u;
+        const uint64_t one = 1ull << ((cs & 7u) * 8u);
+        if (p->env.pre_words > 1) { p->env.pre[((size_t)(uint32_t)e << 9) * 2] = cs < 8u ? one : 0ull; p->env.pre[((size_t)(uint32_t)e << 9) * 2 + 1] = cs >= 8u ? one : 0ull; }
+        else p->env.pre[(size_t)(uint32_t)e << 9] = one;
+    }
 }
 
 #ifndef LCHD_CAT0_STORE
@@ -480,6 +486,34 @@ __global__ __launch_bounds__(64 * LCHD_GROUP_WPB) __attribute__((amdgpu_waves_pe
                 for (int i = lf; i < n; i += 64) {
                     const uint32_t q = (uint32_t)lds.val[i] >> 8;
                     okey[(uint32_t)(((e_first + (int)q) << 9) + (i - (int)lds.gstart[q]))] = lds.key[i];
+                }
+            }
+            // prefix-count rows (EnvStore::pre): per environment an inclusive scan of the sorted points' one-hot category fields -- 8-bit
+            // fields, one or two u64 words per point; the team sweeps read a lane's chunk-start counts from them (lchd_team_tile.h, PRE).
+            // (An environment of more than 255 points overflows its fields: no team rule sweeps such a pair.)
+            if (p->env.pre) {
+                uint64_t* __restrict__ opre = p->env.pre;
+                const int nw = p->env.pre_words;
+                for (int q = 0; q < G; ++q) {
+                    const int s0 = (int)lds.gstart[q], c0 = (int)lds.gcount[q];
+                    const uint32_t row0 = (uint32_t)((e_first + q) << 9);
+                    uint64_t car0 = 0ull, car1 = 0ull;
+                    for (int i0 = 0; i0 < c0; i0 += 64) {
+                        const int i = i0 + lf;
+                        const bool act = i < c0;
+                        const uint32_t cat_raw = (uint32_t)lds.val[s0 + (act ? i : 0)] & 0xFFu;
+                        const uint32_t cat = (int)cat_raw < n_cat ? cat_raw : 0u;  // (as stored)
+                        const uint64_t one = act ? (1ull << ((cat & 7u) * 8u)) : 0ull;
+                        const uint64_t w0 = wave_incl_scan_fields((cat < 8u) ? one : 0ull) + car0;
+                        car0 = readlane_u64(w0, 63);
+                        if (nw > 1) {
+                            const uint64_t w1 = wave_incl_scan_fields((cat >= 8u) ? one : 0ull) + car1;
+                            car1 = readlane_u64(w1, 63);
+                            if (act) { opre[(size_t)(row0 + (uint32_t)i) * 2] = w0; opre[(size_t)(row0 + (uint32_t)i) * 2 + 1] = w1; }
+                        } else if (act) {
+                            opre[row0 + (uint32_t)i] = w0;
+                        }
+                    }
                 }
             }
             if (lf < G) {

@@ -36,10 +36,10 @@ namespace lchd {
 #ifndef LCHD_WGT_W3
 #define LCHD_WGT_W3 0       // 1: ... are compiled for 3 waves per SIMD (170 registers: no spills)
 #endif
-template <int CMAX, int TL = LCHD_DUO_TL, int TILE_ = kDuoTile, bool WGT = false, bool KSM = false>
+template <int CMAX, int TL = LCHD_DUO_TL, int TILE_ = kDuoTile, bool WGT = false, bool KSM = false, bool PRE = false>
 __global__ __launch_bounds__(64 * kSweepWaves, ((CMAX <= 16 && !(WGT && CMAX > 8 && (LCHD_WGT_LDSCNT || LCHD_WGT_W3))) ? 4 : LCHD_TEAM_BIG_WAVES)) void k_sweep_duo(SweepArgs args) {
     // (the tile itself -- merge path, chunk histogram, count scans, event loop, stitching -- is lchd_team_tile.h: shared with k_env_sweep)
-    using TT = TeamTile<CMAX, TL, TILE_, WGT, KSM>;
+    using TT = TeamTile<CMAX, TL, TILE_, WGT, KSM, PRE>;
     constexpr int TEAMS = TT::TEAMS, EPL = TT::EPL, TILE = TT::TILE, WPB = kSweepWaves, NT = TT::NT, LW = TT::LW;
     constexpr bool LCNT = TT::LCNT;
     constexpr int RULE = TILE_ == kDuoTile ? 0 : 2;
@@ -183,28 +183,41 @@ __global__ __launch_bounds__(64 * kSweepWaves, ((CMAX <= 16 && !(WGT && CMAX > 8
 #endif
         wave_sync_lds();
 
-        const double acc = TT::run(sA, cA, sB, cB, mA, mB, T, epl, epl_w, c0a, c0b, F0, Finf0, t_sqrt, t_rsqrt, w_s, lcl, tl);
+        // (PRE: the prefix-count rows of the two environments; an unusable pair's records may name slots that do not exist: row 0 of slot 0)
+        const uint64_t* preA = PRE ? args.env_a.pre + (valid ? offA * (uint64_t)TT::NW : 0ull) : nullptr;
+        const uint64_t* preB = PRE ? args.env_b.pre + (valid ? offB * (uint64_t)TT::NW : 0ull) : nullptr;
+        const double acc = TT::run(sA, cA, sB, cB, mA, mB, T, epl, epl_w, c0a, c0b, F0, Finf0, t_sqrt, t_rsqrt, w_s, lcl, tl, preA, preB);
         if (tl == TL - 1 && live && mine) args.out[p] = valid ? acc : nan("");  // (categories were checked when the environments were built)
     }
 }
 
-template <int CM, int TM>
+template <int CM, int TM, bool PRE>
 static void launch_team_c(hipStream_t s, bool tile240, unsigned grid, const SweepArgs& a) {
     constexpr int NTH = 64 * kSweepWaves;
     constexpr bool WGT = TM == 1, KSM = TM == 2;
-    if (tile240) k_sweep_duo<CM, LCHD_DUO_TL, kDuoTile, WGT, KSM><<<grid, NTH, 0, s>>>(a);
-    else k_sweep_duo<CM, 32, kTeam8Tile, WGT, KSM><<<grid, NTH, 0, s>>>(a);
+    if (tile240) k_sweep_duo<CM, LCHD_DUO_TL, kDuoTile, WGT, KSM, PRE><<<grid, NTH, 0, s>>>(a);
+    else k_sweep_duo<CM, 32, kTeam8Tile, WGT, KSM, PRE><<<grid, NTH, 0, s>>>(a);
 }
 template <int TM>
 static void launch_team_t(hipStream_t s, int cmax, bool tile240, unsigned grid, const SweepArgs& a) {
-    if (cmax <= 8) launch_team_c<8, TM>(s, tile240, grid, a);
-    else if (cmax <= 12) launch_team_c<12, TM>(s, tile240, grid, a);
-    else if (cmax <= 16 || TM != 0) launch_team_c<16, TM>(s, tile240, grid, a);  // (weights / Kolmogorov-Smirnov: at most 16 slots, checked by launch_sweep)
+    // both stores carry prefix-count rows of the width this slot count reads (k_env_group wrote them): the PRE instantiations
+    if constexpr (TM != 1) {
+        const int nw = cmax <= 8 ? 1 : 2;
+        if (cmax <= 16 && a.env_a.pre && a.env_b.pre && a.env_a.pre_words == nw && a.env_b.pre_words == nw) {
+            if (cmax <= 8) launch_team_c<8, TM, true>(s, tile240, grid, a);
+            else if (cmax <= 12) launch_team_c<12, TM, true>(s, tile240, grid, a);
+            else launch_team_c<16, TM, true>(s, tile240, grid, a);
+            return;
+        }
+    }
+    if (cmax <= 8) launch_team_c<8, TM, false>(s, tile240, grid, a);
+    else if (cmax <= 12) launch_team_c<12, TM, false>(s, tile240, grid, a);
+    else if (cmax <= 16 || TM != 0) launch_team_c<16, TM, false>(s, tile240, grid, a);  // (weights / Kolmogorov-Smirnov: at most 16 slots, checked by launch_sweep)
     else if constexpr (TM == 0) {
-        if (cmax <= 20) launch_team_c<20, 0>(s, tile240, grid, a);
-        else if (cmax <= 24) launch_team_c<24, 0>(s, tile240, grid, a);
-        else if (cmax <= 28) launch_team_c<28, 0>(s, tile240, grid, a);
-        else launch_team_c<32, 0>(s, tile240, grid, a);
+        if (cmax <= 20) launch_team_c<20, 0, false>(s, tile240, grid, a);
+        else if (cmax <= 24) launch_team_c<24, 0, false>(s, tile240, grid, a);
+        else if (cmax <= 28) launch_team_c<28, 0, false>(s, tile240, grid, a);
+        else launch_team_c<32, 0, false>(s, tile240, grid, a);
     }
 }
 void launch_team(hipStream_t s, int cmax, int tm, bool tile240, unsigned grid, const SweepArgs& a) {

@@ -108,7 +108,11 @@ __device__ __forceinline__ double team_sum_f64(double v) {  // the last lane of 
 
 // CMAX category slots, teams of TL lanes, pairs of at most TILE_ merged events; WGT: category weights other than 1; KSM: the
 // Kolmogorov-Smirnov distance on unit weights (see k_sweep_duo for the two forms).
-template <int CMAX, int TL, int TILE_, bool WGT = false, bool KSM = false>
+// PRE: the packed counts at a lane's chunk start are READ from the environments' prefix-count rows (EnvStore::pre: row r = the counts
+// of the first r + 1 sorted points of the environment, the anchor included, as 8-bit fields -- written once per environment by
+// k_env_group) instead of being built per tile from a histogram of the lane's chunk and a scan over the team: the position the merge
+// path hands a lane IS the row index.  An environment that is swept many times (C2a: 100 pairs per anchor) pays for its rows once.
+template <int CMAX, int TL, int TILE_, bool WGT = false, bool KSM = false, bool PRE = false>
 struct TeamTile {
     static_assert(!KSM || (!WGT && CMAX <= 16), "the Kolmogorov-Smirnov form: unit weights, one or two count words per side");
     static_assert(TL == 16 || TL == 32, "a team is one or two DPP rows");
@@ -134,6 +138,7 @@ struct TeamTile {
     // -- what these instantiations are compiled for -- still fit up to 28 slots; with 32 they would not (registers there).
     static constexpr bool LCNT = (((CMAX > 16) && (CMAX <= 28)) || (WGT && (LCHD_WGT_LDSCNT != 0) && CMAX > 8 && CMAX <= 16)) && (LCHD_TEAM_LDSCNT != 0);
     static constexpr int LW = LCNT ? (2 * CMAX + 7) / 8 : 1;  // u64 words of a lane's LDS count row ([LW][64] per wavefront)
+    static_assert(!PRE || (!LCNT && !WGT && CMAX <= 16), "prefix-count rows: the register-resident forms of up to two count words per side");
 
     // sA / cA, sB / cB: the two staged lists (mA, mB points; spare entries behind each: the head re-reads may touch one past the end);
     // T = mA + mB; epl = ceil(T / TL); epl_w = the largest epl of the wavefront's teams (wave-uniform trip counts);
@@ -143,7 +148,8 @@ struct TeamTile {
     static __device__ __forceinline__ double run(const uint64_t* sA, const uint8_t* cA, const uint64_t* sB, const uint8_t* cB, const int mA,
                                                  const int mB, const int T, const int epl, const int epl_w, const int c0a, const int c0b,
                                                  const double F0, const double Finf0, const double* t_sqrt, const double* t_rsqrt,
-                                                 const double* w_s, unsigned char* lcl, const int tl) {
+                                                 const double* w_s, unsigned char* lcl, const int tl,
+                                                 const uint64_t* __restrict__ preA = nullptr, const uint64_t* __restrict__ preB = nullptr) {
         auto field = [&](const uint64_t (&ex)[NW], int c) -> int { return (int)((ex[c / FPW] >> ((c % FPW) * FB)) & 0xFFull); };
         const double H0 = (c0a == c0b) ? 0.0 : 1.0;            // two point masses
         // lane tl of a team owns merged events [d0, d1) of its pair
@@ -153,6 +159,15 @@ struct TeamTile {
         if (tl == 0) i0 = 0;
         const int j0 = d0 - i0, j1 = d1 - i1;
 
+        uint64_t exA[NW], exB[NW];
+        if constexpr (PRE) {
+            // the rows of the two chunk starts: i0 / j0 non-anchor points of A / B lie before this lane's first event
+#pragma unroll
+            for (int k = 0; k < NW; ++k) {
+                exA[k] = preA[(size_t)i0 * NW + k];
+                exB[k] = preB[(size_t)j0 * NW + k];
+            }
+        } else {
         // pass 1: 4-bit-per-category histogram of the lane's chunk
         H4 hA[NH], hB[NH];
 #pragma unroll
@@ -209,7 +224,6 @@ struct TeamTile {
             for (int w = 0; w < NH; ++w) hB[w] = hT[w] - hA[w];
         }
         // packed counts at the start of the chunk: the anchors + an exclusive scan over the team's lanes
-        uint64_t exA[NW], exB[NW];
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
             uint64_t va_, vb_;
@@ -233,6 +247,7 @@ struct TeamTile {
             }
             exA[k] = (((c0a / FPW) == k) ? (1ull << ((c0a % FPW) * FB)) : 0ull) + sa_ - va_;
             exB[k] = (((c0b / FPW) == k) ? (1ull << ((c0b % FPW) * FB)) : 0ull) + sb_ - vb_;
+        }
         }
         double D = 0.0;  // (points seen per side incl. the anchor: 1 + i and 1 + j -- the list positions ARE the totals)
         double na = 0.0, nb = 0.0;  // WGT: weighted totals of the two sides

@@ -842,3 +842,54 @@ def test_deterministic_switch_makes_a_pairs_score_independent_of_batch_and_histo
     whole = np.asarray(det.from_primitives(pa, pb, all_pairs * 4, 10.0))[:1500]  # 6000 pairs: the regular pass
     few = np.asarray(det.from_primitives(pa, pb, all_pairs[:64], 10.0))          # 64 pairs: would be the one-launch sweep by default
     assert np.array_equal(whole[:64], few)
+
+
+@pytest.mark.parametrize("n_cat,sd", [(5, None), (8, None), (12, None), (16, None), (11, ("Kolmogorov-Smirnov", []))])
+def test_prefix_count_rows_give_the_same_bits_as_the_per_tile_histogram(lh, oracle, monkeypatch, n_cat, sd):
+    """Configurations of at most 16 categories: k_env_group writes prefix-count rows next to every environment (EnvStore::pre) and the
+    team sweeps read a chunk's start counts from them (lchd_team_tile.h, PRE) instead of a histogram + scan per tile -- integer counts
+    either way, so the scores are bitwise those of LCHD_PRE_ROWS=-1; both follow the oracle (pmf.rs:47-63 counts the same points).
+    Lattice coordinates (exact ties), one object on both sides, a weight-function dictionary and a tag rule ride along."""
+    import torch
+    from loco_hd_amd.device import DeviceSession
+
+    rng = np.random.default_rng(40 + n_cat)
+    cats = [f"c{i}" for i in range(n_cat)]
+    n = 2600
+    side = (n / 0.03) ** (1 / 3)
+    xa, xb = np.round(rng.uniform(0, side, (n, 3)) * 2) / 2, rng.uniform(0, side, (n, 3))
+    ca, cb = rng.integers(0, n_cat, n).astype(np.int32), rng.integers(0, n_cat, n).astype(np.int32)
+    tag = (np.arange(n) // 3).astype(np.int32)
+    pairs = np.stack([rng.integers(0, n, 9000), rng.integers(0, n, 9000)], 1).astype(np.int64)  # every anchor in several pairs
+    wfi = (np.arange(9000) % 2).astype(np.int32)
+
+    def build(mod, dictionary):
+        wf = mod.WeightFunction("hyper_exp", [1.0, 0.12])
+        if dictionary:
+            wf = {"a": wf, "b": mod.WeightFunction("uniform", [2.0, 9.5])}
+        kw = {} if sd is None else {"statistical_distance": mod.StatisticalDistance(*sd)}
+        return mod.LoCoHD(cats, wf, mod.TagPairingRule({"accept_same": False}), **kw)
+
+    for dictionary in (False, True):
+        lo = build(oracle, dictionary)
+        extra = lo._wfs(["ab"[k] for k in wfi], len(pairs)) if dictionary else ()
+        want_ab = np.asarray(lo.from_arrays(xa, ca, tag, xb, cb, tag, pairs, 9.0, *extra))
+        want_aa = np.asarray(lo.from_arrays(xa, ca, tag, xa, ca, tag, pairs, 9.0, *extra))
+        got = {}
+        for hook in ("-1", "0"):
+            monkeypatch.setenv("LCHD_PRE_ROWS", hook)
+            sess = DeviceSession(build(lh, dictionary))
+            monkeypatch.delenv("LCHD_PRE_ROWS")
+            a, b = sess.upload(xa, ca, tag), sess.upload(xb, cb, tag)
+            d_pairs = torch.from_numpy(pairs).cuda()
+            d_wfi = torch.from_numpy(wfi).cuda() if dictionary else None
+            outs = []
+            for _ in range(3):  # first pass: the device picks the sweeps; later passes: the hinted launch set
+                outs.append((sess.from_primitives(a, b, d_pairs, 9.0, wf_index=d_wfi).cpu().numpy(),
+                             sess.from_primitives(a, a, d_pairs, 9.0, wf_index=d_wfi).cpu().numpy()))
+            sess.close()
+            got[hook] = outs
+            for ab, aa in outs:
+                assert np.max(np.abs(ab - want_ab)) < 1e-11 and np.max(np.abs(aa - want_aa)) < 1e-11
+        for (ab0, aa0), (ab1, aa1) in zip(got["-1"], got["0"]):
+            assert np.array_equal(ab0, ab1) and np.array_equal(aa0, aa1)
