@@ -60,7 +60,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 PRIME_STEPS = 6  # untimed set-up passes in front of the warm-up steps (Harness.run)
 
 
@@ -425,7 +425,9 @@ def run_c4(args, torch, dist, dev, rank, world, use_dist):
         result = base_result(args, world, p * world, elapsed, label, {"pairs_per_gpu": p, "mean_env_points_per_pair": env_points[0] / p,
                                                                       "sharding": "frames across ranks, no exchange step, scores stay on their rank",
                                                                       "sessions": n_sess})
-        result["roofline"] = roofline_block("c4", {"env": "k_env_group (side A + side B)", "sweep": "k_sweep_duo<8, 16 lanes, 240 events> (four pairs per wavefront)"}[dom], algo / len(starts),
+        result["roofline"] = roofline_block("c4" if dom == "sweep" else "c4_env",
+                                            {"env": "k_env_group<false, 320, 6> (four environments per wavefront; side B: one environment per pair, no de-duplication)",
+                                             "sweep": "k_sweep_duo<8, 16 lanes, 240 events> (four pairs per wavefront)"}[dom], algo / len(starts),
                                             phase[dom] / len(starts), len(starts), step_ms=result["ms_per_step"])
         result["kernel_ms"] = phase
         result["extras"] = {"k_frames_centroids": {"ms_per_step": phase["convert"], "algorithmic_bytes_per_step": conv_bytes,
@@ -886,7 +888,7 @@ def run_pairs(args, torch, dist, dev, rank, world, use_dist):
         algo_bytes = env_points * 28 + 16 * pairs_this_rank  # B_pair = (n_A + n_B) * 28 B + 8 B + 8 B
         dom = max(("env", "sweep"), key=lambda k: phase_ms[k])
         dom_name = {"env": "k_env_group (side A + side B in one launch)",
-                    "sweep": "k_sweep_duo<slots, 32 lanes, 480 events> (two pairs per wavefront; its launch and the k_pair_meta record pass in front of it)"}[dom]
+                    "sweep": "k_sweep_duo<slots, 32 lanes, 480 events> (two pairs per wavefront; chunk-start counts from the environments' prefix-count rows up to 16 slots; its launch, the k_pair_meta record pass in front of it and the INDIRECT sweep for the few larger pairs)"}[dom]
         result = base_result(args, world, total_pairs, elapsed, w["label"],
                              {"pairs_total" if strong else "pairs_per_gpu": p, "pairs_this_rank": pairs_this_rank,
                               "mean_env_points_per_pair": env_points / max(pairs_this_rank, 1),

@@ -15,10 +15,12 @@ import sys
 
 # (c4: since round 3 the sweep is the longer phase; `c4_env`, `c5_env` describe the environment kernel of those workloads; the small-pair
 # sweeps are k_sweep_duo<slots, lanes per pair, events per pair>: four pairs per wavefront for C3 / C4, two for C2a / C5)
-DOMINANT = {"c2a": "k_sweep_duo<12, 32, 480, false, false>", "c5": "k_sweep_duo<28, 32, 480, false, false>", "c4": "k_sweep_duo<8, 16, 240, false, false>",
-            "c3": "k_sweep_duo<8, 16, 240, false, false>",
+DOMINANT = {"c2a": "k_sweep_duo<12, 32, 480, false, false, true>", "c5": "k_sweep_duo<28, 32, 480, false, false, false>",
+            "c4": "k_sweep_duo<8, 16, 240, false, false, false>", "c3": "k_sweep_duo<8, 16, 240, false, false, true>",
             "c2b": "k_dense_fused<12, false>",
             "c4_env": "k_env_group<false, 320", "c5_env": "k_env_group<false, 320"}
+# (round 5: the sixth template argument of k_sweep_duo says whether the chunk-start counts come from the environments' prefix-count rows:
+#  C2a / C3 yes; C4 -- side B without de-duplication, one pair per environment -- and C5 -- 28 category slots -- no)
 
 
 def main(workload, summary, stats):
