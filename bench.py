@@ -853,13 +853,17 @@ def run_pairs(args, torch, dist, dev, rank, world, use_dist):
         # staging block + ONE H2D copy of structures and pairs + the pass + ONE D2H copy of the scores, all inside the call)
         pa = lh.api._Packed(w["xyz_a"], w["cat_a"], np.zeros(w["n"], np.int32))
         pb = lh.api._Packed(w["xyz_b"], w["cat_b"], np.zeros(w["n"], np.int32))
-        host_scores = lchd.from_packed(pa, pb, w["pairs"], w["thr"])  # (first call: the context's staging block grows)
-        th = time.perf_counter()
-        for _ in range(3):
+        for _ in range(2):  # (first call: the context's staging block grows; second: the launch set picked from the first pass's pair statistics)
             host_scores = lchd.from_packed(pa, pb, w["pairs"], w["thr"])
-        th = (time.perf_counter() - th) / 3
+        ths = []
+        for _ in range(5):
+            th = time.perf_counter()
+            host_scores = lchd.from_packed(pa, pb, w["pairs"], w["thr"])
+            ths.append(time.perf_counter() - th)
+        th = float(np.median(ths))
         value_incl = {"value": p / th, "unit": "pairs/s", "ms_per_call": th * 1e3,
-                      "what": "LoCoHD.from_packed on host arrays: staging + H2D of both structures and the pair list + pass + D2H of the scores"}
+                      "what": "LoCoHD.from_packed on host arrays (median of 5 calls): staging + H2D of both structures and the pair list + pass + D2H of the "
+                              "scores; above 2^18 pairs the list and the scores travel in pipelined chunks copied by up to four threads"}
         extras["host_call_scores_equal_device_resident"] = None  # filled below
     # environment points of this rank's pairs (algorithmic bytes), and the scores to check
     if strong:

@@ -322,6 +322,7 @@ static Tuning tuning_from_env() {  // the ONLY place that reads LCHD_* hooks (te
     t.fused = env_int("LCHD_FUSED", 0);
     t.per_pair = env_int("LCHD_PER_PAIR", 0);
     t.pre_rows = env_int("LCHD_PRE_ROWS", 0);
+    t.pipe = env_int("LCHD_PIPE", 0);
     t.fused_grid = env_int("LCHD_FUSED_GRID", 0);
     return t;
 }
@@ -1770,7 +1771,7 @@ static int host_call_enqueue(lchd_ctx* c, const lchd_config* cfg, const double* 
     int64_t* ha = reinterpret_cast<int64_t*>(c->h_io + o_anchors);
     int32_t* hw = reinterpret_cast<int32_t*>(c->h_io + o_wf);
     bool piped = false;
-    if (!subset && n >= kPipePairs) {
+    if (!subset && n >= kPipePairs && c->tune.pipe >= 0) {
         // the structures (and whatever lies in front of the pair list) first, then the list chunk by chunk: the copy of chunk k + 1
         // into the staging block overlaps the DMA of chunk k
         HIP_TRY(hipMemcpyAsync(c->d_io, c->h_io, o_anchors, hipMemcpyHostToDevice, c->stream));
@@ -1809,7 +1810,7 @@ static int host_call_finish(lchd_ctx* c, HostCall& hc, const int64_t* subset, do
     hc.enqueued = false;
     CTX_GUARD(c);
     int rc = lchd_ctx_finish(c);
-    if (!rc && !hc.direct && !subset && hc.n >= kPipePairs) {
+    if (!rc && !hc.direct && !subset && hc.n >= kPipePairs && c->tune.pipe >= 0) {
         // the scores come back in chunks: chunk k is copied out to the caller's array while the DMA engine fetches chunk k + 1
         const int64_t chunk = std::max<int64_t>(kPipePairs, (hc.n + 3) / 4);
         hipError_t e = hipSuccess;

@@ -93,6 +93,7 @@ struct Tuning {
     int fused = 0;                  // LCHD_FUSED: 1 / 3 the fused environment + sweep kernel (lchd_env_fused.hip) whenever it applies, with the 240-event / the 480-event team rule (default 0: never -- measured slower than the two kernels)
     int per_pair = 0;               // LCHD_PER_PAIR: -1 never a side B without de-duplication, 1 whenever it applies, 0: from the previous pass (side-B anchors (almost) all unique)
     int fused_grid = 0;             // LCHD_FUSED_GRID: workgroups of the fused kernel (0: 4096)
+    int pipe = 0;                   // LCHD_PIPE: -1 large host-pointer calls stage their pair list and scores in one piece (no chunked, multi-threaded copies)
     int pre_rows = 0;               // LCHD_PRE_ROWS: -1 never prefix-count rows next to the environments (the team sweeps build their chunk-start counts per tile), 1 also for small calls, 0: by the rule of prims_enqueue
 };
 

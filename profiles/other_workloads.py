@@ -134,7 +134,7 @@ s2.close()
 # ---- host-pointer API (lchd_from_primitives: packing + H2D + D2H inside the call) ------------------------------------------
 pa, pb = lh.api._Packed(w["xyz_a"], w["cat_a"], np.zeros(w["n"], np.int32)), lh.api._Packed(w["xyz_b"], w["cat_b"], np.zeros(w["n"], np.int32))
 for m in (10_000, 1_000_000):
-    t = timed(lambda: l2.from_packed(pa, pb, w["pairs"][:m], w["thr"]), reps=3, warm=1)
+    t = timed(lambda: l2.from_packed(pa, pb, w["pairs"][:m], w["thr"]), reps=6, warm=3)
     res[f"host_pointer_call_{m}_pairs"] = {"ms": t, "pairs_per_s": m / t * 1e3}
 
 # ---- C2b dense from_coords --------------------------------------------------------------------------------------------
