@@ -22,7 +22,7 @@ def pytest_sessionstart(session):
     ext = list((ROOT / "loco_hd_amd").glob("_fastpack*.so"))
     newest = max(p.stat().st_mtime for p in srcs)
     if not lib.exists() or not ext or min(lib.stat().st_mtime, ext[0].stat().st_mtime) < newest:
-        subprocess.check_call(["make", "-C", str(ROOT / "loco_hd_amd" / "csrc"), "-j4"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", str(ROOT / "loco_hd_amd" / "csrc"), "-j8"], stdout=subprocess.DEVNULL)
 
 
 @pytest.fixture(scope="session")
