@@ -246,7 +246,10 @@ int32_t lchd_ctx_last_dense_fused(lchd_ctx *ctx);
  * on != 0 pins ONE sweep family (one pair per wavefront, global-memory tables; dense rows through the row sort + that sweep) and
  * switches every history-dependent choice off: a pair's score is then a function of the pair and the configuration alone --
  * bitwise equal across batch composition, call order, sharding and second passes -- at roughly half the default throughput.
- * on == 0 returns to the default selection.  Not allowed while an asynchronous call is pending. */
+ * on == 0 returns to the default selection.  Not allowed while an asynchronous call is pending.
+ * (In every mode: points of DIFFERENT categories at EXACTLY the same distance from an anchor -- lattice coordinates -- enter an
+ * environment in the order the cell list's atomics produced, which may differ from run to run; they span zero-width intervals, so only
+ * the rounding of the running sums differs: a few 1e-16 in a handful of pairs.  Inputs without such ties are bit-reproducible.) */
 int lchd_ctx_set_deterministic(lchd_ctx *ctx, int32_t on);
 int32_t lchd_ctx_get_deterministic(lchd_ctx *ctx);
 /* from_primitives passes the context has enqueued since it was created.  A call is one pass in the steady state; a pass is
