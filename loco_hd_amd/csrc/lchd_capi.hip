@@ -205,6 +205,7 @@ struct lchd_ctx {
     // REGULAR pass of the configuration found (almost) every side-B anchor unique; every kFusedRemeasure-th pass is a regular one again
     // (a fused pass does not de-duplicate side B, so it cannot see the anchors becoming shared)
     bool b_use_once = false;        // the last regular pass: n_unique[1] >= 0.8 n_pairs
+    int64_t use_once_pairs = 0, use_once_nb = 0;  // ... its pair count and the size of its side B (the hint holds for lists like it)
     int fused_streak = 0;           // fused passes since the last regular one
     bool fused_companion = true;    // the last fused pass left pairs to the INDIRECT sweep (or nothing is known): launch it
     bool fused_blocked = false;     // a fused pass of this configuration met an environment beyond its group buffer: the regular pipeline from now on
@@ -1015,7 +1016,10 @@ static int prims_enqueue(lchd_ctx* c) {
     // the side's atoms.  Any choice is correct for any input: an anchor that occurs in several pairs is built once per pair, as the
     // reference does (src/locohd.rs:514-554).  Every 64th pass is a regular one again (this mode does not count unique anchors).
     const bool per_pair_ok = group && !same && !P.subset && !c->deterministic && c->tune.per_pair >= 0 && n_pairs < ((int64_t)1 << 22) && n_pairs > 0;
-    bool per_pair = per_pair_ok && (c->tune.per_pair > 0 || (c->b_use_once && !c->fused_blocked && n_pairs > 4096 && c->fused_streak < 64));
+    // (history alone is not enough: the hint must have come from a list of this size on a structure of this size, and a list with more
+    //  pairs than the side has atoms repeats anchors by counting -- C2a: 10^6 pairs over 10^4 atoms right after a list of (i, i) pairs)
+    const bool like_hinted = n_pairs <= b->n && b->n == c->use_once_nb && 2 * n_pairs >= c->use_once_pairs && n_pairs <= 2 * c->use_once_pairs;
+    bool per_pair = per_pair_ok && (c->tune.per_pair > 0 || (c->b_use_once && like_hinted && !c->fused_blocked && n_pairs > 4096 && c->fused_streak < 64));
     // ... and, opt-in (LCHD_FUSED=1 / 3: measured SLOWER than the two kernels on every named workload), side B's
     // environments built, sorted and swept inside ONE kernel (lchd_env_fused.hip): the default configuration only (Hellinger-2, unit
     // weights, one weight function, CDF keys)
@@ -1386,11 +1390,16 @@ static int finish_passes(lchd_ctx* c, uint32_t* flags_out) {
         if (biggest > 0) { c->group_small = biggest <= kEnvGroupSmallUpTo; c->last_biggest = biggest; }
         if (!P.subset) {
             if (P.per_pair) {
-                ++c->fused_streak;  // (this pass did not count side B's unique anchors: the hint stands)
+                ++c->fused_streak;
                 ++c->n_per_pair_passes;
-            } else {  // (almost) every side-B anchor unique: the next passes of this context do not de-duplicate side B
+                // (this pass did not count side B's unique anchors; its bit set counts the repeated ones: a list that shares
+                //  more than a fifth of them goes back to the regular pipeline with the next pass)
+                if ((unsigned long long)c->h_status->n_dup_b * 5ull > (unsigned long long)P.n_pairs) c->b_use_once = false;
+            } else {  // (almost) every side-B anchor unique: the next passes of this context on such lists do not de-duplicate side B
                 const bool same_obj = P.sw.slot_a == P.sw.slot_b;
                 c->b_use_once = !same_obj && (unsigned long long)c->h_status->n_unique[1] * 5ull >= (unsigned long long)P.n_pairs * 4ull;
+                c->use_once_pairs = P.n_pairs;
+                c->use_once_nb = P.b ? P.b->n : 0;
                 c->fused_streak = 0;
             }
         }

@@ -44,7 +44,9 @@ struct DeviceStatus {
     unsigned long long n_small;     // pairs under the pass's first-choice small rule (k_pair_meta): who sweeps them is decided on the device
     unsigned long long n_c8;        // pairs under SweepArgs::c8_rule (the second choice of a pass without a hint)
     uint32_t max_bound;      // k_env_group: most CANDIDATES of an anchor whose candidate table overflowed (an upper bound of its environment; max_env
-    uint32_t pad_;           //  then only says "more than the capacity"); reset with the flags
+                             //  then only says "more than the capacity"); reset with the flags
+    uint32_t n_dup_b;        // a pass without de-duplication of side B (k_pair_anchor_recs): pairs whose side-B anchor another pair of the list had
+                             //  marked before (a bit set in the side's flag region, one returning atomic per pair); reset with the flags
 };
 // Host-mapped (pinned, device-visible) mirror: written with plain stores only -- the snapshot by one thread of k_pair_meta,
 // the error words by whichever sweep wavefront meets the (rare) condition; every writer of a word stores the same value.
@@ -59,7 +61,7 @@ struct HostStatus {
     unsigned long long n_duo, n_c8;  // pairs of at most kDuoTile merged events / with both environments <= 255 points (both always counted)
     uint32_t n_overflow[2];  // DeviceStatus::n_overflow at the end of the record pass
     uint32_t max_bound;      // DeviceStatus::max_bound
-    uint32_t pad2;
+    uint32_t n_dup_b;        // DeviceStatus::n_dup_b
 };
 
 // Test / tuning hooks.  Read from the environment ONCE, when a context is created (lchd_ctx_create), and handed to the

@@ -635,12 +635,14 @@ __global__ __launch_bounds__(64) void k_fused_publish(FusedArgs fa, HostStatus* 
     hst->n_overflow[0] = st->n_overflow[0];
     hst->n_overflow[1] = 0u;
     hst->max_bound = __hip_atomic_load(&st->max_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    hst->n_dup_b = 0u;
     hst->snapshot_seq = seq;
     st->flags = 0u;
     st->max_env = 0u;
     st->n_overflow[0] = 0u;
     st->n_overflow[1] = 0u;
     st->max_bound = 0u;
+    st->n_dup_b = 0u;
 }
 
 template <bool TAGLIST, int CMAX>

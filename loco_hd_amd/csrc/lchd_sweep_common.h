@@ -153,12 +153,14 @@ __device__ __forceinline__ void publish_status(const SweepArgs& args, unsigned l
     h->n_overflow[0] = st->n_overflow[0];
     h->n_overflow[1] = st->n_overflow[1];
     h->max_bound = __hip_atomic_load(&st->max_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    h->n_dup_b = __hip_atomic_load(&st->n_dup_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     h->snapshot_seq = args.seq;
     st->flags = 0u;
     st->max_env = 0u;
     st->n_overflow[0] = 0u;
     st->n_overflow[1] = 0u;
     st->max_bound = 0u;
+    st->n_dup_b = 0u;
 }
 
 

@@ -154,7 +154,19 @@ def test_side_b_is_not_deduplicated_when_its_anchors_are_used_once(lh, oracle, m
         assert np.max(np.abs(g - want_once)) < TIGHT
     # shared side-B anchors: the fused pass that meets them is still correct; the periodic regular pass would switch it off -- here the
     # caller's next REGULAR pass does (a new session state is forced by a call that cannot be fused: a small one)
+    before = sess.pass_counts()["per_pair_passes"]
     assert np.max(np.abs(sess.from_primitives(a, b, d_shared, 10.0).cpu().numpy() - want_shared)) < TIGHT
+    assert sess.pass_counts()["per_pair_passes"] == before + 1  # (a list like the hinted one: one pass per pair -- whose scoreboard counts the repeats)
+    assert np.max(np.abs(sess.from_primitives(a, b, d_shared, 10.0).cpu().numpy() - want_shared)) < TIGHT
+    assert sess.pass_counts()["per_pair_passes"] == before + 1  # ... and the next pass is a regular one again
+    # a list with more pairs than side B has atoms repeats anchors by counting: never without de-duplication, whatever came before
+    assert np.array_equal(sess.from_primitives(a, b, d_once, 10.0).cpu().numpy(), first)       # (regular: the hint comes back)
+    assert np.array_equal(sess.from_primitives(a, b, d_once, 10.0).cpu().numpy(), first)       # (per pair again)
+    many = torch.from_numpy(np.concatenate([once, shared, once[::-1]])).cuda()                # 27 000 pairs over 9 000 atoms
+    n_pp = sess.pass_counts()["per_pair_passes"]
+    got_many = sess.from_primitives(a, b, many, 10.0).cpu().numpy()
+    assert sess.pass_counts()["per_pair_passes"] == n_pp
+    assert np.max(np.abs(got_many[:n] - want_once)) < TIGHT and np.max(np.abs(got_many[n:2 * n] - want_shared)) < TIGHT
     sess.close()
     fused, fc = _run(lh, monkeypatch, "1", build, xa, ca, ta, xb, cb, tb, once, 10.0, repeat=2)
     assert fc["fused_passes"] == 2
