@@ -381,8 +381,9 @@ extern "C" int lchd_ctx_create(int32_t device, lchd_ctx** out) {
     if ((e = hipHostMalloc(&c->h_status, sizeof(HostStatus))) != hipSuccess) return bail(e, "hipHostMalloc(status)");
     memset(c->h_status, 0, sizeof(HostStatus));
     if ((e = hipMalloc(&c->d_tabs, sizeof(double) * 2 * 65536)) != hipSuccess) return bail(e, "hipMalloc(tables)");
-    if ((e = hipMalloc(&c->d_done, sizeof(DoneState))) != hipSuccess) return bail(e, "hipMalloc(done)");
-    if ((e = hipMemset(c->d_done, 0, sizeof(DoneState))) != hipSuccess) return bail(e, "hipMemset(done)");
+    // (+ one cache line behind it: k_dense_fused's row counter, zero between launches -- k_dense_publish resets it)
+    if ((e = hipMalloc(&c->d_done, sizeof(DoneState) + 128)) != hipSuccess) return bail(e, "hipMalloc(done)");
+    if ((e = hipMemset(c->d_done, 0, sizeof(DoneState) + 128)) != hipSuccess) return bail(e, "hipMemset(done)");
     init_device_kernels();  // per device, not per process
     init_dense_fused_kernels();
     launch_fill_sqrt_tables(c->stream, c->d_tabs, c->d_tabs + 65536);
@@ -2276,8 +2277,14 @@ static int dense_pass(lchd_ctx* c, const lchd_cloud& a, const lchd_cloud& b, con
         dense_fused_applies(c->h_cfg.n_categories, cols_a, cols_b)) {
         double* w_ma2 = nullptr;
         double* w_mb2 = nullptr;
+        uint64_t* scr_key = nullptr;
+        uint8_t* scr_val = nullptr;
+        int32_t scr_grid = 0, scr_segs = 0;
+        const size_t scr_n = dense_fused_scratch(rows, cols_a, cols_b, &scr_grid, &scr_segs);
         for (int dry = 1; dry >= 0; --dry) {
             Arena ar(dry ? nullptr : c->ws, dry ? 0 : c->ws_cap, dry != 0);
+            scr_key = ar.take<uint64_t>(scr_n);  // the distance pass's (key, value) pairs, one region per workgroup
+            scr_val = ar.take<uint8_t>(scr_n);
             if (h_ma) {
                 w_ma2 = ar.take<double>((size_t)rows * cols_a);
                 w_mb2 = ar.take<double>((size_t)rows * cols_b);
@@ -2300,6 +2307,11 @@ static int dense_pass(lchd_ctx* c, const lchd_cloud& a, const lchd_cloud& b, con
         da.out = d_out;
         da.st = c->d_status;
         da.sqrt_tab = c->d_tabs;
+        da.scr_key = scr_key;
+        da.scr_val = scr_val;
+        da.scr_grid = scr_grid;
+        da.scr_segs = scr_segs;
+        da.ticket = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->d_done) + sizeof(DoneState));
         mark(c, 2);
         if (launch_dense_fused(c->stream, c->h_cfg.n_categories, da, c->h_status, c->seq)) {
             mark(c, 3);

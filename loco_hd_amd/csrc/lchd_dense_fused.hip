@@ -31,6 +31,8 @@
 // that holds more than a segment) are reported as ST_ROW_RETRY and the host repeats the call with the two-kernel path.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "lchd_kcommon.h"
 
 #define LCHD_AS4 __attribute__((address_space(4)))  // the constant address space: kernel arguments, the configuration blob
@@ -56,26 +58,35 @@ __device__ __forceinline__ const LCHD_AS4 T* df_const(const T* p) {  // memory t
 #define LCHD_DF_NT 512     // threads per workgroup (tuning builds: 1024 with LCHD_DF_CAP 14336 and LCHD_DF_BUCKETS 8192 = one workgroup per CU)
 #endif
 #ifndef LCHD_DF_CAP
-#define LCHD_DF_CAP 7168
+#define LCHD_DF_CAP 6144
 #endif
 #ifndef LCHD_DF_BUCKETS
-#define LCHD_DF_BUCKETS 4096
+#define LCHD_DF_BUCKETS 8192
 #endif
 constexpr int kNT = LCHD_DF_NT, kWaves = kNT / 64;
 constexpr int kCap = LCHD_DF_CAP;     // events of one distance segment (keys + values in LDS)
 constexpr int kEpt = kCap / kNT;      // 14 events per thread in the sort and in the sweep (<= 15: 4-bit chunk-local counters)
-constexpr int kCapTarget = kCap - 448;     // the planner aims at segments of at most this many events (slack: one coarse bin's worth)
+constexpr int kSample = 4;            // the coarse CDF of a row pair is estimated from every kSample-th point of either row
 constexpr int kCoarse = 512;          // uniform bins of the distance image; bin kCoarse holds +inf entries of a distance matrix
+#ifndef LCHD_DF_GRID
+#define LCHD_DF_GRID 512              // workgroups of a launch (two per CU): each owns one scratch region and takes rows blockIdx, + grid, ...
+#endif
+// events a segment may be PLANNED to hold: the plan sees a sample, the segment must hold the real thing (six standard deviations of the
+// count that a sample of one in kSample predicts, and a coarse bin's worth)
+__host__ __device__ inline int df_seg_margin(int est) { return 6 * (int)sqrtf((float)(est * kSample)) + 70; }
 constexpr int kBuckets = LCHD_DF_BUCKETS;  // buckets of a segment's sort, two 16-bit counters per LDS word
 constexpr int kBucketLimit = 64;      // a fuller bucket sends the call to the two-kernel path
 constexpr int kPart = 1024;           // sqrt(k) for k < kPart from LDS, larger counts are computed
 constexpr int kMaxSeg = 16;
 constexpr double kExactBelow = 1e-6;  // as lchd_team_tile.h (kExactH2Below): below this H^2 the literal difference-of-roots form
 static_assert(kEpt <= 15 && kCap % kNT == 0, "chunk-local counters are 4-bit fields");
-static_assert(kBuckets / 2 == 4 * kNT, "the bucket scan gives every thread four histogram words");
+static_assert((kBuckets / 2) % (4 * kNT) == 0 && kBuckets <= 8192, "the bucket scan gives every thread whole 16-byte groups of histogram words; 13-bit bucket ids");
 static_assert(kBuckets * 2 >= kPart * 8, "histogram and sqrt table share their bytes");
 
-constexpr size_t kDynLds = (size_t)kCap * 9 + (size_t)kBuckets * 2 + 16;  // (+ the histogram's end word)
+constexpr int kKeyPad = 4;           // sentinel keys behind a segment's last event (the ranking reads four members from a bucket's start)
+constexpr size_t kValOff = (size_t)(kCap + kKeyPad) * 8, kHistOff = kValOff + (size_t)kCap;
+static_assert(kHistOff % 16 == 0, "the bucket scan reads 16-byte groups");
+constexpr size_t kDynLds = kHistOff + (size_t)kBuckets * 2 + 16;  // (+ the histogram's end word)
 
 __device__ __forceinline__ uint64_t df_spread4(uint64_t x) {  // four 4-bit fields -> four 16-bit fields
     const uint32_t v = (uint32_t)x;
@@ -168,7 +179,8 @@ __device__ __forceinline__ double df_cdf(const DfWf& w, double x, const double* 
 // workgroup sees them (barrier waits included), read back with lchd_debug_dense_stamps().
 #ifdef LCHD_DF_STAMPS
 __device__ unsigned long long g_df_stamps[16];
-#define DSTAMP(i) do { if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_df_stamps[i], t_ - dstamp_last); dstamp_last = t_; } } while (0)
+// (accumulated in LDS and flushed once per workgroup: global atomics per phase sit in front of every wait for the phase's own loads)
+#define DSTAMP(i) do { if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); dstamp_acc[i] += t_ - dstamp_last; dstamp_last = t_; } } while (0)
 #else
 #define DSTAMP(i) do { } while (0)
 #endif
@@ -179,14 +191,16 @@ __global__ __launch_bounds__(kNT, 4) void k_dense_fused(DenseArgs a) {
     constexpr int NW = CMAX / 4;  // u64 words of four 16-bit count fields per side
     static_assert(CMAX % 4 == 0 && CMAX <= 16, "one u64 of 4-bit chunk counters per side");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t* skey = reinterpret_cast<uint64_t*>(smem);                  // [kCap] key bits of the current segment
-    uint8_t* sval = smem + (size_t)kCap * 8;                             // [kCap] side << 7 | category
-    uint32_t* hist = reinterpret_cast<uint32_t*>(smem + (size_t)kCap * 9);  // [kBuckets / 2] (sort)
-    double* t_part = reinterpret_cast<double*>(smem + (size_t)kCap * 9);    // [kPart] sqrt(k) (sweep): the same bytes
-    __shared__ uint32_t coarse[kCoarse + 1], cum[kCoarse + 2];
+    uint64_t* skey = reinterpret_cast<uint64_t*>(smem);                  // [kCap + kKeyPad] key bits of the current segment
+    uint8_t* sval = smem + kValOff;                                      // [kCap] side << 7 | category
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem + kHistOff);       // [kBuckets / 2 + 1] (sort)
+    double* t_part = reinterpret_cast<double*>(smem + kHistOff);         // [kPart] sqrt(k) (sweep): the same bytes
+    __shared__ uint32_t coarse[kCoarse + 1], cum[kCoarse + 2];  // the SAMPLE's counts per coarse bin / below a bin
     __shared__ int bnd[kMaxSeg + 1];
+    __shared__ uint8_t segtab[kCoarse + 1];                      // coarse bin -> distance segment
+    __shared__ unsigned long long fillw[kMaxSeg / 4];            // events of the segments, four 16-bit fields per word
     __shared__ int n_seg_s;
-    __shared__ uint32_t fill_s, rowflags_s, wsum[kWaves], wtot_a[kWaves], seg_a_s;
+    __shared__ uint32_t rowflags_s, wsum[kWaves], wtot_a[kWaves], seg_a_s;
     __shared__ uint64_t wtot[kWaves][2 * NW], base_cnt[2 * NW];
     __shared__ double st_f[kWaves], st_h[kWaves], carry_f[2], carry_h[2], red_s[kWaves], red_max[kWaves], exp_tab[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -204,9 +218,16 @@ __global__ __launch_bounds__(kNT, 4) void k_dense_fused(DenseArgs a) {
 
     if (tid < 64) exp_tab[tid] = kExp2Tab[tid];  // (made visible by the row loop's first barrier)
 #ifdef LCHD_DF_STAMPS
+    __shared__ unsigned long long dstamp_acc[16];
+    if (tid < 16) dstamp_acc[tid] = 0ull;
+    __syncthreads();
     unsigned long long dstamp_last = __builtin_amdgcn_s_memtime();
 #endif
-    for (int64_t r = blockIdx.x; r < a.n_rows; r += gridDim.x) {
+    // rows: blockIdx first, then whatever row the ticket counter hands out next (the launch has a fixed number of workgroups, one per
+    // scratch region; k_dense_publish zeroes the counter again)
+    __shared__ long long next_row_s[2];  // (two slots: a thread may still have to read row i's successor when thread 0 fetches row i + 1's)
+    int it = 0;
+    for (int64_t r = blockIdx.x; r < a.n_rows; r = next_row_s[it & 1], ++it) {
         int nA, nB, wfi;
         {
             const LCHD_AS4 DenseArgs* kp = df_opaque(ka);
@@ -276,25 +297,20 @@ __global__ __launch_bounds__(kNT, 4) void k_dense_fused(DenseArgs a) {
             const int b = min((int)((float)key * inv_wf), kCoarse - 1);
             return key <= dmax ? b : kCoarse;
         };
-        // ---- 1. empirical CDF of the row pair on the coarse bins ---------------------------------------------------------
+        // ---- 1. the row pair's CDF on the coarse bins, estimated from every kSample-th point -----------------------------
+        uint32_t m_tot = 0;  // points of the sample
         for (int side = 0; side < 2; ++side) {
             const SideIn si = side_in(side);
-            const int n_cat = kc->n_categories;
-            bool zero = false, badc = false;
-            for (int i = tid; i < si.n; i += kNT) {
-                const double k = key_of(si, i);
-                zero |= (k == 0.0);
-                badc |= (int)si.cat[i] >= n_cat;  // pmf.rs:38-42: every point of a row enters a PMF
-                atomicAdd(&coarse[bin_of(k)], 1u);
-            }
-            if (zero) myflags |= side ? RF_ZERO_B : RF_ZERO_A;
-            if (badc) myflags |= RF_BAD_CAT;
+            const int off = (int)((r + side) & (kSample - 1));
+            m_tot += (uint32_t)((si.n - off + kSample - 1) / kSample);
+            for (int i = kSample * tid + off; i < si.n; i += kSample * kNT) atomicAdd(&coarse[bin_of(key_of(si, i))], 1u);
         }
-        for (int k = 32; k > 0; k >>= 1) myflags |= (uint32_t)__shfl_xor((int)myflags, k);
-        if (lane == 0 && myflags) atomicOr(&rowflags_s, myflags);
+        if (tid < kMaxSeg / 4) fillw[tid] = 0ull;
         __syncthreads();
         DSTAMP(0);
-        if (wave == 0) {  // cum[b] = events below bin b; then the segment plan
+        // (the next row's ticket is fetched by a wavefront that would otherwise wait for the plan)
+        if (tid == kNT - 1) next_row_s[it & 1] = (long long)gridDim.x + (long long)atomicAdd(df_opaque(ka)->ticket, 1ull);
+        if (wave == 0) {  // cum[b] = sampled points below bin b; then the segment plan
             uint32_t carry = 0;
             for (int base = 0; base <= kCoarse; base += 64) {
                 const uint32_t v = base + lane <= kCoarse ? coarse[base + lane] : 0u;
@@ -304,14 +320,16 @@ __global__ __launch_bounds__(kNT, 4) void k_dense_fused(DenseArgs a) {
             }
             if (lane == 0) cum[kCoarse + 1] = carry;
             wave_sync_lds();
-            // S segments at bin boundaries, every one of at most kCap events: boundary s = the first bin at which the CDF
-            // reaches s / S of the events (lane s searches it)
-            int S = max(1, (total + kCapTarget - 1) / kCapTarget);
+            // S segments at bin boundaries: boundary s = the first bin at which the sample's CDF reaches s / S; a segment is accepted
+            // when the events the sample predicts for it, plus the margin, fit the LDS arrays (one segment: whatever fits fits)
+            const float per = (float)total / (float)max(m_tot, 1u);  // events per sampled point
+            const int s_max = min(df_opaque(ka)->scr_segs, kMaxSeg);
+            int S = max(1, (total + kCap - 1) / kCap);
             for (;; ++S) {
-                if (S > kMaxSeg) { S = 0; break; }
+                if (S > s_max) { S = 0; break; }
                 int b = lane >= S ? kCoarse + 1 : 0;
                 if (lane >= 1 && lane < S) {
-                    const uint32_t tgt = (uint32_t)(((uint64_t)lane * (uint64_t)total) / (uint64_t)S);
+                    const uint32_t tgt = (uint32_t)(((uint64_t)lane * (uint64_t)m_tot) / (uint64_t)S);
                     int lo = 0, hi = kCoarse + 1;
                     while (lo < hi) {
                         const int mid = (lo + hi) >> 1;
@@ -320,8 +338,9 @@ __global__ __launch_bounds__(kNT, 4) void k_dense_fused(DenseArgs a) {
                     b = lo;
                 }
                 const int bn = __shfl_down(b, 1);
-                const uint32_t sz = lane < S ? cum[bn] - cum[b] : 0u;
-                if (__ballot(sz > (uint32_t)kCap) == 0ull) {
+                const int est = lane < S ? (int)((float)(cum[bn] - cum[b]) * per) + 1 : 0;
+                const bool fits = S == 1 ? total <= kCap : est + df_seg_margin(est) <= kCap;
+                if (__ballot(lane < S && !fits) == 0ull) {
                     if (lane <= S) bnd[lane] = b;
                     break;
                 }
@@ -329,10 +348,82 @@ __global__ __launch_bounds__(kNT, 4) void k_dense_fused(DenseArgs a) {
             if (lane == 0) n_seg_s = S;
         }
         __syncthreads();
-        DSTAMP(1);
         const int S = n_seg_s;
+        for (int b = tid; b <= kCoarse; b += kNT) {
+            int sg = 0;
+            for (int k = 1; k < S; ++k) sg += b >= bnd[k] ? 1 : 0;
+            segtab[b] = (uint8_t)sg;
+        }
+        __syncthreads();
+        DSTAMP(1);
+        // ---- 2. ONE pass over the distances: every point goes to its segment's scratch array ---------------------------------
+        // (position = the segment's fill count so far + the number of earlier lanes with a point for the same segment: a wave scan of
+        //  four 16-bit one-hot fields per word, one LDS atomic per wavefront, word and step)
+        if (S > 0) {
+            const int nsw = (S + 3) >> 2;
+            const size_t my_scr = (size_t)blockIdx.x * (size_t)df_opaque(ka)->scr_segs * (size_t)kCap;
+            uint64_t* const gkey = df_opaque(ka)->scr_key + my_scr;
+            uint8_t* const gval = df_opaque(ka)->scr_val + my_scr;
+            const int n_cat = kc->n_categories;
+            for (int side = 0; side < 2; ++side) {
+                const SideIn si = side_in(side);
+                const int ns = si.n;
+                bool zero = false, badc = false;
+                for (int i0 = 0; i0 < ns; i0 += 4 * kNT) {
+                    double k[4];
+                    uint32_t sg[4];
+                    uint8_t v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = i0 + u * kNT + tid;
+                        const int ii = i < ns ? i : 0;
+                        k[u] = key_of(si, ii);
+                        const uint32_t c = si.cat[ii];
+                        zero |= (k[u] == 0.0);
+                        badc |= (int)c >= n_cat;  // pmf.rs:38-42: every point of a row enters a PMF
+                        sg[u] = i < ns ? (uint32_t)segtab[bin_of(k[u])] : 0xFFu;
+                        v[u] = (uint8_t)((c & 15u) | (uint32_t)(side << 7));
+                    }
+                    for (int w = 0; w < nsw; ++w) {  // (wave-uniform)
+                        uint64_t oh = 0ull;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) oh += (sg[u] >> 2) == (uint32_t)w ? 1ull << ((sg[u] & 3u) * 16u) : 0ull;
+                        const uint64_t incl = wave_incl_scan_fields(oh);
+                        const uint64_t wave_tot = readlane_u64(incl, 63);
+                        unsigned long long base = 0ull;
+                        if (lane == 0 && wave_tot) base = atomicAdd(&fillw[w], (unsigned long long)wave_tot);
+                        uint64_t mine = readlane_u64((uint64_t)base, 0) + (incl - oh);  // my first position in each of the word's four segments
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if ((sg[u] >> 2) == (uint32_t)w) {
+                                const uint32_t f = (sg[u] & 3u) * 16u;
+                                const uint32_t pos = (uint32_t)(mine >> f) & 0xFFFFu;
+                                mine += 1ull << f;
+                                if (pos < (uint32_t)kCap) {
+                                    if (sg[u] == 0u) {  // the first segment is sorted first: it waits in the LDS arrays themselves
+                                        skey[pos] = d2u(k[u]);
+                                        sval[pos] = v[u];
+                                    } else {
+                                        const size_t at = (size_t)sg[u] * (size_t)kCap + pos;
+                                        gkey[at] = d2u(k[u]);
+                                        gval[at] = v[u];
+                                    }
+                                }
+                            }
+                    }
+                }
+                if (zero) myflags |= side ? RF_ZERO_B : RF_ZERO_A;
+                if (badc) myflags |= RF_BAD_CAT;
+            }
+        }
+        for (int k = 32; k > 0; k >>= 1) myflags |= (uint32_t)__shfl_xor((int)myflags, k);
+        if (lane == 0 && myflags) atomicOr(&rowflags_s, myflags);
+        __syncthreads();  // (orders the scratch writes before the segment loop's reads: one workgroup, one CU)
+        DSTAMP(2);
         uint32_t rf = rowflags_s;
         if (S == 0) rf |= RF_RETRY;
+        for (int sg = 0; sg < S; ++sg)
+            if (((uint32_t)(fillw[sg >> 2] >> ((sg & 3) * 16)) & 0xFFFFu) > (uint32_t)kCap) rf |= RF_RETRY;  // the sample under-estimated a segment
         if (!(rf & RF_ZERO_A) || !(rf & RF_ZERO_B) || (rf & (RF_BAD_DIST | RF_BAD_CAT | RF_RETRY)) || bad_wf) {
             // src/locohd.rs:74-77 (the sorted rows must start with a distance of 0), pmf.rs:38-42, a NaN / negative entry,
             // a row pair this kernel cannot segment: reported, the host turns the flags into the reference's errors
@@ -354,67 +445,54 @@ __global__ __launch_bounds__(kNT, 4) void k_dense_fused(DenseArgs a) {
         int base_na = 0, base_nb = 0;  // points of A / B in the segments already swept
         bool give_up = false;
         int swept = 0;  // non-empty segments swept so far (parity of the carry slot)
+        // a segment's (key, value) pairs come back from the scratch arrays into the sort's registers (issuing the loads a phase or a
+        // segment ahead was measured: the sort's 32 registers then live through the sweep, the allocator spills them, and a spill waits
+        // for its load -- 3.08 -> 3.17 / 3.61 ms)
+        double m[kEpt];
+        uint32_t vv[(kEpt + 3) / 4];
+        auto fill_of = [&](int sgi) -> int { return (int)((uint32_t)(fillw[sgi >> 2] >> ((sgi & 3) * 16)) & 0xFFFFu); };
+        auto load_segment = [&](int sgi) {
+            int tl = tid;
+            asm volatile("" : "+v"(tl));
+            const int nn = fill_of(sgi);
+            const size_t seg_scr = ((size_t)blockIdx.x * (size_t)df_opaque(ka)->scr_segs + (size_t)sgi) * (size_t)kCap;
+            const uint64_t* const gkey = df_opaque(ka)->scr_key + seg_scr;
+            const uint8_t* const gval = df_opaque(ka)->scr_val + seg_scr;
+#pragma unroll
+            for (int q = 0; q < (kEpt + 3) / 4; ++q) vv[q] = 0u;
+            if (sgi == 0) {  // (workgroup-uniform)
+#pragma unroll
+                for (int q = 0; q < kEpt; ++q) {
+                    const int e = tl + q * kNT, ee = e < nn ? e : 0;
+                    m[q] = u2d(skey[ee]);
+                    vv[q >> 2] |= (uint32_t)sval[ee] << ((q & 3) * 8);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < kEpt; ++q) {
+                    const int e = tl + q * kNT, ee = e < nn ? e : 0;
+                    m[q] = u2d(gkey[ee]);
+                    vv[q >> 2] |= (uint32_t)gval[ee] << ((q & 3) * 8);
+                }
+            }
+        };
 #pragma unroll 1
         for (int sg = 0; sg < S; ++sg) {
             const int lo_bin = bnd[sg], hi_bin = bnd[sg + 1];
             const uint32_t cum_lo = cum[lo_bin];
-            const int n = (int)(cum[hi_bin] - cum_lo);  // events of this segment
-            if (n == 0) continue;                        // (workgroup-uniform)
-            // ---- 2. keep the segment's points: ballot compaction into the key / value arrays --------------------------
-            if (tid == 0) fill_s = 0u;
-            __syncthreads();
-            for (int side = 0; side < 2; ++side) {
-                const SideIn si = side_in(side);
-                const int ns = si.n;
-                for (int i0 = 0; i0 < ns; i0 += 4 * kNT) {
-                    double k[4];
-                    bool in[4];
-                    uint8_t v[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int i = i0 + u * kNT + tid;
-                        const int ii = i < ns ? i : 0;
-                        k[u] = key_of(si, ii);
-                        const int b = bin_of(k[u]);
-                        in[u] = i < ns && b >= lo_bin && b < hi_bin;
-                        v[u] = (uint8_t)((si.cat[ii] & 15) | (side << 7));
-                    }
-                    unsigned long long m[4];
-                    uint32_t cnt = 0;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { m[u] = __ballot(in[u]); cnt += (uint32_t)__popcll(m[u]); }
-                    uint32_t at = 0;
-                    if (lane == 0 && cnt) at = atomicAdd(&fill_s, cnt);
-                    at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if (in[u]) {
-                            const uint32_t pos = at + __builtin_amdgcn_mbcnt_hi((uint32_t)(m[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[u], 0u));
-                            if (pos < (uint32_t)kCap) { skey[pos] = d2u(k[u]); sval[pos] = v[u]; }
-                        }
-                        at += (uint32_t)__popcll(m[u]);
-                    }
-                }
-            }
+            const int n = fill_of(sg);  // events of this segment
+            if (n == 0) continue;       // (workgroup-uniform)
+            load_segment(sg);
             for (int w = tid; w < kBuckets / 2; w += kNT) hist[w] = 0u;
-            __syncthreads();
-            DSTAMP(2);
             // ---- 3. bucket sort ------------------------------------------------------------------------------------------
             // (an opaque copy of the thread index per phase: the slot indices tid + q * 512 are otherwise computed once at the
             //  kernel's entry, for every unrolled loop below, and spilled)
             int ts = tid;
             asm volatile("" : "+v"(ts));
-            double m[kEpt];
-            uint32_t bs[kEpt], vv[(kEpt + 3) / 4];
-#pragma unroll
-            for (int q = 0; q < (kEpt + 3) / 4; ++q) vv[q] = 0u;
-#pragma unroll
-            for (int q = 0; q < kEpt; ++q) {
-                const int e = ts + q * kNT, ee = e < n ? e : 0;
-                m[q] = u2d(skey[ee]);
-                vv[q >> 2] |= (uint32_t)sval[ee] << ((q & 3) * 8);
-            }
-            const float scale = (float)kBuckets / (float)n;
+            uint32_t bs[kEpt];
+            __syncthreads();
+            DSTAMP(3);
+            const float scale = (float)kBuckets / (float)max(cum[hi_bin] - cum_lo, 1u);  // (sample counts: buckets per sampled point)
             uint32_t biggest = 0;
 #pragma unroll
             for (int q = 0; q < kEpt; ++q) {
@@ -440,18 +518,36 @@ __global__ __launch_bounds__(kNT, 4) void k_dense_fused(DenseArgs a) {
             if (biggest > (uint32_t)kBucketLimit) { give_up = true; break; }  // (workgroup-uniform)
             __syncthreads();
             DSTAMP(3);
-            {   // exclusive scan of the 4096 counters: four words (eight buckets) per thread
-                const uint4 w4 = *reinterpret_cast<const uint4*>(&hist[4 * tid]);
-                const uint32_t c0 = w4.x & 0xFFFFu, c1 = w4.x >> 16, c2 = w4.y & 0xFFFFu, c3 = w4.y >> 16, c4 = w4.z & 0xFFFFu, c5 = w4.z >> 16,
-                               c6 = w4.w & 0xFFFFu, c7 = w4.w >> 16;
-                const uint32_t T = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
+            {   // exclusive scan of the bucket counters: kScanW words (2 kScanW buckets) per thread
+                constexpr int kScanW = kBuckets / 2 / kNT;
+                uint32_t c[2 * kScanW];
+#pragma unroll
+                for (int g = 0; g < kScanW / 4; ++g) {
+                    const uint4 w4 = *reinterpret_cast<const uint4*>(&hist[kScanW * tid + 4 * g]);
+                    const uint32_t ww[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { c[8 * g + 2 * k] = ww[k] & 0xFFFFu; c[8 * g + 2 * k + 1] = ww[k] >> 16; }
+                }
+                uint32_t T = 0;
+#pragma unroll
+                for (int k = 0; k < 2 * kScanW; ++k) T += c[k];
                 const uint32_t incl = wave_incl_scan_u32(T);
                 if (lane == 63) wsum[wave] = incl;
                 __syncthreads();
-                uint32_t s0 = incl - T;
-                for (int w = 0; w < kWaves; ++w) s0 += w < wave ? wsum[w] : 0u;
-                const uint32_t s1 = s0 + c0, s2 = s1 + c1, s3 = s2 + c2, s4 = s3 + c3, s5 = s4 + c4, s6 = s5 + c5, s7 = s6 + c6;
-                *reinterpret_cast<uint4*>(&hist[4 * tid]) = make_uint4(s0 | (s1 << 16), s2 | (s3 << 16), s4 | (s5 << 16), s6 | (s7 << 16));
+                uint32_t run = incl - T;
+                for (int w = 0; w < kWaves; ++w) run += w < wave ? wsum[w] : 0u;
+#pragma unroll
+                for (int g = 0; g < kScanW / 4; ++g) {
+                    uint32_t o[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t lo_ = run;
+                        run += c[8 * g + 2 * k];
+                        o[k] = lo_ | (run << 16);
+                        run += c[8 * g + 2 * k + 1];
+                    }
+                    *reinterpret_cast<uint4*>(&hist[kScanW * tid + 4 * g]) = make_uint4(o[0], o[1], o[2], o[3]);
+                }
                 if (tid == 0) hist[kBuckets / 2] = (uint32_t)n;
             }
             __syncthreads();
@@ -468,34 +564,42 @@ __global__ __launch_bounds__(kNT, 4) void k_dense_fused(DenseArgs a) {
                     sval[pos] = (uint8_t)(vv[q >> 2] >> ((q & 3) * 8));
                     bs[q] = b | (pos << 13);
                 }
+            if (tid < kKeyPad) skey[n + tid] = ~0ull;  // (n <= kCap; larger than every key)
             __syncthreads();
             DSTAMP(5);
             // every event ranks itself among the members of its bucket on (key, value, position): the sequence of (key, value)
-            // pairs that results does not depend on the order in which the compaction happened to place the points.  One member
-            // per step and two comparisons on the key (the loop runs, in every wavefront, for the fullest bucket any of its 64 lanes
-            // has met, so the step is what counts); equal keys (rare: lattices, +inf entries) are recounted with the full order.
+            // pairs that results does not depend on the order in which the distance pass happened to place the points.  The
+            // first four members are read without a look at the bucket's end: what lies behind it belongs to later buckets (larger
+            // keys: a bucket is a non-decreasing function of the key) or is a sentinel, and counts neither as smaller nor as equal.
+            // Fuller buckets (one event in three hundred at 0.6 events per bucket) and equal keys (lattices, +inf entries) take the loops.
 #pragma unroll
             for (int q = 0; q < kEpt; ++q)
                 if (bs[q] != ~0u) {
                     const uint32_t b = bs[q] & 8191u, pos = bs[q] >> 13;
-                    const uint32_t lo = start_of(b), hi = start_of(b + 1u);
+                    const uint32_t w0 = hist[b >> 1], w1 = hist[(b >> 1) + 1u];
+                    const uint32_t lo = (b & 1u) ? w0 >> 16 : w0 & 0xFFFFu, hi = (b & 1u) ? w1 & 0xFFFFu : w0 >> 16;
                     const uint64_t mine = d2u(m[q]);
+                    uint64_t kj[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) kj[u] = skey[lo + u];
                     uint32_t less = 0, same = 0;
-                    for (uint32_t j = lo; j < hi; j += 4) {  // (four members per step: their LDS reads in flight together)
-                        uint64_t kj[4];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) kj[u] = skey[min(j + u, hi - 1u)];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            less += ((j + u < hi) & (kj[u] < mine)) ? 1u : 0u;
-                            same += ((j + u < hi) & (kj[u] == mine)) ? 1u : 0u;
-                        }
+                    for (int u = 0; u < 4; ++u) {
+                        less += kj[u] < mine ? 1u : 0u;
+                        same += kj[u] == mine ? 1u : 0u;
                     }
-                    if (same > 1u) {  // (itself and at least one other member)
+                    for (uint32_t j = lo + 4u; j < hi; ++j) {
+                        const uint64_t kk = skey[j];
+                        less += kk < mine ? 1u : 0u;
+                        same += kk == mine ? 1u : 0u;
+                    }
+                    if (same > 1u) {  // (itself and at least one other member): recount with the full order
                         const uint32_t myv = (vv[q >> 2] >> ((q & 3) * 8)) & 0xFFu;
+                        less = 0;
                         for (uint32_t j = lo; j < hi; ++j) {
                             const uint32_t vj = sval[j];
-                            less += (skey[j] == mine) & ((vj < myv) | ((vj == myv) & (j < pos))) ? 1u : 0u;
+                            const uint64_t kk = skey[j];
+                            less += (kk < mine) | ((kk == mine) & ((vj < myv) | ((vj == myv) & (j < pos)))) ? 1u : 0u;
                         }
                     }
                     bs[q] = lo + less;
@@ -678,11 +782,16 @@ __global__ __launch_bounds__(kNT, 4) void k_dense_fused(DenseArgs a) {
         __syncthreads();
         DSTAMP(11);
     }
+#ifdef LCHD_DF_STAMPS
+    __syncthreads();
+    if (tid < 16) atomicAdd(&g_df_stamps[tid], dstamp_acc[tid]);
+#endif
 }
 
 // The end of a dense pass that did not run k_pair_meta: what the kernels reported goes into the host-mapped mirror, the
 // device status is reset for the next pass (one thread; ordered behind the fused kernel by the stream).
-__global__ void k_dense_publish(DeviceStatus* st, HostStatus* h, uint32_t seq) {
+__global__ void k_dense_publish(DeviceStatus* st, HostStatus* h, uint32_t seq, unsigned long long* ticket) {
+    *ticket = 0ull;
     h->flags = st->flags;
     h->max_env = 0u;
     h->n_unique[0] = h->n_unique[1] = 0u;
@@ -709,6 +818,19 @@ bool dense_fused_applies(int n_categories, int64_t len_a, int64_t len_b) {
     return n_categories <= 16 && longest > kDenseFusedMinRow && longest <= kDenseFusedMaxRow && len_a >= 1 && len_b >= 1;
 }
 
+size_t dense_fused_scratch(int64_t n_rows, int64_t len_a, int64_t len_b, int32_t* grid_out, int32_t* segs_out) {
+    const int64_t total = len_a + len_b;
+    // the plan starts at ceil(total / kCap) segments and adds some until the sample's estimates fit with their margin: two more
+    // than the balanced plan needs cover every row pair whose sample is not grossly off (otherwise: ST_ROW_RETRY)
+    int S = (int)std::max<int64_t>(1, (total + kCap - 1) / kCap);
+    while (S < kMaxSeg && (int)(total / S) + df_seg_margin((int)(total / S)) > kCap) ++S;
+    const int segs = std::min(kMaxSeg, S + 2);
+    const int grid = (int)std::min<int64_t>(n_rows, LCHD_DF_GRID);
+    if (grid_out) *grid_out = grid;
+    if (segs_out) *segs_out = segs;
+    return (size_t)std::max(grid, 1) * (size_t)segs * (size_t)kCap;
+}
+
 void init_dense_fused_kernels() {
     auto raise = [](const void* fn) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDynLds); };
     raise(reinterpret_cast<const void*>(&k_dense_fused<8, false>));
@@ -725,7 +847,8 @@ bool launch_dense_fused(hipStream_t s, int n_categories, const DenseArgs& a, Hos
     const bool dmx = a.s[0].dmx != nullptr;
     if (dmx != (a.s[1].dmx != nullptr)) return false;
     if (!dense_fused_applies(n_categories, a.s[0].row_len, a.s[1].row_len)) return false;
-    const unsigned grid = (unsigned)(a.n_rows < (1 << 20) ? a.n_rows : (1 << 20));
+    if (!a.scr_key || !a.scr_val || !a.ticket || a.scr_segs < 1 || a.scr_grid < 1) return false;
+    const unsigned grid = (unsigned)std::min<int64_t>(a.n_rows, a.scr_grid);  // (a workgroup per scratch region; rows blockIdx, + grid, ...)
     if (n_categories <= 8) {
         if (dmx) k_dense_fused<8, true><<<grid, kNT, kDynLds, s>>>(a); else k_dense_fused<8, false><<<grid, kNT, kDynLds, s>>>(a);
     } else if (n_categories <= 12) {
@@ -733,7 +856,7 @@ bool launch_dense_fused(hipStream_t s, int n_categories, const DenseArgs& a, Hos
     } else {
         if (dmx) k_dense_fused<16, true><<<grid, kNT, kDynLds, s>>>(a); else k_dense_fused<16, false><<<grid, kNT, kDynLds, s>>>(a);
     }
-    k_dense_publish<<<1, 1, 0, s>>>(a.st, hst, seq);
+    k_dense_publish<<<1, 1, 0, s>>>(a.st, hst, seq, a.ticket);
     return true;
 }
 

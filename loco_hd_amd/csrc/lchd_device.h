@@ -293,7 +293,15 @@ struct DenseArgs {
     double* out;
     DeviceStatus* st;
     const double* sqrt_tab;   // [65536] sqrt(k), context-owned
+    // scratch of the distance pass: workgroup w keeps the (key, value) pairs of distance segment s of its CURRENT row pair at
+    // [(w * scr_segs + s) * dense_fused_seg_cap() ...); dense_fused_scratch() sizes both arrays and sets scr_segs / scr_grid
+    uint64_t* scr_key;
+    uint8_t* scr_val;
+    int32_t scr_segs, scr_grid;
+    unsigned long long* ticket;  // context-owned: rows handed out beyond the first one of every workgroup (zero between launches)
 };
+// workgroups of a launch and segments per workgroup for rows of up to (len_a, len_b) points; returns the ENTRIES of either scratch array
+size_t dense_fused_scratch(int64_t n_rows, int64_t len_a, int64_t len_b, int32_t* grid_out, int32_t* segs_out);
 bool dense_fused_applies(int n_categories, int64_t len_a, int64_t len_b);
 // returns false (nothing launched) when the kernel does not apply; otherwise the kernel and the status hand-over are enqueued
 bool launch_dense_fused(hipStream_t s, int n_categories, const DenseArgs& a, HostStatus* hst, uint32_t seq);
