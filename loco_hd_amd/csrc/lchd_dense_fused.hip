@@ -66,7 +66,10 @@ __device__ __forceinline__ const LCHD_AS4 T* df_const(const T* p) {  // memory t
 constexpr int kNT = LCHD_DF_NT, kWaves = kNT / 64;
 constexpr int kCap = LCHD_DF_CAP;     // events of one distance segment (keys + values in LDS)
 constexpr int kEpt = kCap / kNT;      // 14 events per thread in the sort and in the sweep (<= 15: 4-bit chunk-local counters)
-constexpr int kSample = 4;            // the coarse CDF of a row pair is estimated from every kSample-th point of either row
+#ifndef LCHD_DF_SAMPLE
+#define LCHD_DF_SAMPLE 4
+#endif
+constexpr int kSample = LCHD_DF_SAMPLE;  // the coarse CDF of a row pair is estimated from every kSample-th point of either row
 constexpr int kCoarse = 512;          // uniform bins of the distance image; bin kCoarse holds +inf entries of a distance matrix
 #ifndef LCHD_DF_GRID
 #define LCHD_DF_GRID 512              // workgroups of a launch (two per CU): each owns one scratch region and takes rows blockIdx, + grid, ...
@@ -76,7 +79,7 @@ constexpr int kCoarse = 512;          // uniform bins of the distance image; bin
 __host__ __device__ inline int df_seg_margin(int est) { return 6 * (int)sqrtf((float)(est * kSample)) + 70; }
 constexpr int kBuckets = LCHD_DF_BUCKETS;  // buckets of a segment's sort, two 16-bit counters per LDS word
 constexpr int kBucketLimit = 64;      // a fuller bucket sends the call to the two-kernel path
-constexpr int kPart = 1024;           // sqrt(k) for k < kPart from LDS, larger counts are computed
+constexpr int kPart = kBuckets / 4;   // sqrt(k) for k < kPart from LDS (the histogram's bytes), larger counts are computed
 constexpr int kMaxSeg = 16;
 constexpr double kExactBelow = 1e-6;  // as lchd_team_tile.h (kExactH2Below): below this H^2 the literal difference-of-roots form
 static_assert(kEpt <= 15 && kCap % kNT == 0, "chunk-local counters are 4-bit fields");
@@ -198,10 +201,10 @@ __global__ __launch_bounds__(kNT, 4) void k_dense_fused(DenseArgs a) {
     __shared__ uint32_t coarse[kCoarse + 1], cum[kCoarse + 2];  // the SAMPLE's counts per coarse bin / below a bin
     __shared__ int bnd[kMaxSeg + 1];
     __shared__ uint8_t segtab[kCoarse + 1];                      // coarse bin -> distance segment
-    __shared__ unsigned long long fillw[kMaxSeg / 4];            // events of the segments, four 16-bit fields per word
+    __shared__ uint32_t fill32[kMaxSeg];                         // events of the segments
     __shared__ int n_seg_s;
-    __shared__ uint32_t rowflags_s, wsum[kWaves], wtot_a[kWaves], seg_a_s;
-    __shared__ uint64_t wtot[kWaves][2 * NW], base_cnt[2 * NW];
+    __shared__ uint32_t rowflags_s, wsum[kWaves], wbig[kWaves], wtot_a[kWaves];
+    __shared__ uint64_t wtot[kWaves][2 * NW], base_cnt[2][2 * NW];
     __shared__ double st_f[kWaves], st_h[kWaves], carry_f[2], carry_h[2], red_s[kWaves], red_max[kWaves], exp_tab[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // kernel arguments and configuration in the constant address space (scalar loads, re-issued per phase: df_opaque)
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(kNT, 4) void k_dense_fused(DenseArgs a) {
             if (lane == 0) red_max[wave] = dmax;
         }
         for (int b = tid; b <= kCoarse; b += kNT) coarse[b] = 0u;
-        if (tid < 2 * NW) base_cnt[tid] = 0ull;
+        if (tid < 2 * NW) base_cnt[0][tid] = 0ull;
         if (tid == 0) { rowflags_s = 0u; carry_f[0] = carry_f[1] = 0.0; carry_h[0] = carry_h[1] = 0.0; }
         __syncthreads();
         if constexpr (DMX)
@@ -297,15 +300,17 @@ __global__ __launch_bounds__(kNT, 4) void k_dense_fused(DenseArgs a) {
             const int b = min((int)((float)key * inv_wf), kCoarse - 1);
             return key <= dmax ? b : kCoarse;
         };
-        // ---- 1. the row pair's CDF on the coarse bins, estimated from every kSample-th point -----------------------------
+        // ---- 1. the row pair's CDF on the coarse bins, estimated from every kSample-th point -------------------------------
+        // (a row pair that fits one segment needs no plan, only balanced buckets: every 2nd point then -- 0.319 -> 0.299 ms at 3000 atoms)
+        const int smp = total <= kCap ? 2 : kSample;
         uint32_t m_tot = 0;  // points of the sample
         for (int side = 0; side < 2; ++side) {
             const SideIn si = side_in(side);
-            const int off = (int)((r + side) & (kSample - 1));
-            m_tot += (uint32_t)((si.n - off + kSample - 1) / kSample);
-            for (int i = kSample * tid + off; i < si.n; i += kSample * kNT) atomicAdd(&coarse[bin_of(key_of(si, i))], 1u);
+            const int off = (int)((r + side) & (smp - 1));
+            m_tot += (uint32_t)((si.n - off + smp - 1) / smp);
+            for (int i = smp * tid + off; i < si.n; i += smp * kNT) atomicAdd(&coarse[bin_of(key_of(si, i))], 1u);
         }
-        if (tid < kMaxSeg / 4) fillw[tid] = 0ull;
+        if (tid < kMaxSeg) fill32[tid] = 0u;
         __syncthreads();
         DSTAMP(0);
         // (the next row's ticket is fetched by a wavefront that would otherwise wait for the plan)
@@ -357,10 +362,7 @@ __global__ __launch_bounds__(kNT, 4) void k_dense_fused(DenseArgs a) {
         __syncthreads();
         DSTAMP(1);
         // ---- 2. ONE pass over the distances: every point goes to its segment's scratch array ---------------------------------
-        // (position = the segment's fill count so far + the number of earlier lanes with a point for the same segment: a wave scan of
-        //  four 16-bit one-hot fields per word, one LDS atomic per wavefront, word and step)
         if (S > 0) {
-            const int nsw = (S + 3) >> 2;
             const size_t my_scr = (size_t)blockIdx.x * (size_t)df_opaque(ka)->scr_segs * (size_t)kCap;
             uint64_t* const gkey = df_opaque(ka)->scr_key + my_scr;
             uint8_t* const gval = df_opaque(ka)->scr_val + my_scr;
@@ -384,21 +386,28 @@ __global__ __launch_bounds__(kNT, 4) void k_dense_fused(DenseArgs a) {
                         sg[u] = i < ns ? (uint32_t)segtab[bin_of(k[u])] : 0xFFu;
                         v[u] = (uint8_t)((c & 15u) | (uint32_t)(side << 7));
                     }
-                    for (int w = 0; w < nsw; ++w) {  // (wave-uniform)
-                        uint64_t oh = 0ull;
+                    if (S == 1) {  // (workgroup-uniform) one segment: ballot compaction straight into the LDS arrays
+                        unsigned long long bm[4];
+                        uint32_t cnt = 0;
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) oh += (sg[u] >> 2) == (uint32_t)w ? 1ull << ((sg[u] & 3u) * 16u) : 0ull;
-                        const uint64_t incl = wave_incl_scan_fields(oh);
-                        const uint64_t wave_tot = readlane_u64(incl, 63);
-                        unsigned long long base = 0ull;
-                        if (lane == 0 && wave_tot) base = atomicAdd(&fillw[w], (unsigned long long)wave_tot);
-                        uint64_t mine = readlane_u64((uint64_t)base, 0) + (incl - oh);  // my first position in each of the word's four segments
+                        for (int u = 0; u < 4; ++u) { bm[u] = __ballot(sg[u] != 0xFFu); cnt += (uint32_t)__popcll(bm[u]); }
+                        uint32_t at = 0;
+                        if (lane == 0 && cnt) at = atomicAdd(&fill32[0], cnt);
+                        at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (sg[u] != 0xFFu) {
+                                const uint32_t pos = at + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm[u], 0u));
+                                if (pos < (uint32_t)kCap) { skey[pos] = d2u(k[u]); sval[pos] = v[u]; }
+                            }
+                            at += (uint32_t)__popcll(bm[u]);
+                        }
+                    } else {  // several: one returning LDS atomic per point on its segment's fill count (measured against a wave scan of
+                              // one-hot count fields with one atomic per wavefront: 11.58 -> 10.83 ms at 2 x 10^4 atoms, 2.80 -> 2.76 at 10^4)
 #pragma unroll
                         for (int u = 0; u < 4; ++u)
-                            if ((sg[u] >> 2) == (uint32_t)w) {
-                                const uint32_t f = (sg[u] & 3u) * 16u;
-                                const uint32_t pos = (uint32_t)(mine >> f) & 0xFFFFu;
-                                mine += 1ull << f;
+                            if (sg[u] != 0xFFu) {
+                                const uint32_t pos = atomicAdd(&fill32[sg[u]], 1u);
                                 if (pos < (uint32_t)kCap) {
                                     if (sg[u] == 0u) {  // the first segment is sorted first: it waits in the LDS arrays themselves
                                         skey[pos] = d2u(k[u]);
@@ -423,7 +432,7 @@ __global__ __launch_bounds__(kNT, 4) void k_dense_fused(DenseArgs a) {
         uint32_t rf = rowflags_s;
         if (S == 0) rf |= RF_RETRY;
         for (int sg = 0; sg < S; ++sg)
-            if (((uint32_t)(fillw[sg >> 2] >> ((sg & 3) * 16)) & 0xFFFFu) > (uint32_t)kCap) rf |= RF_RETRY;  // the sample under-estimated a segment
+            if (fill32[sg] > (uint32_t)kCap) rf |= RF_RETRY;  // the sample under-estimated a segment
         if (!(rf & RF_ZERO_A) || !(rf & RF_ZERO_B) || (rf & (RF_BAD_DIST | RF_BAD_CAT | RF_RETRY)) || bad_wf) {
             // src/locohd.rs:74-77 (the sorted rows must start with a distance of 0), pmf.rs:38-42, a NaN / negative entry,
             // a row pair this kernel cannot segment: reported, the host turns the flags into the reference's errors
@@ -450,7 +459,7 @@ __global__ __launch_bounds__(kNT, 4) void k_dense_fused(DenseArgs a) {
         // for its load -- 3.08 -> 3.17 / 3.61 ms)
         double m[kEpt];
         uint32_t vv[(kEpt + 3) / 4];
-        auto fill_of = [&](int sgi) -> int { return (int)((uint32_t)(fillw[sgi >> 2] >> ((sgi & 3) * 16)) & 0xFFFFu); };
+        auto fill_of = [&](int sgi) -> int { return (int)fill32[sgi]; };
         auto load_segment = [&](int sgi) {
             int tl = tid;
             asm volatile("" : "+v"(tl));
@@ -512,11 +521,9 @@ __global__ __launch_bounds__(kNT, 4) void k_dense_fused(DenseArgs a) {
                 }
             }
             for (int k = 32; k > 0; k >>= 1) biggest = max(biggest, (uint32_t)__shfl_xor((int)biggest, k));
-            if (lane == 0) wsum[wave] = biggest;
+            if (lane == 0) wbig[wave] = biggest;
             __syncthreads();
-            for (int w = 0; w < kWaves; ++w) biggest = max(biggest, wsum[w]);
-            if (biggest > (uint32_t)kBucketLimit) { give_up = true; break; }  // (workgroup-uniform)
-            __syncthreads();
+            for (int w = 0; w < kWaves; ++w) biggest = max(biggest, wbig[w]);  // (checked behind the scan's barrier: an over-full bucket does not hurt the scan)
             DSTAMP(3);
             {   // exclusive scan of the bucket counters: kScanW words (2 kScanW buckets) per thread
                 constexpr int kScanW = kBuckets / 2 / kNT;
@@ -534,6 +541,7 @@ __global__ __launch_bounds__(kNT, 4) void k_dense_fused(DenseArgs a) {
                 const uint32_t incl = wave_incl_scan_u32(T);
                 if (lane == 63) wsum[wave] = incl;
                 __syncthreads();
+                if (biggest > (uint32_t)kBucketLimit) { give_up = true; break; }  // (workgroup-uniform)
                 uint32_t run = incl - T;
                 for (int w = 0; w < kWaves; ++w) run += w < wave ? wsum[w] : 0u;
 #pragma unroll
@@ -616,10 +624,24 @@ __global__ __launch_bounds__(kNT, 4) void k_dense_fused(DenseArgs a) {
             // keys -> F(distance): the sweep needs nothing else of a point's distance, and here every lane converts (the event
             // loop is a chain of dependent steps per lane).  utils.rs:1-8: the distance is the root of the sum of squares.
             {
+                // (one loop per kind of weight function -- the kind is uniform: a loop that may CALL the pow-based CDFs keeps the
+                //  parameters of the inline ones in spilled scalar registers, a v_readlane per use and event)
                 const DfWf wf = df_wf_load(df_opaque(kc), wfi);
-                for (int p = tid; p < n; p += kNT) {
-                    const double kv = u2d(skey[p]);
-                    skey[p] = d2u(df_cdf(wf, DMX ? kv : df_sqrt(kv), exp_tab));  // (within 1 ulp of utils.rs:1-8's powf(0.5): 1e-16 of F)
+                if (wf.kind == WF_HYPER_EXP && wf.fast) {  // cdfs.rs:5-21, same accumulation order
+                    for (int p = tid; p < n; p += kNT) {
+                        const double kv = u2d(skey[p]);
+                        const double x = DMX ? kv : df_sqrt(kv);  // (within 1 ulp of utils.rs:1-8's powf(0.5): 1e-16 of F)
+                        double sum = 0.0;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (i < wf.nterm) sum += wf.a[i] * df_exp_nonpos(-wf.b[i] * x, exp_tab);
+                        skey[p] = d2u(1.0 - sum * wf.inv);
+                    }
+                } else {
+                    for (int p = tid; p < n; p += kNT) {
+                        const double kv = u2d(skey[p]);
+                        skey[p] = d2u(df_cdf(wf, DMX ? kv : df_sqrt(kv), exp_tab));
+                    }
                 }
             }
             for (int k = tid; k < kPart; k += kNT) t_part[k] = df_opaque(ka)->sqrt_tab[k];  // (the histogram's bytes: no longer needed)
@@ -652,21 +674,25 @@ __global__ __launch_bounds__(kNT, 4) void k_dense_fused(DenseArgs a) {
             const uint32_t sna = wave_incl_scan_u32(n_al);
             if (lane == 63) wtot_a[wave] = sna;
             __syncthreads();
-            if (tid < 2 * NW) {  // per field word: exclusive prefix over the waves on top of the previous segments' counts
-                uint64_t run = base_cnt[tid];
-                for (int w = 0; w < kWaves; ++w) { const uint64_t t = wtot[w][tid]; wtot[w][tid] = run; run += t; }
-                base_cnt[tid] = run;
-            } else if (tid == 2 * NW) {
-                uint32_t run = 0;
-                for (int w = 0; w < kWaves; ++w) { const uint32_t t = wtot_a[w]; wtot_a[w] = run; run += t; }
-                seg_a_s = run;
+            // exclusive prefix over the wavefronts on top of the previous segments' counts: lane k of every wavefront adds up word k
+            // (no second barrier: the next segment's base goes to the other slot of base_cnt)
+            const int par = swept & 1;
+            uint64_t run = 0ull;
+            uint32_t run_a = 0u, tot_a = 0u;
+            if (lane < 2 * NW) {
+                const uint64_t base = base_cnt[par][lane];
+                uint64_t tot = 0ull;
+                run = base;
+                for (int w = 0; w < kWaves; ++w) { const uint64_t t = wtot[w][lane]; run += w < wave ? t : 0ull; tot += t; }
+                if (wave == 0) base_cnt[par ^ 1][lane] = base + tot;
+            } else if (lane == 2 * NW) {
+                for (int w = 0; w < kWaves; ++w) { const uint32_t t = wtot_a[w]; run_a += w < wave ? t : 0u; tot_a += t; }
             }
-            __syncthreads();
 #pragma unroll
-            for (int k = 0; k < NW; ++k) { exA[k] += wtot[wave][k]; exB[k] += wtot[wave][NW + k]; }
-            const int a_before = (int)(sna - n_al + wtot_a[wave]);
+            for (int k = 0; k < NW; ++k) { exA[k] += readlane_u64(run, k); exB[k] += readlane_u64(run, NW + k); }
+            const int a_before = (int)(sna - n_al) + __builtin_amdgcn_readlane((int)run_a, 2 * NW);
             int totA = base_na + a_before, totB = base_nb + (d0 - a_before);
-            const int seg_a = (int)seg_a_s;
+            const int seg_a = __builtin_amdgcn_readlane((int)tot_a, 2 * NW);
 
             DSTAMP(8);
             auto sqrt_cnt = [&](int cnt) -> double { if (cnt < kPart) return t_part[cnt]; else return df_sqrt((double)cnt); };
