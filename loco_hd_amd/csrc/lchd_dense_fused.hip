@@ -5,12 +5,13 @@
 // k_sweep (read them back, merge, integrate)  of lchd_env_rows.hip / lchd_sweep.hip:
 //
 //   reference                                     here
-//   calculate_distance_matrix  utils.rs:10-22     the distance images of a row are recomputed per distance segment
+//   calculate_distance_matrix  utils.rs:10-22     ONE pass over the row pair's distances (plus a quarter of a pass for the plan)
 //   sort_together              utils.rs:25-39     bucket sort of the UNION of both rows' points, one distance segment at a time
 //   stat_dist_integral         locohd.rs:61-226   the sorted segment is integrated where it lies (LDS), counts carried on
 //   PMFSystem / hellinger      pmf.rs, statistical_distances.rs:4-10   O(1) update of the Bhattacharyya sum per event
 //
-// One 512-thread workgroup per row PAIR (row r of A and row r of B), two workgroups per CU (80 KB of LDS each).
+// A launch has 512 workgroups of 512 threads (two per CU, 78 KB of LDS each); a workgroup takes row pair blockIdx (row r of A and
+// row r of B), then whatever row pair a ticket counter hands out next, and owns one scratch region in global memory.
 //
 // Why the union: the reference's two-pointer loop integrates  S = sum_k [F(t_k+1) - F(t_k)] H(after k events)  over the merged
 // order of both lists; equal distances give zero-width intervals whose H never counts, so ANY order among equal keys gives
@@ -19,16 +20,22 @@
 // distance of 0 (checked: :74-77), every interval before the last zero-distance event has width F(0) - F(0) = 0, and H is
 // only evaluated once both sides hold a point.
 //
-// Why segments: 2 x 10^4 points x (8-byte key + 1-byte side | category) do not fit 80 KB.  A coarse empirical CDF of the
-// row pair (512 bins of the distance image, one pass) cuts the distance axis into S balanced segments of at most kCap
-// events at bin boundaries; for every segment the workgroup walks both rows again (coalesced, L2-resident), keeps the points
-// of the segment (ballot compaction into LDS), bucket-sorts them (interpolated rank -> 4096 buckets, ranks inside a bucket
-// on the exact (key, value) pair: deterministic whatever order the compaction produced), and sweeps them with the category
-// counts, totals and the last (F, H) carried from the previous segment.  The bin of a point is a non-decreasing function
-// of its exact key, so segments are exact key ranges and the concatenation of the sorted segments is the sorted union.
+// Why segments, and how a row pair is cut into them (round 5): 2 x 10^4 points x (8-byte key + 1-byte side | category) do not fit
+// 80 KB.  The coarse CDF of the row pair (512 bins of the distance image) is ESTIMATED from every 4th point; it cuts the distance
+// axis into S balanced segments at bin boundaries, each planned with a margin of six standard deviations of what such a sample
+// predicts, so that the real segment fits the LDS arrays (kCap = 6144 events).  Then ONE pass over both rows computes every
+// squared distance once and appends the point -- one returning LDS atomic on its segment's fill count -- to its segment: segment 0
+// straight into the LDS arrays, the others into the workgroup's scratch region (1.35 GB written and read back per 10^4-atom
+// call: 1 TB/s, a quarter of what the fabric delivers to this kernel's access pattern, and the price of not recomputing every
+// distance per segment as round 4 did -- three passes at 10^4 atoms, six at 2 x 10^4).  A segment then comes back into the sort's
+// registers (coalesced), is bucket-sorted (interpolated rank on the sample's CDF -> 8192 buckets, ranks inside a bucket on the
+// exact (key, value) pair: deterministic whatever order the distance pass produced), and swept with the category counts, totals
+// and the last (F, H) carried from the previous segment.  The bin of a point is a non-decreasing function of its exact key, so
+// segments are exact key ranges and the concatenation of the sorted segments is the sorted union.
 //
-// Rows this kernel gives up on (a bucket of more than 64 points: thousands of identical distances; a single coarse bin
-// that holds more than a segment) are reported as ST_ROW_RETRY and the host repeats the call with the two-kernel path.
+// Rows this kernel gives up on (a bucket of more than 64 points: thousands of identical distances; a segment that outgrew its plan:
+// a sample that does not represent the row -- six standard deviations; a row pair that needs more segments than its scratch region
+// holds) are reported as ST_ROW_RETRY and the host repeats the call with the two-kernel path.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

@@ -1,8 +1,8 @@
 """Dense rows (from_coords / from_dmxs, src/locohd.rs:410-476) through the fused sort + sweep kernel
 (loco_hd_amd/csrc/lchd_dense_fused.hip) and, on the same inputs, through the two-kernel path it replaces
 (k_env_rows2 + k_sweep: LCHD_NO_DENSE_FUSED) -- both against the CPU oracle on sampled rows (1e-11) and against each other on
-every row.  Row lengths cover one segment (<= 3 500 points per side), the 10 000-point rows of BASELINE config 2 (three
-segments; the two-kernel path runs its 8 193 .. 10 240-point instantiation there) and 20 000-point rows (six segments)."""
+every row.  Row lengths cover one segment (<= 3 072 points per side), two and three, the 10 000-point rows of BASELINE config 2 (four
+segments; the two-kernel path runs its 8 193 .. 10 240-point instantiation there) and 20 000-point rows (eight segments)."""
 import itertools
 
 import numpy as np
@@ -148,6 +148,41 @@ def test_lattice_ties_and_identical_structures(lh, oracle):
     rows = [0, 5, 17, 1234, n - 1]
     want2 = oracle_rows(lo, s, s[::-1], [dist_row(x2, i) for i in rows], [dist_row(x2[::-1], i) for i in rows])
     assert np.max(np.abs(got2[rows] - want2)) < TIGHT
+
+
+def test_a_sample_that_misrepresents_the_rows(lh, oracle, monkeypatch):
+    """The fused kernel plans a row pair's distance segments from every 4th point (lchd_dense_fused.hip).  Here every 4th atom lies in a
+    far-away cluster and the others in a compact one, so for the rows whose sample is that residue class the plan is wrong by thousands of
+    events: the segment outgrows its LDS arrays, the kernel reports the row (ST_ROW_RETRY) and the host repeats the call with the
+    two-kernel path.  Same scores either way; the ordinary random cloud of the same size stays on the fused path."""
+    rng = np.random.default_rng(4242)
+    n, n_cat = 5000, 9
+    cats, wf = NAMES[:n_cat], ("hyper_exp", [1.0, 0.1])
+
+    def skewed():
+        x = rng.uniform(0.0, 30.0, (n, 3))
+        x[::4] += 400.0  # atoms 0, 4, 8, ...: a second cluster 700 A away
+        return [NAMES[k] for k in rng.integers(0, n_cat, n)], x
+
+    (sa, xa), (sb, xb) = skewed(), skewed()
+    lchd = lh.LoCoHD(cats, lh.WeightFunction(*wf))
+    got = np.asarray(lchd.from_coords(sa, sb, xa, xb))
+    assert fused_flag(lchd) == 0  # the call was repeated by the two-kernel path
+    rows = sorted(set(rng.integers(0, n, 12).tolist()) | {0, 1, 2, 3, 4, n - 1})
+    lo = oracle.LoCoHD(cats, oracle.WeightFunction(*wf))
+    want = oracle_rows(lo, sa, sb, [dist_row(xa, i) for i in rows], [dist_row(xb, i) for i in rows])
+    assert np.max(np.abs(got[rows] - want)) < TIGHT
+    monkeypatch.setenv("LCHD_NO_DENSE_FUSED", "1")
+    plain = lh.LoCoHD(cats, lh.WeightFunction(*wf))
+    assert np.array_equal(np.asarray(plain.from_coords(sa, sb, xa, xb)), got)
+    monkeypatch.delenv("LCHD_NO_DENSE_FUSED")
+    s, x = cloud(rng, n, n_cat, 46.0)
+    t, y = cloud(rng, n, n_cat, 46.0)
+    fused = lh.LoCoHD(cats, lh.WeightFunction(*wf))
+    ok = np.asarray(fused.from_coords(s, t, x, y))
+    assert fused_flag(fused) == 1
+    rows = [0, 77, n - 1]
+    assert np.max(np.abs(ok[rows] - oracle_rows(lo, s, t, [dist_row(x, i) for i in rows], [dist_row(y, i) for i in rows]))) < TIGHT
 
 
 def test_other_configurations_keep_the_two_kernel_path(lh, oracle):
