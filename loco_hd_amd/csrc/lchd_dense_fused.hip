@@ -87,7 +87,10 @@ __host__ __device__ inline int df_seg_margin(int est) { return 6 * (int)sqrtf((f
 constexpr int kBuckets = LCHD_DF_BUCKETS;  // buckets of a segment's sort, two 16-bit counters per LDS word
 constexpr int kBucketLimit = 64;      // a fuller bucket sends the call to the two-kernel path
 constexpr int kPart = kBuckets / 4;   // sqrt(k) for k < kPart from LDS (the histogram's bytes), larger counts are computed
-constexpr int kMaxSeg = 16;
+#ifndef LCHD_DF_MAXSEG
+#define LCHD_DF_MAXSEG 16
+#endif
+constexpr int kMaxSeg = LCHD_DF_MAXSEG;  // (<= 64: the plan gives every boundary a lane)
 constexpr double kExactBelow = 1e-6;  // as lchd_team_tile.h (kExactH2Below): below this H^2 the literal difference-of-roots form
 static_assert(kEpt <= 15 && kCap % kNT == 0, "chunk-local counters are 4-bit fields");
 static_assert((kBuckets / 2) % (4 * kNT) == 0 && kBuckets <= 8192, "the bucket scan gives every thread whole 16-byte groups of histogram words; 13-bit bucket ids");
