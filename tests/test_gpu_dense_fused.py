@@ -185,6 +185,36 @@ def test_a_sample_that_misrepresents_the_rows(lh, oracle, monkeypatch):
     assert np.max(np.abs(ok[rows] - oracle_rows(lo, s, t, [dist_row(x, i) for i in rows], [dist_row(y, i) for i in rows]))) < TIGHT
 
 
+def test_random_shapes_against_the_two_kernel_path(lh, oracle, monkeypatch):
+    """A sweep over row lengths (one to four distance segments, sizes next to the LDS arrays' capacity of 6144 events per segment: 3072
+    points per side), category counts (all three instantiations), weight functions and box shapes: every row of the fused kernel against the
+    two-kernel path (1e-13), two rows per case against the oracle."""
+    rng = np.random.default_rng(555)
+    wfs = [("hyper_exp", [1.0, 0.1]), ("hyper_exp", [0.6, 0.3, 0.1, 0.25, 0.1, 0.04]), ("uniform", [3.0, 25.0]), ("dagum", [2.5, 12.0, 0.8]),
+           ("hyper_exp", [0.25, 0.25, 0.25, 0.25, 1.0, 0.5, 0.2, 0.05])]
+    cases = [(3071, 8), (3072, 5), (3073, 12), (4100, 16), (1030, 3), (6100, 9), (6200, 11), (8191, 7), (2048, 16), (5000, 1)]
+    for k, (n, n_cat) in enumerate(cases):
+        wf = wfs[k % len(wfs)]
+        box = np.array([1.0, 1.0 + (k % 3), 1.0 + (k % 2) * 4.0])  # cubes, slabs and rods: different distance distributions
+        scale = (n / 0.05 / box.prod()) ** (1 / 3)
+        sa, xa = [NAMES[c] for c in rng.integers(0, n_cat, n)], rng.uniform(0.0, 1.0, (n, 3)) * box * scale
+        sb, xb = [NAMES[c] for c in rng.integers(0, n_cat, n)], rng.uniform(0.0, 1.0, (n, 3)) * box * scale
+        cats = NAMES[:n_cat]
+        monkeypatch.delenv("LCHD_NO_DENSE_FUSED", raising=False)
+        fused = lh.LoCoHD(cats, lh.WeightFunction(*wf))
+        got = np.asarray(fused.from_coords(sa, sb, xa, xb))
+        assert fused_flag(fused) == 1, (n, n_cat)
+        monkeypatch.setenv("LCHD_NO_DENSE_FUSED", "1")
+        plain = lh.LoCoHD(cats, lh.WeightFunction(*wf))
+        old = np.asarray(plain.from_coords(sa, sb, xa, xb))
+        assert fused_flag(plain) == 0
+        assert np.max(np.abs(old - got)) < 1e-13, (n, n_cat, wf)
+        rows = [int(rng.integers(0, n)), n - 1]
+        lo = oracle.LoCoHD(cats, oracle.WeightFunction(*wf))
+        want = oracle_rows(lo, sa, sb, [dist_row(xa, i) for i in rows], [dist_row(xb, i) for i in rows])
+        assert np.max(np.abs(got[rows] - want)) < TIGHT, (n, n_cat, wf)
+
+
 def test_other_configurations_keep_the_two_kernel_path(lh, oracle):
     """Category weights, another statistical distance or more than 16 categories: not the fused kernel's configuration."""
     rng = np.random.default_rng(80)
