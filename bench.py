@@ -38,8 +38,8 @@ Multi-GPU (--scaling):
 The JSON line also carries:
   roofline      dominant kernel's ALGORITHMIC bytes per launch (B_pair = (n_A+n_B)*28 + 16) / its average
                 launch duration (HIP events on the launch stream, recorded by the C library) against the 8 TB/s HBM peak
-                (`frac`, as section 8d defines it), plus what actually binds the kernel: `hbm_measured_frac` (HBM-side bytes
-                from the committed rocprofv3 PMC passes / the live duration / peak) and `valu_issue_frac` (SQ_ACTIVE_INST_VALU
+                (`frac`, as section 8d defines it), plus what actually binds the kernel: `fabric_measured_frac` (fabric-side
+                bytes of the committed rocprofv3 PMC passes / the PROFILED duration / peak; Infinity-Cache hits counted) and `valu_issue_frac` (SQ_ACTIVE_INST_VALU
                 x 4 cycles / 1024 SIMDs / the profiled duration at the counter run's clock).
   cpu_baseline  the CPU oracle (C restatement of the reference algorithm, kind "port": the Rust reference cannot be built
                 here) timed on this host's cores on a bounded sample of the same pairs; the same sample is the parity gate
@@ -172,7 +172,8 @@ def roofline_block(workload: str, kernel: str, algo_bytes: float, launch_ms: flo
                      "8 TB/s HBM peak, as section 8d defines the figure; frac_step = the algorithmic bytes of the WHOLE step / ms_per_step / "
                      "peak (what the byte model actually covers: points in, score out).  What binds the kernels of this path is VALU "
                      "issue, not bandwidth (`bound`): valu_issue_frac = SQ_ACTIVE_INST_VALU x 4 cycles / 1024 SIMDs / kernel cycles, "
-                     "hbm_measured_frac = PMC traffic / time / peak; valu_ceiling_frac = (vector instructions of the launch per SIMD x the "
+                     "fabric_measured_frac = PMC traffic / the profiled launch time / peak (Infinity-Cache hits counted); frac_no_reuse "
+                     "(c2a) = the same byte model over the unique-anchor call, where every environment is built for ONE pair; valu_ceiling_frac = (vector instructions of the launch per SIMD x the "
                      "class-weighted cost of the kernel's hot-loop instruction mix, measured per class by profiles/ubench/issue_rates.hip) / "
                      "launch time: 1.0 = the kernel issues as fast as its own instruction mix allows"}
     if step_ms > 0.0:
@@ -181,8 +182,15 @@ def roofline_block(workload: str, kernel: str, algo_bytes: float, launch_ms: flo
     if prof and prof.get("kernel") and prof["kernel"].split("<")[0] in kernel:
         block["traffic"] = prof.get("traffic_bytes_per_launch")
         block["traffic_source"] = f"profiles/{PROFILE_ROUND}/traffic_{workload}.json (separate rocprofv3 --pmc passes of this command)"
-        if block["traffic"]:
-            block["hbm_measured_frac"] = block["traffic"] / (launch_ms * 1e-3) / (HBM_PEAK_GBS * 1e9)
+        prof_ns = prof.get("avg_launch_ns_kernel_trace")
+        if block["traffic"] and prof_ns:
+            # counter bytes over the PROFILED launch time of the same collection (not this run's live time: another box, another
+            # clock).  FETCH_SIZE counts requests at the fabric, Infinity-Cache (MALL) hits included (MI355X_MICROARCH.md, HBM
+            # section): an upper bound of the HBM traffic, hence "fabric", not "hbm"
+            block["fabric_measured_frac"] = block["traffic"] / (prof_ns * 1e-9) / (HBM_PEAK_GBS * 1e9)
+            block["fabric_measured_note"] = ("traffic / avg_launch_ns_kernel_trace of the same profile / 8 TB/s; the counters see fabric "
+                                             "requests, Infinity-Cache hits included: an upper bound of what reached HBM")
+            block["profiled_launch_ms"] = prof_ns * 1e-6
         if prof.get("valu_issue_frac") is not None:
             block["valu_issue_frac"] = prof["valu_issue_frac"]
         for k in ("valu_ceiling_frac", "valu_avg_ns_per_instr_measured", "valu_avg_ns_per_instr_class_mix", "valu_share_of_2_cycle_class",
@@ -270,7 +278,7 @@ class Harness:
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         if self.use_dist:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         return elapsed
@@ -846,7 +854,9 @@ def run_pairs(args, torch, dist, dev, rank, world, use_dist):
         torch.cuda.synchronize()
         tu = (time.perf_counter() - tu) / 20
         extras["unique_anchor_call"] = {"pairs": int(n_atoms), "ms_per_call": tu * 1e3, "pairs_per_s": n_atoms / tu,
-                                        "note": "every anchor used once: no environment re-use between pairs"}
+                                        "algorithmic_bytes": int(sess.last_env_points()) * 28 + 16 * int(n_atoms),
+                                        "note": "every anchor used once: no environment re-use between pairs (whole call: prologue, environments, "
+                                                "sweep, status wait)"}
     value_incl = None
     if rank == 0 and not args.no_cpu_baseline and not strong:
         # the same job through the host-pointer entry point (lchd_from_primitives: packing into the pinned
@@ -901,6 +911,15 @@ def run_pairs(args, torch, dist, dev, rank, world, use_dist):
                               **collective_note(args, world, use_dist)})
         result["roofline"] = roofline_block(args.workload, dom_name, algo_bytes, phase_ms[dom], step_ms=result["ms_per_step"])
         result["kernel_ms"] = phase_ms
+        # how often the step uses an environment it builds: frac (28 B per environment point PER PAIR) can exceed 1 when this is large
+        pl = w["pairs"]
+        result["config"]["env_reuse_factor"] = 2.0 * len(pl) / max(len(np.unique(pl[:, 0])) + len(np.unique(pl[:, 1])), 1)
+        result["config"]["env_reuse_note"] = ("anchor pairs per distinct anchor of the list (SURVEY.md 8d defines C2a as 100 permutation rounds over all "
+                                              "atoms): distances + sort run once per distinct anchor, the sweep once per pair; roofline.frac_no_reuse is "
+                                              "the same byte model on the list with factor 1")
+        if "unique_anchor_call" in extras:
+            u = extras["unique_anchor_call"]
+            result["roofline"]["frac_no_reuse"] = u["algorithmic_bytes"] / (u["ms_per_call"] * 1e-3) / (HBM_PEAK_GBS * 1e9)
         if strong:
             # what the plan cache keeps OUT of the timed steps: one uncached plan + select of this rank's share (two partition kernels and
             # the host's wait for the counts), timed once here so that cached and uncached (--no-plan-cache) lines can be compared
@@ -945,6 +964,40 @@ def run_pairs(args, torch, dist, dev, rank, world, use_dist):
     return final_line
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` with no launcher around it: start `python -m torch.distributed.run --nproc-per-node N bench.py
+    <the same arguments>` as a child process -- this process has not imported torch and has made no GPU call, and it never
+    replaces itself --, pass the child's stdout through line by line (rank 0's JSON line stays the last line) and return its
+    exit code.  The rendezvous is on 127.0.0.1 at a port that was free a moment ago (MASTER_PORT overrides)."""
+    import socket
+    import subprocess
+
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", port, str(Path(__file__).resolve()), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between the ranks needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    print(f"[bench] --gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    try:
+        for line in child.stdout:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        return child.wait()
+    except BaseException:
+        child.terminate()  # (the exact process this function started; torchrun takes its workers down with it)
+        try:
+            child.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            child.kill()
+        raise
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -969,12 +1022,16 @@ def main():
                          "2 for N > 1 and --emulate-world: consecutive steps overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg, the parity gate and the extras (profiling runs)")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (a CHILD process, before this one has
+        # imported torch or touched a GPU -- never an exec), relay their output and exit with the launcher's code
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        print(f"[bench] rank {rank} of {world} up (pid {os.getpid()}, local rank {local_rank})", file=sys.stderr, flush=True)
     if world != args.gpus:  # (the launcher's world is what runs; the defaults below follow it, not just --gpus)
-        if world == 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         if args.gpus != 1:
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch as many ranks as GPUs")
         args.gpus = world  # torchrun without --gpus: the job is `world` GPUs wide
@@ -988,19 +1045,46 @@ def main():
     import torch
     import torch.distributed as dist
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if os.environ.get("LCHD_BENCH_RENDEZVOUS_ONLY"):
+        # launcher check (tests/test_bench_helpers.py, no GPU): the ranks meet over gloo, add up their ranks, rank 0 reports
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank)], dtype=torch.float64)
+        dist.all_reduce(t)
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"rendezvous": "ok", "world": world, "rank_sum": float(t.item()), "gpus": args.gpus}), flush=True)
+        return
+    n_dev = torch.cuda.device_count()  # (does not initialise the GPU on this image)
+    # LCHD_BENCH_SHARE_GPU=1: a REHEARSAL of the N-rank job on fewer GPUs (tests/test_gpu_dist.py: two ranks on the one GPU of a
+    # test box) -- ranks share devices round-robin and meet over gloo with a host-staged gather (RCCL refuses two ranks on one
+    # device); every code path of a real N-rank run except the RCCL transport, and its line says so: not a scaling measurement
+    share = bool(os.environ.get("LCHD_BENCH_SHARE_GPU")) and world > 1 and n_dev >= 1
+    if n_dev <= local_rank and not share:
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank} but this machine shows {n_dev} GPU(s): "
+                         f"--gpus {args.gpus} needs {args.gpus} visible devices (one rank per GPU)")
+    dev_index = local_rank % n_dev if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     use_dist = world > 1 or bool(os.environ.get("LCHD_BENCH_FORCE_DIST"))  # the latter: exercise RCCL init + gather on one GPU
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     runner = {"c4": run_c4, "c3": run_c3, "c2b": run_c2b}.get(args.workload, run_pairs)
     result = runner(args, torch, dist, dev, rank, world, use_dist)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and share:
+        result["rehearsal"] = (f"{world} ranks shared {n_dev} GPU(s) over gloo with a host-staged gather (LCHD_BENCH_SHARE_GPU): every code path "
+                               "of an N-rank run except the RCCL transport; the value is NOT a scaling measurement")
     if rank == 0:
         # RCCL prints a version banner through C stdio; flush it first so that the JSON line is the LAST line of stdout
         import ctypes

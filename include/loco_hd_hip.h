@@ -261,9 +261,6 @@ int64_t lchd_ctx_pass_count(lchd_ctx *ctx);
  * used once (trajectory frames, (i, i) lists, a rank's partners under strong scaling).  The reference builds an environment per
  * pair and side as well (src/locohd.rs:514-554). */
 int64_t lchd_ctx_per_pair_pass_count(lchd_ctx *ctx);
-/* Passes so far that built, sorted and swept side B's environments inside ONE kernel (lchd_env_fused.hip: no environment store write,
- * no pair-record pass, no second staging).  Opt-in through the LCHD_FUSED test hook: measured slower than the two kernels. */
-int64_t lchd_ctx_fused_pass_count(lchd_ctx *ctx);
 /* Second passes run so far.  Environments live in fixed-stride slots (512 points by default); the reference's environments have no
  * capacity (src/locohd.rs:514-542: a Vec per anchor).  When a FEW environments of a call do not fit their slots, only the pairs
  * that touch them are scored again -- a pass of their own with larger slots, its scores scattered over the first pass's --

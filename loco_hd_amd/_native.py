@@ -101,7 +101,6 @@ _PROTOS = {
     "lchd_ctx_get_deterministic": (C.c_int32, [_VP]),
     "lchd_ctx_pass_count": (C.c_int64, [_VP]),
     "lchd_ctx_subset_pass_count": (C.c_int64, [_VP]),
-    "lchd_ctx_fused_pass_count": (C.c_int64, [_VP]),
     "lchd_ctx_per_pair_pass_count": (C.c_int64, [_VP]),
     "lchd_ctx_last_store_bytes": (C.c_int64, [_VP]),
 }

@@ -201,16 +201,13 @@ struct lchd_ctx {
     int64_t last_biggest = 0;  // largest environment of the last pass (0: unknown): anchors per wavefront of k_env_group
     int shrink_votes = 0;  // consecutive passes whose largest environment would fit half of cap_hint
     bool last_dense_fused = false;  // the most recent dense pass ran the fused sort + sweep kernel (lchd_dense_fused.hip)
-    // environment build + sweep in one kernel for side-B environments that are used once (lchd_env_fused.hip): taken when the last
-    // REGULAR pass of the configuration found (almost) every side-B anchor unique; every kFusedRemeasure-th pass is a regular one again
-    // (a fused pass does not de-duplicate side B, so it cannot see the anchors becoming shared)
+    // side B without de-duplication (one environment slot per PAIR) for side-B environments that are used once: taken when the last
+    // REGULAR pass of the configuration found (almost) every side-B anchor unique; every 64th pass is a regular one again
+    // (such a pass does not count side B's unique anchors, so it cannot see the anchors becoming shared)
     bool b_use_once = false;        // the last regular pass: n_unique[1] >= 0.8 n_pairs
     int64_t use_once_pairs = 0, use_once_nb = 0;  // ... its pair count and the size of its side B (the hint holds for lists like it)
-    int fused_streak = 0;           // fused passes since the last regular one
-    bool fused_companion = true;    // the last fused pass left pairs to the INDIRECT sweep (or nothing is known): launch it
-    bool fused_blocked = false;     // a fused pass of this configuration met an environment beyond its group buffer: the regular pipeline from now on
-    int64_t n_fused_passes = 0;
-    int64_t n_per_pair_passes = 0;  // regular passes whose side B was not de-duplicated
+    int per_pair_streak = 0;        // passes without side-B de-duplication since the last regular one
+    int64_t n_per_pair_passes = 0;  // passes whose side B was not de-duplicated
     // second pass over the pairs of overflowed environments (lchd_ctx_finish): grow-only device blocks outside the arena
     char *d_ovf_bits = nullptr, *d_ovf_lists = nullptr;
     size_t ovf_bits_cap = 0, ovf_lists_cap = 0;
@@ -237,9 +234,6 @@ struct lchd_ctx {
         const uint32_t *ovf_a = nullptr, *ovf_b = nullptr;  // overflow lists of the enqueued pass (null: its kernels keep none)
         int64_t n_slots_a = 0, n_slots_b = 0;               // environment slots per side
         bool subset = false;                                // the enqueued pass IS a second pass over the pairs of overflowed environments
-        bool fused = false;                                 // the enqueued pass ran k_env_sweep for side B (no side-B slots, no k_pair_meta)
-        bool fused_no_comp = false;                         // ... without the INDIRECT sweep behind it
-        bool no_fused = false;                              // this call: the regular pipeline only (a fused pass met an overflow)
         bool per_pair = false;                              // the enqueued pass did not de-duplicate side B (slot p = pair p)
     } pend;
     // multi-GPU sharding helpers (lchd_shard_*): device state, host-mapped counts, the plan they belong to
@@ -296,7 +290,6 @@ static int env_int(const char* name, int dflt) {
 static Tuning tuning_from_env() {  // the ONLY place that reads LCHD_* hooks (tests and tuning runs; unset in production)
     Tuning t;
     t.no_struct_cells = getenv("LCHD_NO_STRUCT_CELLS") != nullptr;
-    t.no_small_dedupe = getenv("LCHD_NO_SMALL_DEDUPE") != nullptr;
     t.no_share = getenv("LCHD_NO_SHARED_ENVS") != nullptr;
     t.no_cdf_keys = getenv("LCHD_NO_CDF_KEYS") != nullptr;
     t.no_key_sets = getenv("LCHD_NO_KEY_SETS") != nullptr;
@@ -304,27 +297,18 @@ static Tuning tuning_from_env() {  // the ONLY place that reads LCHD_* hooks (te
     t.force_wide = env_int("LCHD_FORCE_WIDE", 0) != 0;
     t.force_generic = env_int("LCHD_FORCE_GENERIC", 0) != 0;
     t.force_bigenv = env_int("LCHD_FORCE_BIGENV", 0) != 0;
-    t.no_sweep_hint = getenv("LCHD_NO_SWEEP_HINT") != nullptr;
     t.no_inline_meta = getenv("LCHD_NO_INLINE_META") != nullptr;
     t.no_count8 = getenv("LCHD_NO_COUNT8") != nullptr;
     t.no_c8_team = getenv("LCHD_NO_C8_TEAM") != nullptr;
-    if (const char* v = getenv("LCHD_C8_TEAM_MAX")) t.c8_team_max = atoi(v);
     t.old_rows = getenv("LCHD_OLD_ROWS") != nullptr;
     t.no_dense_fused = getenv("LCHD_NO_DENSE_FUSED") != nullptr;
-    t.no_tables = getenv("LCHD_NO_SD_TABLES") != nullptr;
     t.no_env_group = getenv("LCHD_NO_ENV_GROUP") != nullptr;
     t.no_overflow_subset = getenv("LCHD_NO_OVERFLOW_SUBSET") != nullptr;
     t.env_apw = env_int("LCHD_ENV_APW", 0);
-    t.env_small = env_int("LCHD_ENV_GROUP_SMALL", -1);
-    t.sweep_grid = env_int("LCHD_SWEEP_GRID", 0);
     t.no_sd_inc = getenv("LCHD_NO_SD_INC") != nullptr;
     t.force_cmax = env_int("LCHD_FORCE_CMAX", 0);
-    t.cap_hint = env_int("LCHD_CAP_HINT", 0);
-    t.fused = env_int("LCHD_FUSED", 0);
     t.per_pair = env_int("LCHD_PER_PAIR", 0);
     t.pre_rows = env_int("LCHD_PRE_ROWS", 0);
-    t.pipe = env_int("LCHD_PIPE", 0);
-    t.fused_grid = env_int("LCHD_FUSED_GRID", 0);
     return t;
 }
 
@@ -368,7 +352,6 @@ extern "C" int lchd_ctx_create(int32_t device, lchd_ctx** out) {
     lchd_ctx* c = new lchd_ctx();
     c->device = device >= 0 ? device : cur;
     c->tune = c->tune_env = tuning_from_env();
-    if (c->tune.cap_hint > 0) c->cap_hint = c->tune.cap_hint;
     CTX_GUARD(c);  // the caller's current device is restored on every path out of here
     auto bail = [&](hipError_t err, const char* what) {
         lchd_ctx_destroy(c);
@@ -468,7 +451,6 @@ extern "C" int lchd_ctx_set_deterministic(lchd_ctx* c, int32_t on) {
     if (c->deterministic) {
         Tuning& t = c->tune;
         t.no_duo = t.no_count8 = t.no_c8_team = t.no_inline_meta = t.force_bigenv = t.no_dense_fused = t.no_sd_inc = t.no_sweep_hint = true;
-        t.sweep_grid = 0;
     }
     c->sweep_hint = 0;
     return LCHD_OK;
@@ -566,8 +548,6 @@ extern "C" int lchd_ctx_set_config(lchd_ctx* c, const lchd_config* cfg) {
     c->cfg_set = false;
     c->sweep_hint = 0;  // another configuration: what the last pass looked like says nothing about the next
     c->b_use_once = false;
-    c->fused_companion = true;
-    c->fused_blocked = false;
     c->cfg_blob_host.swap(sig);
     DevConfig h{};
     h.n_categories = C;
@@ -1004,7 +984,7 @@ static int prims_enqueue(lchd_ctx* c) {
     // list and every environment are built once -- the anchors of both columns share side A's flags, slots and store.
     const bool same = (a == b) && !c->tune.no_share;
     const int64_t max_env_a = same ? std::min<int64_t>(a->n, 2 * n_pairs) : std::min<int64_t>(a->n, n_pairs);
-    int64_t max_env_b = same ? 0 : std::min<int64_t>(b->n, n_pairs);  // (a fused pass: one slot per PAIR, below)
+    int64_t max_env_b = same ? 0 : std::min<int64_t>(b->n, n_pairs);  // (side B without de-duplication: one slot per PAIR, below)
     // (the grouped kernel addresses environment slots and records with 32-bit offsets: the limits of launch_env_group; larger
     //  calls take k_env_cells, which has none)
     const bool group = cap == kEnvGroupCap && !c->tune.no_env_group && a->n < ((int64_t)1 << 27) && b->n < ((int64_t)1 << 27) &&
@@ -1020,23 +1000,8 @@ static int prims_enqueue(lchd_ctx* c) {
     // (history alone is not enough: the hint must have come from a list of this size on a structure of this size, and a list with more
     //  pairs than the side has atoms repeats anchors by counting -- C2a: 10^6 pairs over 10^4 atoms right after a list of (i, i) pairs)
     const bool like_hinted = n_pairs <= b->n && b->n == c->use_once_nb && 2 * n_pairs >= c->use_once_pairs && n_pairs <= 2 * c->use_once_pairs;
-    bool per_pair = per_pair_ok && (c->tune.per_pair > 0 || (c->b_use_once && like_hinted && !c->fused_blocked && n_pairs > 4096 && c->fused_streak < 64));
-    // ... and, opt-in (LCHD_FUSED=1 / 3: measured SLOWER than the two kernels on every named workload), side B's
-    // environments built, sorted and swept inside ONE kernel (lchd_env_fused.hip): the default configuration only (Hellinger-2, unit
-    // weights, one weight function, CDF keys)
-    int frule = -1;
-    {
-        const int hint = c->tune.no_sweep_hint ? 0 : c->sweep_hint;
-        const bool applies = per_pair_ok && !P.no_fused && c->tune.fused > 0 && c->hellinger2 && c->unit_weights &&
-                             c->h_cfg.n_wf == 1 && !c->tune.no_cdf_keys && !c->tune.no_duo && !c->tune.no_count8 && !c->tune.force_generic &&
-                             !c->tune.force_wide && !c->tune.force_bigenv && fused_applies(std::max(c->h_cfg.n_categories, c->tune.force_cmax));
-        if (applies) frule = c->tune.fused == 3 ? 2 : ((hint & 4) && !(hint & 1) && (hint & 2) ? 2 : 0);
-    }
-    const bool fused = frule >= 0;
-    if (fused) per_pair = true;
-    P.fused = fused;
+    const bool per_pair = per_pair_ok && (c->tune.per_pair > 0 || (c->b_use_once && like_hinted && n_pairs > 4096 && c->per_pair_streak < 64));
     P.per_pair = per_pair;
-    P.fused_no_comp = false;
     if (per_pair) max_env_b = n_pairs;  // (one slot per PAIR)
     const GridPlan ga = plan_grid(a, thr, group ? 2 : 1), gb = plan_grid(b, thr, group ? 2 : 1);
     // Keys of the store: F(distance) whenever the sweep can use them without evaluating a CDF -- one weight function, or a
@@ -1100,13 +1065,13 @@ static int prims_enqueue(lchd_ctx* c) {
         PrepSide psa = prep_side(cva, gva, sa), psb = prep_side(cvb, gvb, sb);
         psb.no_anchors = per_pair ? 1 : 0;  // (side B without de-duplication: no flags, no slots -- one environment per pair)
         (void)launch_prologue(s, c->tune, P.anchors, n_pairs, psa, psb, pb.zero_base, pb.zero_bytes, c->d_status, same);
-        if (per_pair && !fused) launch_pair_anchor_recs(s, P.anchors, n_pairs, psb, c->d_status);  // (k_env_sweep reads the pair list itself)
+        if (per_pair) launch_pair_anchor_recs(s, P.anchors, n_pairs, psb, c->d_status);
     }
     mark(c, 1);
     mark(c, 2);  // (cell lists and anchor de-duplication are one phase now; "anchors" reads 0)
     const bool tag_list = c->h_cfg.tag_mode != 0;
     const EnvSide esa{cva, gva, sa.uniq, sa.env, max_env_a, sa.raw_key, sa.raw_cat, sa.ovf_list},
-                  esb{cvb, gvb, sb.uniq, sb.env, fused ? 0 : max_env_b, sb.raw_key, sb.raw_cat, sb.ovf_list};
+                  esb{cvb, gvb, sb.uniq, sb.env, max_env_b, sb.raw_key, sb.raw_cat, sb.ovf_list};
     P.ovf_a = sa.ovf_list;
     P.ovf_b = sb.ovf_list;
     P.n_slots_a = max_env_a;
@@ -1121,7 +1086,7 @@ static int prims_enqueue(lchd_ctx* c) {
         const int by_size = c->last_biggest > 0 && c->last_biggest <= 140 ? 4 : (c->last_biggest > kEnvGroupSmallUpTo ? 1 : 2);
         const int apw = c->tune.env_apw > 0 ? c->tune.env_apw
                                             : (int)std::max<int64_t>(1, std::min<int64_t>(by_size, (max_env_a + max_env_b) / 8192));
-        P.group_small = c->tune.env_small >= 0 ? (c->tune.env_small != 0 && c->last_biggest <= kEnvGroupCapSmall) : c->group_small;
+        P.group_small = c->group_small;
         if (!launch_env_group(s, c->d_cfg, tag_list, P.group_small, esa, esb, thr, apw, c->d_status))
             return fail(LCHD_EDEVICE, "the grouped environment kernel rejected its launch configuration");
     } else if (!launch_env_cells(s, cap, c->d_cfg, tag_list, esa, esb, thr, c->d_status))
@@ -1148,32 +1113,7 @@ static int prims_enqueue(lchd_ctx* c) {
     sw.n_pairs = n_pairs;
     sw.out = P.out;
     sw.meta = pb.pair_meta;
-    if (fused) {
-        FusedArgs fa{};
-        fa.cfg = c->d_cfg;
-        fa.b = EnvSide{cvb, gvb, nullptr, sb.env, n_pairs, nullptr, nullptr, nullptr};
-        fa.env_a = sa.env;
-        fa.slot_a = sa.slot;
-        fa.anchors = P.anchors;
-        fa.n_pairs = n_pairs; fa.n_atoms_a = a->n; fa.n_atoms_b = b->n;
-        fa.thr = thr;
-        fa.out = P.out;
-        fa.meta = pb.pair_meta;
-        fa.st = c->d_status;
-        fa.done = c->d_done;
-        fa.sqrt_tab = c->d_tabs;
-        fa.rsqrt_tab = c->d_tabs + 65536;
-        const int cm = std::max(c->h_cfg.n_categories, c->tune.force_cmax);
-        if (!launch_env_sweep(s, cm, tag_list, frule, fa, c->h_status, c->seq, c->tune.fused_grid))
-            return fail(LCHD_EDEVICE, "the fused environment + sweep kernel rejected its launch configuration");
-        P.fused_no_comp = !c->fused_companion && c->tune.fused <= 0;
-        if (!P.fused_no_comp) launch_sweep_companion(s, c->tune, c->h_cfg.n_categories, frule, sw);
-        launch_fused_publish(s, fa, c->h_status, c->seq);
-        P.sweep_info = frule == 2 ? 1 : 0;
-        ++c->n_fused_passes;
-    } else {
-        P.sweep_info = launch_sweep(s, c->tune, c->h_cfg.n_categories, c->hellinger2, c->unit_weights, c->wf_pow, c->sweep_hint, sw);
-    }
+    P.sweep_info = launch_sweep(s, c->tune, c->h_cfg.n_categories, c->hellinger2, c->unit_weights, c->wf_pow, c->sweep_hint, sw);
     mark(c, 4);
     if (a->ev_used) { HIP_TRY(hipEventRecord(a->ev_used, s)); a->used_valid = true; }
     if (b->ev_used) { HIP_TRY(hipEventRecord(b->ev_used, s)); b->used_valid = true; }
@@ -1203,7 +1143,6 @@ extern "C" int lchd_from_primitives_dev_async(lchd_ctx* c, lchd_cloud* a, lchd_c
     P.a = a; P.b = b; P.anchors = d_anchors; P.wf = d_wf_index; P.n_pairs = n_pairs; P.thr = thr; P.out = d_out;
     P.cap = c->cap_hint;
     P.subset = false;
-    P.no_fused = false;
     c->last_store_bytes = 0;
     if (int rc = prims_enqueue(c)) return rc;
     P.active = true;
@@ -1309,29 +1248,6 @@ static int finish_passes(lchd_ctx* c, uint32_t* flags_out) {
         collect_times(c, 0, 4);
         if (f & ST_BAD_ANCHOR) { *flags_out = f; return LCHD_OK; }
         const int64_t biggest = c->h_status->max_env;  // largest environment of the pass (k_pair_meta), or what overflowed
-        if (P.fused) {
-            // A pass of k_env_sweep.  An environment that did not fit (its group buffer, a side-A slot): the regular pipeline takes the
-            // call (its kernels grow).  Pairs left without the INDIRECT sweep having been launched: the pass again, with it.
-            if (f & ST_ENV_OVERFLOW) {
-                P.no_fused = true;
-                c->fused_blocked = true;
-                if (int rc = prims_enqueue(c)) return rc;
-                continue;
-            }
-            const unsigned long long taken = c->h_status->n_small;
-            if (f == 0 && P.fused_no_comp && taken < (unsigned long long)P.n_pairs) {
-                c->fused_companion = true;
-                if (int rc = prims_enqueue(c)) return rc;
-                continue;
-            }
-            c->fused_companion = taken < (unsigned long long)P.n_pairs;
-            ++c->fused_streak;
-            if (biggest > 0) { c->group_small = biggest <= kEnvGroupSmallUpTo; c->last_biggest = biggest; }
-            c->last = P.sw;
-            c->last_valid = true;
-            *flags_out = f;
-            return LCHD_OK;
-        }
         if (f & ST_ENV_OVERFLOW) {  // an environment did not fit its slot: its pairs again with larger slots, or the whole pass
             if (biggest > 65535 && (c->h_cfg.n_categories > kMaxCategories || biggest > (1 << 23)))
                 return fail(LCHD_EUNSUPPORTED, "an environment holds %lld points; beyond 65535 per environment this build handles at most %d "
@@ -1373,7 +1289,7 @@ static int finish_passes(lchd_ctx* c, uint32_t* flags_out) {
         // The capacity hint decays: a single dense environment should not make every later call of this context pay for
         // its slot size (slots are fixed-stride).  Eight passes in a row that would have fitted half the capacity halve it.
         if (!P.subset) {
-            if (c->cap_hint > 512 && !c->tune.cap_hint && biggest > 0 && 2 * next_pow2_host(biggest) <= c->cap_hint) {
+            if (c->cap_hint > 512 && biggest > 0 && 2 * next_pow2_host(biggest) <= c->cap_hint) {
                 if (++c->shrink_votes >= 8) { c->cap_hint = std::max(512, c->cap_hint / 2); c->shrink_votes = 0; }
             } else {
                 c->shrink_votes = 0;
@@ -1391,7 +1307,7 @@ static int finish_passes(lchd_ctx* c, uint32_t* flags_out) {
         if (biggest > 0) { c->group_small = biggest <= kEnvGroupSmallUpTo; c->last_biggest = biggest; }
         if (!P.subset) {
             if (P.per_pair) {
-                ++c->fused_streak;
+                ++c->per_pair_streak;
                 ++c->n_per_pair_passes;
                 // (this pass did not count side B's unique anchors; its bit set counts the repeated ones: a list that shares
                 //  more than a fifth of them goes back to the regular pipeline with the next pass)
@@ -1401,7 +1317,7 @@ static int finish_passes(lchd_ctx* c, uint32_t* flags_out) {
                 c->b_use_once = !same_obj && (unsigned long long)c->h_status->n_unique[1] * 5ull >= (unsigned long long)P.n_pairs * 4ull;
                 c->use_once_pairs = P.n_pairs;
                 c->use_once_nb = P.b ? P.b->n : 0;
-                c->fused_streak = 0;
+                c->per_pair_streak = 0;
             }
         }
         if (c->h_status->n_small != ~0ull)  // what the pairs looked like this time picks the sweep kernels of the next pass of this configuration
@@ -1428,7 +1344,6 @@ extern "C" int lchd_ctx_finish(lchd_ctx* c) {
 }
 
 extern "C" int64_t lchd_ctx_subset_pass_count(lchd_ctx* c) { return c ? c->n_subset_passes : -1; }
-extern "C" int64_t lchd_ctx_fused_pass_count(lchd_ctx* c) { return c ? c->n_fused_passes : -1; }
 extern "C" int64_t lchd_ctx_per_pair_pass_count(lchd_ctx* c) { return c ? c->n_per_pair_passes : -1; }
 extern "C" int64_t lchd_ctx_last_store_bytes(lchd_ctx* c) { return c ? (int64_t)c->last_store_bytes : -1; }
 
@@ -1781,7 +1696,7 @@ static int host_call_enqueue(lchd_ctx* c, const lchd_config* cfg, const double* 
     int64_t* ha = reinterpret_cast<int64_t*>(c->h_io + o_anchors);
     int32_t* hw = reinterpret_cast<int32_t*>(c->h_io + o_wf);
     bool piped = false;
-    if (!subset && n >= kPipePairs && c->tune.pipe >= 0) {
+    if (!subset && n >= kPipePairs) {
         // the structures (and whatever lies in front of the pair list) first, then the list chunk by chunk: the copy of chunk k + 1
         // into the staging block overlaps the DMA of chunk k
         HIP_TRY(hipMemcpyAsync(c->d_io, c->h_io, o_anchors, hipMemcpyHostToDevice, c->stream));
@@ -1820,7 +1735,7 @@ static int host_call_finish(lchd_ctx* c, HostCall& hc, const int64_t* subset, do
     hc.enqueued = false;
     CTX_GUARD(c);
     int rc = lchd_ctx_finish(c);
-    if (!rc && !hc.direct && !subset && hc.n >= kPipePairs && c->tune.pipe >= 0) {
+    if (!rc && !hc.direct && !subset && hc.n >= kPipePairs) {
         // the scores come back in chunks: chunk k is copied out to the caller's array while the DMA engine fetches chunk k + 1
         const int64_t chunk = std::max<int64_t>(kPipePairs, (hc.n + 3) / 4);
         hipError_t e = hipSuccess;
@@ -2083,7 +1998,7 @@ extern "C" int lchd_group_from_primitives(lchd_group* g, const lchd_config* cfg,
         return LCHD_OK;
     }
     // several devices, one weight function: the partition runs on the devices (above)
-    if (world > 1 && n_a > 0 && !wf_index && !getenv("LCHD_GROUP_HOST_PARTITION"))
+    if (world > 1 && n_a > 0 && !wf_index)
         return group_call_device_partition(g, cfg, xyz_a, cat_a, tag_a, n_a, xyz_b, cat_b, tag_b, n_b, anchors, n_pairs, thr, out);
     // the pair list, binned by anchor (the rule of k_shard_plan): device r gets the positions subset[r]
     std::vector<std::vector<int64_t>> subset((size_t)world);

@@ -68,7 +68,6 @@ struct HostStatus {
 // launchers by value: nothing in the launch path calls getenv().
 struct Tuning {
     bool no_struct_cells = false;   // LCHD_NO_STRUCT_CELLS: always the generic (multi-pass, global atomics) cell list
-    bool no_small_dedupe = false;   // LCHD_NO_SMALL_DEDUPE: never the fused one-workgroup-per-side prologue
     bool no_share = false;          // LCHD_NO_SHARED_ENVS: build both sides even when they are the same device object
     bool no_key_sets = false;       // LCHD_NO_KEY_SETS: weight-function dictionaries keep distance keys (the CDF is evaluated by the sweep, per event)
     bool no_cdf_keys = false;       // LCHD_NO_CDF_KEYS: environments keep distance keys even with a single weight function
@@ -76,26 +75,18 @@ struct Tuning {
     bool force_wide = false;        // LCHD_FORCE_WIDE: k_sweep_wide for any category count
     bool force_generic = false;     // LCHD_FORCE_GENERIC: MODE_GEN even for Hellinger-2
     bool force_bigenv = false;      // LCHD_FORCE_BIGENV: the !LDSTAB sweep instantiations
-    bool no_sweep_hint = false;     // LCHD_NO_SWEEP_HINT: always launch all three sweep kernels and let the device decide
+    bool no_sweep_hint = false;     // (deterministic mode only) always launch all three sweep kernels and let the device decide
     bool no_inline_meta = false;    // LCHD_NO_INLINE_META: small calls also run k_pair_meta + the regular sweep kernels
     bool old_rows = false;          // LCHD_OLD_ROWS: dense rows through k_env_rows (three distance passes) for every length
     bool no_dense_fused = false;    // LCHD_NO_DENSE_FUSED: dense rows always through the two-kernel path (row sort, then sweep)
     bool no_count8 = false;         // LCHD_NO_COUNT8: never the 8-bit-count sweep
     bool no_c8_team = false;        // LCHD_NO_C8_TEAM: the 8-bit-count sweep always one pair per wavefront (k_sweep<.., CNT8>)
-    int c8_team_max = 0;            // LCHD_C8_TEAM_MAX: ... above this many category slots (0: the two-pairs form up to 32)
-    bool no_tables = false;         // LCHD_NO_SD_TABLES: generic distances without the per-launch power / log tables
     bool no_overflow_subset = false;  // LCHD_NO_OVERFLOW_SUBSET: an overflowing environment repeats the WHOLE pass with larger slots (never only its pairs)
     bool no_env_group = false;      // LCHD_NO_ENV_GROUP: environments of the default capacity through k_env_cells (one per wavefront) too
     bool no_sd_inc = false;         // LCHD_NO_SD_INC: Kullback-Leibler / Renyi through the generic sweep even where k_sweep_inc applies
-    int sweep_grid = 0;             // LCHD_SWEEP_GRID: most workgroups of a sweep launch (0: 8192)
-    int env_small = -1;             // LCHD_ENV_GROUP_SMALL: 0 / 1 forces the regular / the small instantiation of k_env_group (-1: from the previous pass)
     int env_apw = 0;                // LCHD_ENV_APW: anchors per wavefront of k_env_group (0: chosen from the number of anchors)
     int force_cmax = 0;             // LCHD_FORCE_CMAX: at least this many category slots
-    int cap_hint = 0;               // LCHD_CAP_HINT: first environment capacity to try
-    int fused = 0;                  // LCHD_FUSED: 1 / 3 the fused environment + sweep kernel (lchd_env_fused.hip) whenever it applies, with the 240-event / the 480-event team rule (default 0: never -- measured slower than the two kernels)
     int per_pair = 0;               // LCHD_PER_PAIR: -1 never a side B without de-duplication, 1 whenever it applies, 0: from the previous pass (side-B anchors (almost) all unique)
-    int fused_grid = 0;             // LCHD_FUSED_GRID: workgroups of the fused kernel (0: 4096)
-    int pipe = 0;                   // LCHD_PIPE: -1 large host-pointer calls stage their pair list and scores in one piece (no chunked, multi-threaded copies)
     int pre_rows = 0;               // LCHD_PRE_ROWS: -1 never prefix-count rows next to the environments (the team sweeps build their chunk-start counts per tile), 1 also for small calls, 0: by the rule of prims_enqueue
 };
 
@@ -199,7 +190,7 @@ struct PrepSide {
     uint32_t* chunk_base;    // [(n >> 18) + 2] anchors before each chunk
     uint32_t* slot;          // [n + 1] atom -> environment slot (anchors only)
     AnchorRec* uniq;         // [max_envs]
-    int32_t no_anchors;      // 1: this side's anchors are neither flagged nor de-duplicated (k_env_sweep builds an environment per PAIR): cell list only
+    int32_t no_anchors;      // 1: this side's anchors are neither flagged nor de-duplicated (side B without de-duplication: k_pair_anchor_recs writes an anchor record per PAIR): cell list only
 };
 // Cell lists of both sides + anchor de-duplication (see lchd_prologue.hip).  [zero_base, zero_base + zero_bytes) is the
 // contiguous region holding cell_count of both sides followed by flag8_a, flag8_b (in this order, flag8_b last): the prologue
@@ -307,37 +298,12 @@ bool dense_fused_applies(int n_categories, int64_t len_a, int64_t len_b);
 bool launch_dense_fused(hipStream_t s, int n_categories, const DenseArgs& a, HostStatus* hst, uint32_t seq);
 void init_dense_fused_kernels();  // per device (dynamic LDS above 64 KB), called by lchd_ctx_create
 
-// Environment build + sweep in one kernel for side-B environments that are used once (lchd_env_fused.hip).  Side A's environments
-// come from the store (k_env_group ran before); side B needs its cell list only (PrepSide::no_anchors).  Slot p of side B's store
-// and record p of `meta` belong to pair p: the kernel writes the record of every pair, the length of every slot, and the
-// environment itself for the pairs it leaves to the INDIRECT sweep behind it.
-struct FusedArgs {
-    const DevConfig* cfg;
-    EnvSide b;                 // side B: structure, grid, the store's slots [n_pairs] (uniq / ovf_list unused)
-    EnvStore env_a;
-    const uint32_t* slot_a;    // side A: atom -> environment slot
-    const int64_t* anchors;    // [P][2]
-    int64_t n_pairs, n_atoms_a, n_atoms_b;
-    double thr;
-    double* out;
-    int4* meta;
-    DeviceStatus* st;
-    DoneState* done;           // context-owned, zero between kernels: the pass's totals (pairs swept here, largest environment)
-    const double* sqrt_tab;
-    const double* rsqrt_tab;
-};
-bool fused_applies(int n_categories);
-// rule: 0 = teams of 16 lanes, pairs of at most 240 merged events; 2 = teams of 32, 8-bit-count pairs of at most 480.  Returns false
-// (nothing launched) when the kernel does not apply.
-bool launch_env_sweep(hipStream_t s, int n_categories, bool tag_list, int rule, const FusedArgs& fa, HostStatus* hst, uint32_t seq, int grid_cap);
-void launch_fused_publish(hipStream_t s, const FusedArgs& fa, HostStatus* hst, uint32_t seq);
-
 struct SweepArgs {
     const DevConfig* cfg;
     EnvStore env_a, env_b;
     const int64_t* anchors;   // [P][2] or nullptr => pair p uses env (p, p)
     const uint32_t* slot_a;   // anchor index -> env slot (nullptr with anchors == nullptr)
-    const uint32_t* slot_b;   // (nullptr with anchors != nullptr: side B's slot of pair p is p -- a pass of k_env_sweep)
+    const uint32_t* slot_b;   // (nullptr with anchors != nullptr: side B's slot of pair p is p -- side B without de-duplication)
     int64_t n_slot_a, n_slot_b;  // atoms per side (bounds for the anchor indices)
     const int32_t* wf_index;  // [P] or nullptr => 0
     int64_t n_pairs;
@@ -371,9 +337,6 @@ struct SweepArgs {
 // launch was left out: the caller must check this pass's counts, HostStatus::n_duo / n_c8 against the number of pairs).
 int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinger2, bool unit_weights, bool wf_pow, int sweep_hint,
                  const SweepArgs& a);
-// The INDIRECT one-pair-per-wavefront sweep alone, over the pair records somebody else wrote (k_env_sweep): the pairs that are not
-// small under `rule`.  Hellinger-2, unit weights, CDF-keyed stores of the default capacity.
-void launch_sweep_companion(hipStream_t s, const Tuning& t, int n_categories, int rule, const SweepArgs& a);
 // Kullback-Leibler / Renyi in O(1) per event (lchd_sweep_inc.hip): unit weights, CDF-keyed environments of at most 512 points, tiny eps;
 // reads the pair records of k_pair_meta.  kind: SweepArgs::sd_fast.
 void launch_sweep_inc(hipStream_t s, int kind, int cmax, const SweepArgs& a);

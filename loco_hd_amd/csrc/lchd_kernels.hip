@@ -13,7 +13,6 @@
 //                                            lchd_sweep_wide.hip    33 .. 65534 categories, environments beyond 65535 points
 //                                            lchd_sweep_inc.hip     Kullback-Leibler / Renyi in O(1) per event
 //                                            (stat_dist_integral :61-226, pmf.rs, statistical_distances.rs, cdfs.rs)
-//       fused K1 + K2 (opt-in)               lchd_env_fused.hip
 //
 // Here: launch_sweep (which of the sweep kernels take a pass -- from the configuration, the call's size and the previous pass's
 // pair statistics), the record pass, and the kernels around the path: multi-GPU sharding of a pair list, the second pass over
@@ -110,7 +109,7 @@ int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinge
     SweepArgs a = a_in;
     a.duo_enabled = 0;
     a.forced = 0;
-    a.gen_tab = (unit_weights && !t.no_tables) ? 1 : 0;  // (MODE_GEN, Hellinger with a general exponent: the configuration's power tables apply)
+    a.gen_tab = unit_weights ? 1 : 0;  // (MODE_GEN, Hellinger with a general exponent: the configuration's power tables apply)
     if (t.force_generic) hellinger2 = false;  // test hook
     if (a.n_pairs <= kInlineMetaPairs && !t.no_inline_meta && hellinger2 && unit_weights && n_categories <= 32 && !t.force_wide &&
         a.env_a.cdf_keys && a.env_b.cdf_keys && a.env_a.stride <= kSqrtTab && a.env_b.stride <= kSqrtTab && !t.force_bigenv) {
@@ -124,9 +123,9 @@ int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinge
     const int64_t blocks = (a.n_pairs + kSweepWaves - 1) / kSweepWaves;
     // grid-stride: LDS tables are built once per block.  8192 workgroups = 8 rounds of the 1024 that are resident at a time: finer
     // than that the table loads show, coarser the last round's imbalance does (measured on C2a: 4096 +2.8 %, 16384 +0.5 %)
-    const int64_t gcap = t.sweep_grid > 0 ? t.sweep_grid : 8192;
+    const int64_t gcap = 8192;
     // ... the team sweeps (shorter iterations, a smaller table load per workgroup): 16384 (C2a 1.3648 -> 1.358 ms, C3 0.7835 -> 0.7769; 32768: no further gain)
-    const int64_t tcap = t.sweep_grid > 0 ? t.sweep_grid : 16384;
+    const int64_t tcap = 16384;
     const unsigned grid = (unsigned)(blocks < gcap ? blocks : gcap);
     const int cmax = std::max(n_categories, t.force_cmax);  // (force_cmax: test hook)
     const bool small = a.env_a.stride <= kSqrtTab && a.env_b.stride <= kSqrtTab && !t.force_bigenv;  // every count fits the LDS tables
@@ -136,10 +135,9 @@ int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinge
     // environments <= 255 points, more than 16 slots); the INDIRECT 16-bit k_sweep takes what they leave over.
     // ... and, up to 16 slots, for category weights other than 1 (the WGT instantiations of the team kernels; the one-pair-per-wavefront
     // 8-bit-count sweep has no weighted form, so both team rules must be available)
-    const bool weighted_team = !unit_weights && cmax <= 16 && !t.no_duo && !t.no_c8_team && !t.no_count8 && (t.c8_team_max == 0 || t.c8_team_max >= cmax);
+    const bool weighted_team = !unit_weights && cmax <= 16 && !t.no_duo && !t.no_c8_team && !t.no_count8;
     // ... and for the Kolmogorov-Smirnov distance with unit weights (SweepArgs::sd_fast == 3: the KSM instantiations)
-    const bool ks_team = !hellinger2 && a.sd_fast == 3 && unit_weights && cmax <= 16 && !t.no_duo && !t.no_c8_team && !t.no_count8 && !t.force_generic &&
-                         (t.c8_team_max == 0 || t.c8_team_max >= cmax);
+    const bool ks_team = !hellinger2 && a.sd_fast == 3 && unit_weights && cmax <= 16 && !t.no_duo && !t.no_c8_team && !t.no_count8 && !t.force_generic;
     const bool fast_cfg = !wide && ((hellinger2 && (unit_weights || weighted_team)) || ks_team) && small && fmode == F_KEY;  // (F_KEY with a weight-function dictionary: the store holds one key set per function)
     // sweep_hint (what k_pair_meta counted in the previous pass of this configuration): 0 = nothing known, else
     // 4 | (pairs of <= 240 events were the majority ? 1 : 0) | (pairs with both environments <= 255 points were ? 2 : 0).
@@ -152,7 +150,7 @@ int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinge
     const bool use_duo = fast_cfg && cmax <= 16 && !t.no_duo && !c8_small_slots;
     const bool use_c8 = fast_cfg && !t.no_count8 && (cmax > 16 || c8_small_slots);
     // up to 16 slots the 8-bit-count pairs are swept two per wavefront (rule 2: and at most 480 merged events)
-    const bool team_ok = !t.no_c8_team && cmax <= (t.c8_team_max > 0 ? t.c8_team_max : 32);
+    const bool team_ok = !t.no_c8_team && cmax <= 32;
     const bool c8_team = use_c8 && team_ok;
     a.c8_rule = team_ok ? 2 : 1;  // (what k_pair_meta counts as n_c8 -- whichever small-pair kernel this pass uses)
     a.small_rule = use_c8 ? a.c8_rule : 0;
@@ -215,20 +213,6 @@ int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinge
         launch_sweep_plain(s, unit_weights ? MODE_H2U : MODE_H2W, small, cmax, grid, fmode, a);
     }
     return info & 1;
-}
-
-void launch_sweep_companion(hipStream_t s, const Tuning& t, int n_categories, int rule, const SweepArgs& a_in) {
-    if (a_in.n_pairs <= 0) return;
-    SweepArgs a = a_in;
-    a.duo_enabled = 1;
-    a.forced = 1;
-    a.small_rule = rule;
-    a.c8_rule = 2;
-    a.second_rule = 0;
-    a.gen_tab = 0;
-    const int64_t blocks = (a.n_pairs + kSweepWaves - 1) / kSweepWaves;
-    const unsigned bgrid = (unsigned)std::min<int64_t>(blocks, LCHD_COMPANION_GRID);
-    launch_sweep_indirect(s, std::max(n_categories, t.force_cmax), 0, bgrid, a);
 }
 
 // Kernels that may be launched with more than 64 KB of dynamic LDS need the limit raised per DEVICE: lchd_ctx_create calls this

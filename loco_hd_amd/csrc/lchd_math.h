@@ -17,8 +17,10 @@
 
 // Loop over categories: with NMAX > 0 the loop is fully unrolled to NMAX iterations and guarded by c < n
 // (register-resident state on the device); with NMAX == 0 it is a plain runtime loop (host).
+// (unroll count 1 = "do not unroll": a bare `unroll` on the runtime loop draws -Wpass-failed from every instantiation with NMAX == 0)
+#define LCHD_PRAGMA_(x) _Pragma(#x)
 #define LCHD_FOR_C(NMAX, n, c) \
-    _Pragma("unroll") for (int c = 0; c < ((NMAX) > 0 ? (NMAX) : (n)); ++c) if ((NMAX) == 0 || c < (n))
+    LCHD_PRAGMA_(clang loop unroll_count((NMAX) > 0 ? (NMAX) : 1)) for (int c = 0; c < ((NMAX) > 0 ? (NMAX) : (n)); ++c) if ((NMAX) == 0 || c < (n))
 
 namespace lchd {
 

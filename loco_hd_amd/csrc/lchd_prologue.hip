@@ -235,7 +235,7 @@ __global__ __launch_bounds__(1024) void k_prologue_fused(const int64_t* __restri
     const int n = c.n, cps = P.g.dim[0] * P.g.dim[1] * P.g.dim[2], nw = (n + 31) >> 5;
     for (int w = tid; w <= kBitWordsMax; w += 1024) bits[w] = 0u;
     cell_build_wg<1024>(c, P.g, cps, 0, n, 0, true, P.rec, P.pos_of, P.cell_start, smem_pf, wsum);  // (its barriers order the clear above)
-    if (P.no_anchors) {  // (k_env_sweep validates this side's anchor indices itself)
+    if (P.no_anchors) {  // (side B without de-duplication: k_pair_anchor_recs validates this side's anchor indices)
         if (tid == 0) st->n_unique[side] = 0u;
         return;
     }
@@ -525,7 +525,7 @@ int launch_prologue(hipStream_t s, const Tuning& t, const int64_t* anchors, int6
     }
     const int cps_a = a.g.dim[0] * a.g.dim[1] * a.g.dim[2], cps_b = b.g.dim[0] * b.g.dim[1] * b.g.dim[2];
     int ops = 0;
-    if (!same && fa && fb && csa.n_struct == 1 && csb.n_struct == 1 && n_pairs <= kFusedPairsMax && !t.no_small_dedupe && a.c.n > 0 && b.c.n > 0) {
+    if (!same && fa && fb && csa.n_struct == 1 && csb.n_struct == 1 && n_pairs <= kFusedPairsMax && a.c.n > 0 && b.c.n > 0) {
         const size_t lds = std::max((size_t)cps_a * 4 + (size_t)a.c.n * 4, (size_t)cps_b * 4 + (size_t)b.c.n * 4);
         k_prologue_fused<<<2, 1024, lds, s>>>(anchors, n_pairs, a, b, st);
         return 1;

@@ -99,6 +99,26 @@ __device__ unsigned long long g_sweep_stamps[8];
 // counts are 8-bit fields, eight per word instead of four -- half the words to scan across the wavefront, to unpack at every
 // tile and to keep per lane, and 3 KB less LDS per wavefront, which lets the many-slot variants run at 3 waves per SIMD
 // instead of 2.  Pairs with a larger environment are left to the INDIRECT instantiation of the 16-bit kernel.
+#ifndef LCHD_C8S_WAVES
+#define LCHD_C8S_WAVES 4   // waves per SIMD the 8-bit-count sweep with at most 12 category slots is compiled for
+#endif
+// Waves per SIMD an instantiation is COMPILED for (the register budget: 512 / waves).  The default configurations (Hellinger-2, unit
+// weights, CDF keys, LDS tables) are register-bound: 4 up to 12 slots, 3 up to 16, 2 beyond.  The others are bound by their LDS
+// footprint -- 576-event tiles without the LDS tables (deterministic mode, environments beyond 512 points), the weighted sweeps'
+// 448-event tiles + per-category multipliers, the CDF-evaluating FMODEs -- and were asking for an occupancy their LDS does not admit
+// (round 5: 16 -Wpass-failed warnings, "desired occupancy was 4, final occupancy is 3"): they now ask for what they get, and the
+// allocator may use the registers that occupancy leaves.
+template <int CMAX, int MODE, int FMODE, bool LDSTAB, bool CNT8>
+constexpr int sweep_waves_per_simd() {
+    if (MODE == MODE_GEN) return CMAX <= LCHD_GEN_W3MAX ? 3 : 2;
+    if (CMAX <= 12) {
+        if (CNT8) return LCHD_C8S_WAVES;
+        if (!LDSTAB) return ((CMAX > 8 && (FMODE == 2 || MODE == MODE_H2W)) || (MODE == MODE_H2W && FMODE == 2)) ? 2 : 3;
+        return MODE == MODE_H2W ? 3 : 4;
+    }
+    if (CMAX <= LCHD_SWEEP_W3MAX) return (MODE == MODE_H2W && LDSTAB) ? 2 : 3;
+    return CNT8 ? LCHD_C8_WAVES : 2;
+}
 template <int CMAX, int MODE, int FMODE, bool LDSTAB, bool INDIRECT = false, bool INLINE_META = false, bool CNT8 = false>
 #ifndef LCHD_DENSE_PARTTAB
 #define LCHD_DENSE_PARTTAB 1024   // entries of the partial sqrt table of the sweeps without full LDS tables (0: none)
@@ -106,10 +126,7 @@ template <int CMAX, int MODE, int FMODE, bool LDSTAB, bool INDIRECT = false, boo
 #ifndef LCHD_EXACT_H2_LOOP
 #define LCHD_EXACT_H2_LOOP 1
 #endif
-#ifndef LCHD_C8S_WAVES
-#define LCHD_C8S_WAVES 4   // waves per SIMD the 8-bit-count sweep with at most 12 category slots is compiled for
-#endif
-__global__ __launch_bounds__(64 * kSweepWaves, (MODE == MODE_GEN ? (CMAX <= LCHD_GEN_W3MAX ? 3 : 2) : (CMAX <= 12 ? (CNT8 ? LCHD_C8S_WAVES : 4) : (CMAX <= LCHD_SWEEP_W3MAX ? 3 : (CNT8 ? LCHD_C8_WAVES : 2))))) void k_sweep(SweepArgs args) {
+__global__ __launch_bounds__(64 * kSweepWaves, (sweep_waves_per_simd<CMAX, MODE, FMODE, LDSTAB, CNT8>())) void k_sweep(SweepArgs args) {
     static_assert(!(INDIRECT && INLINE_META), "the indirect instantiation reads the records of k_pair_meta");
     static_assert(!CNT8 || (MODE == MODE_H2U && FMODE == F_KEY && LDSTAB && !INDIRECT && !INLINE_META), "8-bit counts: default configuration only");
     // Merged events per lane per tile.  The per-tile prologue (staging, merge path, scan of the packed counts, state reload)

@@ -38,7 +38,7 @@ namespace lchd {
 #endif
 template <int CMAX, int TL = LCHD_DUO_TL, int TILE_ = kDuoTile, bool WGT = false, bool KSM = false, bool PRE = false>
 __global__ __launch_bounds__(64 * kSweepWaves, ((CMAX <= 16 && !(WGT && CMAX > 8 && (LCHD_WGT_LDSCNT || LCHD_WGT_W3))) ? 4 : LCHD_TEAM_BIG_WAVES)) void k_sweep_duo(SweepArgs args) {
-    // (the tile itself -- merge path, chunk histogram, count scans, event loop, stitching -- is lchd_team_tile.h: shared with k_env_sweep)
+    // (the tile itself -- merge path, chunk histogram, count scans, event loop, stitching -- is lchd_team_tile.h)
     using TT = TeamTile<CMAX, TL, TILE_, WGT, KSM, PRE>;
     constexpr int TEAMS = TT::TEAMS, EPL = TT::EPL, TILE = TT::TILE, WPB = kSweepWaves, NT = TT::NT, LW = TT::LW;
     constexpr bool LCNT = TT::LCNT;

@@ -2,9 +2,7 @@
 // (reference: LoCoHD::stat_dist_integral, /root/reference/src/locohd.rs:61-226; PMFSystem, src/locohd/pmf.rs:47-88;
 // hellinger_distance / kolmogorov_smirnov_distance, src/locohd/pmf/statistical_distances.rs:4-21).
 //
-// Shared by k_sweep_duo (lchd_sweep_team.hip: both environments staged from the environment store) and k_env_sweep
-// (lchd_env_fused.hip: list B is the environment the wavefront has just built and sorted in LDS, list A comes from the store).
-// The caller stages the two sorted lists (keys = bits of F(distance), ascending; categories; anchors excluded) into LDS and hands
+// Used by k_sweep_duo (lchd_sweep_team.hip: both environments staged from the environment store).  The caller stages the two sorted lists (keys = bits of F(distance), ascending; categories; anchors excluded) into LDS and hands
 // over pointers; everything from the merge-path partition to the team's reduced integral happens here.
 #pragma once
 #include <type_traits>

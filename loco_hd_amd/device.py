@@ -62,7 +62,7 @@ class DeviceSession:
         (lchd_ctx_pass_count, lchd_ctx_subset_pass_count); store_bytes: environment-store bytes of the last call's passes."""
         lib = N.lib()
         return {"passes": int(lib.lchd_ctx_pass_count(self._ctx)), "subset_passes": int(lib.lchd_ctx_subset_pass_count(self._ctx)),
-                "fused_passes": int(lib.lchd_ctx_fused_pass_count(self._ctx)), "per_pair_passes": int(lib.lchd_ctx_per_pair_pass_count(self._ctx)),
+                "per_pair_passes": int(lib.lchd_ctx_per_pair_pass_count(self._ctx)),
                 "store_bytes": int(lib.lchd_ctx_last_store_bytes(self._ctx))}
 
     def upload(self, xyz: np.ndarray, cat: np.ndarray, tag: Optional[np.ndarray] = None):

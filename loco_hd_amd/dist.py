@@ -136,9 +136,27 @@ def gather_scores(local, gathered, world: int, rank: int, group=None, force_coll
             gathered[: local.numel()].copy_(local.reshape(-1))
         return None
     n = local.numel()
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo has no gather of device tensors: staged through the host (rehearsals of the multi-rank path on one GPU or on CPU
+        # ranks; RCCL -- backend "nccl" -- gathers device to device).  `.cpu()` waits for the scoring pass on the current stream.
+        import torch
+
+        host = local.reshape(-1).cpu()
+        got = [torch.empty(n, dtype=local.dtype) for _ in range(world)] if rank == 0 else None
+        dist.gather(host, gather_list=got, dst=0, group=group)
+        if rank == 0:
+            gathered[: world * n].copy_(torch.cat(got))
+        return _DoneWork() if async_op else None
     chunks = [gathered[r * n:(r + 1) * n] for r in range(world)] if rank == 0 else None
     work = dist.gather(local.reshape(-1), gather_list=chunks, dst=0, group=group, async_op=async_op)
     return work if async_op else None
+
+
+class _DoneWork:
+    """work handle of a collective that had already completed when it was handed out"""
+
+    def wait(self):
+        return True
 
 
 def unshard(gathered, counts: List[int], stride: int, n_pairs: int, out=None, session=None):

@@ -16,7 +16,9 @@ from pathlib import Path
 import numpy as np
 
 _DIR = Path(__file__).resolve().parent
-_SO = _DIR / "liblocohd_oracle.so"
+# LCHD_ASAN=1: the AddressSanitizer / UBSan build of the checker (make -C oracle asan; README "Sanitizer run")
+_ASAN = bool(os.environ.get("LCHD_ASAN"))
+_SO = _DIR / ("asan/liblocohd_oracle.so" if _ASAN else "liblocohd_oracle.so")
 
 WF_KINDS = {"hyper_exp": 0, "dagum": 1, "uniform": 2, "kumaraswamy": 3}
 SD_KINDS = {"Hellinger": 0, "Kolmogorov-Smirnov": 1, "Kullback-Leibler": 2, "Renyi": 3}
@@ -29,7 +31,7 @@ class OraclePanic(RuntimeError):
 def build(force: bool = False) -> Path:
     src = _DIR / "locohd_oracle.c"
     if force or not _SO.exists() or _SO.stat().st_mtime < src.stat().st_mtime:
-        subprocess.check_call(["make", "-C", str(_DIR), "-B", "liblocohd_oracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", str(_DIR), "-B", "asan" if _ASAN else "liblocohd_oracle.so"], stdout=subprocess.DEVNULL)
     return _SO
 
 

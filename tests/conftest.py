@@ -10,6 +10,29 @@ if str(ROOT) not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    _use_sanitizer_builds()
+
+
+def _use_sanitizer_builds():
+    """LCHD_ASAN=1 (README "Sanitizer run"; CPU tests only): the AddressSanitizer + UBSan build of the CPython helper takes the place of
+    loco_hd_amd._fastpack BEFORE the package is imported (oracle/oracle.py picks its own sanitizer build from the same variable).  The
+    interpreter itself is not instrumented, so the run needs LD_PRELOAD=$(gcc -print-file-name=libasan.so)."""
+    import importlib.util
+    import os
+    import subprocess
+
+    if not os.environ.get("LCHD_ASAN"):
+        return
+    csrc = ROOT / "loco_hd_amd" / "csrc"
+    subprocess.check_call(["make", "-C", str(csrc), "asan"], stdout=subprocess.DEVNULL)
+    so = next((csrc / "asan").glob("_fastpack*.so"))
+    spec = importlib.util.spec_from_file_location("loco_hd_amd._fastpack", so)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    sys.modules["loco_hd_amd._fastpack"] = mod
+    import loco_hd_amd.api as api
+
+    assert api._fastpack is mod, "the sanitizer build of _fastpack did not replace the regular one"
 
 
 def pytest_sessionstart(session):

@@ -51,15 +51,51 @@ def test_roofline_block_arithmetic(tmp_path, monkeypatch):
     blk = bench.roofline_block("no_such_workload", "k_sweep", 9.6e9, 1.6)
     assert blk["bound"] == "valu" and blk["unit"] == "GB/s" and blk["peak"] == bench.HBM_PEAK_GBS
     assert blk["achieved"] == pytest.approx(9.6e9 / 1.6e-3 / 1e9) and blk["frac"] == pytest.approx(blk["achieved"] / blk["peak"])
-    assert blk["traffic"] is None and "hbm_measured_frac" not in blk and "frac_step" not in blk
+    assert blk["traffic"] is None and "fabric_measured_frac" not in blk and "frac_step" not in blk
     blk = bench.roofline_block("no_such_workload", "k_sweep", 9.6e9, 1.6, launches_per_step=2, step_ms=4.0)
     assert blk["frac_step"] == pytest.approx(2 * 9.6e9 / 4.0e-3 / 8e12)
     # with a committed profile of the workload: measured traffic and the issue utilisation travel with the line
-    prof = {"kernel": "k_sweep<12, 0, 0, true, false, false, true>", "traffic_bytes_per_launch": 2.7e9, "valu_issue_frac": 0.9, "binding": "valu issue"}
+    prof = {"kernel": "k_sweep<12, 0, 0, true, false, false, true>", "traffic_bytes_per_launch": 2.7e9, "valu_issue_frac": 0.9, "binding": "valu issue",
+            "avg_launch_ns_kernel_trace": 1.5e6}
     monkeypatch.setattr(bench, "profile_numbers", lambda w: prof)
     blk = bench.roofline_block("c2a", "k_sweep (its launch and the k_pair_meta record pass in front of it)", 9.6e9, 1.6)
-    assert blk["traffic"] == 2.7e9 and blk["hbm_measured_frac"] == pytest.approx(2.7e9 / 1.6e-3 / 8e12)
+    assert blk["traffic"] == 2.7e9 and blk["fabric_measured_frac"] == pytest.approx(2.7e9 / 1.5e-3 / 8e12)  # the PROFILED time, not the live 1.6 ms
     assert blk["valu_issue_frac"] == 0.9 and blk["binding"] == "valu issue"
     # a profile of another kernel family is not attached
     blk = bench.roofline_block("c2b", "k_env_rows2 (both structures' rows in one launch)", 5.6e9, 2.3)
     assert blk["traffic"] is None
+
+
+def _run_bench(extra_env, *argv, timeout=180):
+    import os
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(extra_env)
+    return subprocess.run([sys.executable, str(ROOT / "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_gpus_2_without_a_launcher_starts_its_own_ranks():
+    """`python3 bench.py --gpus N` -- the form the driver uses for N = 1 -- must not die for N > 1 (round 5: rc 1, "launch with
+    torch.distributed.run"): it starts N ranks as a child process.  Here the ranks only meet (gloo) and report."""
+    import json
+
+    p = _run_bench({"LCHD_BENCH_RENDEZVOUS_ONLY": "1"}, "--gpus", "2", "--steps", "1", "--warmup", "0")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "rank 0 of 2 up" in p.stderr and "rank 1 of 2 up" in p.stderr, p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])  # rank 0's line is the last line of stdout, relayed by the parent
+    assert line == {"rendezvous": "ok", "world": 2, "rank_sum": 1.0, "gpus": 2}
+
+
+def test_bench_gpus_2_on_a_machine_with_fewer_gpus_fails_loudly_and_quickly():
+    """Exactly the driver's command.  Without two GPUs (this container: none; a one-GPU box: one) every rank comes up, the rank
+    without a device says so, the launcher takes the others down, and the exit code is not 0 -- no hang."""
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible: the command would run the real benchmark")
+    p = _run_bench({}, "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline")
+    assert p.returncode != 0
+    assert "rank 0 of 2 up" in p.stderr and "rank 1 of 2 up" in p.stderr, p.stderr[-2000:]
+    assert "needs 2 visible devices" in p.stderr, p.stderr[-2000:]
+    assert "{\"metric\"" not in p.stdout

@@ -180,3 +180,45 @@ def test_bench_strong_scaling_line_under_a_forced_process_group(workload, extra)
     assert 0 < line["roofline"]["frac"] < 1.5
     if workload != "c3":
         assert line["config"]["plan_cache"] is True and line["config"]["plan_ms"] > 0
+
+
+def _bench_without_launcher(extra_env, *argv, timeout=900):
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "LCHD_BENCH_FORCE_DIST")}
+    env.update(extra_env)
+    return subprocess.run([sys.executable, str(root / "bench.py"), *argv], cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("workload,extra", [("c2a", ["--pairs", "200000"]), ("c3", [])])
+def test_bench_with_two_real_ranks_started_by_bench_itself(workload, extra):
+    """`python3 bench.py --gpus 2` -- the driver's command form, no launcher -- with TWO real ranks on this box's one GPU
+    (LCHD_BENCH_SHARE_GPU: gloo + host-staged gather instead of RCCL, which refuses two ranks on one device): the ranks start, both
+    partition the one list with the library's kernels, score their shares, rank 0 gathers, restores anchor-pair order and bench.py
+    asserts the result equals a single pass over the whole list (src/locohd.rs:545-557).  Everything of an N-rank run but the
+    RCCL transport."""
+    import json
+
+    run = _bench_without_launcher({"LCHD_BENCH_SHARE_GPU": "1"}, "--gpus", "2", "--workload", workload, "--steps", "2", "--warmup", "1",
+                                  "--no-cpu-baseline", *extra)
+    assert run.returncode == 0, run.stderr[-3000:]
+    assert "rank 0 of 2 up" in run.stderr and "rank 1 of 2 up" in run.stderr
+    line = json.loads(run.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0 and "rehearsal" in line
+    assert "gather" in line["config"]["collective"]
+    if workload == "c2a":
+        assert 0.3 * 200000 < line["config"]["pairs_this_rank"] < 0.7 * 200000  # rank 0 scored its share, not the list
+
+
+def test_bench_gpus_2_on_one_gpu_fails_loudly():
+    """The driver's exact command on a box with fewer GPUs than ranks: a clear message and a non-zero exit code, no hang."""
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible: the command would run the real benchmark")
+    run = _bench_without_launcher({}, "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", timeout=300)
+    assert run.returncode != 0
+    assert "needs 2 visible devices" in run.stderr, run.stderr[-2000:]

@@ -47,13 +47,10 @@ def test_random_configuration(oracle, seed, monkeypatch):
     # the previous pass's pair statistics afterwards) instead of the one-launch sweep of small calls; read when the context is created
     if seed % 2:
         monkeypatch.setenv("LCHD_NO_INLINE_META", "1")
-    # seeds 3 mod 4: side B without de-duplication (one environment slot per pair); seeds 5 mod 8: environments built, sorted and
-    # swept inside one kernel where the configuration allows it (Hellinger-2, unit weights, one weight function) -- both forced
-    # onto whatever the seed draws (any choice is correct for any input)
+    # seeds 3 mod 4: side B without de-duplication (one environment slot per pair), forced onto whatever the seed draws (any choice
+    # is correct for any input)
     if seed % 4 == 3:
         monkeypatch.setenv("LCHD_PER_PAIR", "1")
-    if seed % 8 == 5:
-        monkeypatch.setenv("LCHD_FUSED", "1" if seed % 16 == 5 else "3")
 
     rng = np.random.default_rng(1000 + seed)
     ncat = int(rng.choice([2, 3, 5, 7, 10, 13, 20, 25, 31, 40]))

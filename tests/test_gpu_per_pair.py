@@ -1,12 +1,10 @@
 """Side-B environments that are used ONCE (the frames of a trajectory, (i, i) lists, a rank's partners under strong scaling).  The
 reference builds and consumes an environment inside one closure per pair and side (/root/reference/src/locohd.rs:514-554); here
 
-  * the regular pipeline skips the de-duplication of such a side: environment slot p belongs to pair p (picked by the library when the
-    previous regular pass found (almost) every side-B anchor unique; LCHD_PER_PAIR=1 / -1 force it on / off), and
-  * k_env_sweep (loco_hd_amd/csrc/lchd_env_fused.hip, opt-in: LCHD_FUSED=1 four pairs of at most 240 merged events per wavefront,
-    LCHD_FUSED=3 two 8-bit-count pairs of at most 480) builds, sorts and sweeps them inside ONE kernel.
-
-Both are forced onto inputs the CPU oracle can follow."""
+the pipeline skips the de-duplication of such a side: environment slot p belongs to pair p (picked by the library when the previous
+regular pass found (almost) every side-B anchor unique; LCHD_PER_PAIR=1 / -1 force it on / off).  Forced here onto inputs the CPU
+oracle can follow.  (Round 5's k_env_sweep -- environment build + sweep in one kernel -- measured 12 % slower than the two kernels
+and left the tree in round 6)"""
 import numpy as np
 import pytest
 
@@ -29,17 +27,15 @@ def _cloud(rng, n, side, n_cat, n_tags=0):
     return xyz, cat, tag
 
 
-def _run(lh, monkeypatch, hook, build, xa, ca, ta, xb, cb, tb, pairs, thr, repeat=2, per_pair=None):
+def _run(lh, monkeypatch, build, xa, ca, ta, xb, cb, tb, pairs, thr, repeat=2, per_pair=None):
     import torch
     from loco_hd_amd.device import DeviceSession
 
-    for name, val in (("LCHD_FUSED", hook), ("LCHD_PER_PAIR", per_pair)):
-        if val is None:
-            monkeypatch.delenv(name, raising=False)
-        else:
-            monkeypatch.setenv(name, val)
-    sess = DeviceSession(build(lh))
-    monkeypatch.delenv("LCHD_FUSED", raising=False)
+    if per_pair is None:
+        monkeypatch.delenv("LCHD_PER_PAIR", raising=False)
+    else:
+        monkeypatch.setenv("LCHD_PER_PAIR", per_pair)
+    sess = DeviceSession(build(lh))  # (the hooks are read when the context is created)
     monkeypatch.delenv("LCHD_PER_PAIR", raising=False)
     a, b = sess.upload(xa, ca, ta), sess.upload(xb, cb, tb)
     anchors = torch.from_numpy(np.ascontiguousarray(pairs, dtype=np.int64)).cuda()
@@ -53,10 +49,9 @@ def _run(lh, monkeypatch, hook, build, xa, ca, ta, xb, cb, tb, pairs, thr, repea
 
 
 @pytest.mark.parametrize("n_cat", [5, 12, 16, 20, 28])
-@pytest.mark.parametrize("hook", ["1", "3"])
-def test_forced_fused_pass_matches_the_oracle_and_the_regular_pipeline(lh, oracle, monkeypatch, n_cat, hook):
+def test_forced_per_pair_side_b_matches_the_oracle_and_the_regular_pipeline(lh, oracle, monkeypatch, n_cat):
     """(i, i) pairs + random pairs (side-B anchors that occur several times are built once per pair), protein-like density: pairs of
-    ~150 ... 350 merged events, so under the 240-event rule a good part of them is left to the INDIRECT sweep behind the kernel."""
+    ~150 ... 350 merged events."""
     rng = np.random.default_rng(100 + n_cat)
     cats = [f"c{i}" for i in range(n_cat)]
     n = 2400
@@ -68,25 +63,20 @@ def test_forced_fused_pass_matches_the_oracle_and_the_regular_pipeline(lh, oracl
                             np.stack([rng.integers(0, n, 302), np.full(302, 5)], 1)])  # one side-B anchor in 302 pairs; 5625 pairs: not a multiple of 4
     build = lambda mod: mod.LoCoHD(cats, mod.WeightFunction("hyper_exp", [1.0, 0.1]))
     want = np.asarray(build(oracle).from_arrays(xa, ca, ta, xb, cb, tb, pairs, 9.0))
-    got, counts = _run(lh, monkeypatch, hook, build, xa, ca, ta, xb, cb, tb, pairs, 9.0)
-    assert counts["fused_passes"] == 2 and counts["passes"] == 2
-    for g in got:
-        assert np.max(np.abs(g - want)) < TIGHT
-        assert np.array_equal(g, got[0])
-    regular, rc = _run(lh, monkeypatch, None, build, xa, ca, ta, xb, cb, tb, pairs, 9.0, repeat=3, per_pair="-1")
-    assert rc["fused_passes"] == 0 and rc["per_pair_passes"] == 0
-    assert np.max(np.abs(regular[-1] - got[0])) < 1e-13
-    if hook == "1":  # the regular pipeline without side B's de-duplication: the same environments, the same sweeps -- the same bits
-        forced, fc = _run(lh, monkeypatch, None, build, xa, ca, ta, xb, cb, tb, pairs, 9.0, repeat=3, per_pair="1")
-        assert fc["per_pair_passes"] == 3 and fc["fused_passes"] == 0
-        for f, r in zip(forced, regular):
-            assert np.array_equal(f, r)
+    regular, rc = _run(lh, monkeypatch, build, xa, ca, ta, xb, cb, tb, pairs, 9.0, repeat=3, per_pair="-1")
+    assert rc["per_pair_passes"] == 0 and rc["passes"] == 3
+    # without side B's de-duplication: the same environments, the same sweeps -- the same bits
+    forced, fc = _run(lh, monkeypatch, build, xa, ca, ta, xb, cb, tb, pairs, 9.0, repeat=3, per_pair="1")
+    assert fc["per_pair_passes"] == 3 and fc["passes"] == 3
+    for f, r in zip(forced, regular):
+        assert np.max(np.abs(f - want)) < TIGHT
+        assert np.array_equal(f, r)
 
 
 @pytest.mark.parametrize("rule", [{"accept_same": False}, {"accept_same": True},
                                   {"tag_pairs": [(0, 1), (2, 2), (5, 3), (7, 7), (1, 6)], "accepted_pairs": True, "ordered": False},
                                   {"tag_pairs": [(0, 1), (2, 2), (5, 3)], "accepted_pairs": False, "ordered": True}])
-def test_forced_fused_pass_with_tag_rules_and_weight_functions(lh, oracle, monkeypatch, rule):
+def test_forced_per_pair_side_b_with_tag_rules_and_weight_functions(lh, oracle, monkeypatch, rule):
     """Both tag-rule instantiations, coarse-grained density (~90 points per environment: four pairs per wavefront), every weight-function
     family as the single function of the configuration."""
     rng = np.random.default_rng(7)
@@ -109,22 +99,22 @@ def test_forced_fused_pass_with_tag_rules_and_weight_functions(lh, oracle, monke
             import loco_hd_amd.api as api  # noqa: F401  (string tags travel through the list-of-PrimitiveAtom call)
             pa = lambda mod, x, c, t: [mod.PrimitiveAtom(cats[k], str(tt), xyz) for k, tt, xyz in zip(c, t, x)]
             want = np.asarray(build(oracle).from_primitives(pa(oracle, xa, ca, ta), pa(oracle, xb, cb, tb), [tuple(map(int, p)) for p in pairs], 10.0))
-            monkeypatch.setenv("LCHD_FUSED", "1")
+            monkeypatch.setenv("LCHD_PER_PAIR", "1")
             lchd = build(lh)
             got = np.asarray(lchd.from_primitives(pa(lh, xa, ca, ta), pa(lh, xb, cb, tb), [tuple(map(int, p)) for p in pairs], 10.0))
-            monkeypatch.delenv("LCHD_FUSED")
+            monkeypatch.delenv("LCHD_PER_PAIR")
             assert np.max(np.abs(got - want)) < TIGHT, wf
         else:
             want = np.asarray(build(oracle).from_arrays(xa, ca, ta, xb, cb, tb, pairs, 10.0))
-            got, counts = _run(lh, monkeypatch, "1", build, xa, ca, ta, xb, cb, tb, pairs, 10.0, repeat=1)
-            assert counts["fused_passes"] == 1
+            got, counts = _run(lh, monkeypatch, build, xa, ca, ta, xb, cb, tb, pairs, 10.0, repeat=1, per_pair="1")
+            assert counts["per_pair_passes"] == 1
             assert np.max(np.abs(got[0] - want)) < TIGHT, wf
 
 
 def test_side_b_is_not_deduplicated_when_its_anchors_are_used_once(lh, oracle, monkeypatch):
     """No hook: the first call of a session is a regular pass with de-duplication (it counts the unique anchors); with every side-B
     anchor unique the next calls give every pair its own side-B slot -- the same bits --, a list whose side-B anchors are shared is
-    still scored correctly in that mode, and the forced fused kernel gives the same bits again (one tile function, the same lists)."""
+    still scored correctly in that mode."""
     rng = np.random.default_rng(11)
     n_cat = 8
     cats = [f"c{i}" for i in range(n_cat)]
@@ -141,19 +131,19 @@ def test_side_b_is_not_deduplicated_when_its_anchors_are_used_once(lh, oracle, m
     import torch
     from loco_hd_amd.device import DeviceSession
 
-    monkeypatch.delenv("LCHD_FUSED", raising=False)
+    monkeypatch.delenv("LCHD_PER_PAIR", raising=False)
     sess = DeviceSession(build(lh))
     a, b = sess.upload(xa, ca, ta), sess.upload(xb, cb, tb)
     d_once, d_shared = torch.from_numpy(once).cuda(), torch.from_numpy(shared).cuda()
     first = sess.from_primitives(a, b, d_once, 10.0).cpu().numpy()
     assert sess.pass_counts()["per_pair_passes"] == 0
     later = [sess.from_primitives(a, b, d_once, 10.0).cpu().numpy() for _ in range(3)]
-    assert sess.pass_counts()["per_pair_passes"] == 3 and sess.pass_counts()["fused_passes"] == 0
+    assert sess.pass_counts()["per_pair_passes"] == 3
     for g in later:
         assert np.array_equal(g, first)
         assert np.max(np.abs(g - want_once)) < TIGHT
-    # shared side-B anchors: the fused pass that meets them is still correct; the periodic regular pass would switch it off -- here the
-    # caller's next REGULAR pass does (a new session state is forced by a call that cannot be fused: a small one)
+    # shared side-B anchors: the per-pair pass that meets them is still correct; the periodic regular pass would switch it off -- here the
+    # caller's next REGULAR pass does (the pass's scoreboard counted the repeats)
     before = sess.pass_counts()["per_pair_passes"]
     assert np.max(np.abs(sess.from_primitives(a, b, d_shared, 10.0).cpu().numpy() - want_shared)) < TIGHT
     assert sess.pass_counts()["per_pair_passes"] == before + 1  # (a list like the hinted one: one pass per pair -- whose scoreboard counts the repeats)
@@ -168,14 +158,11 @@ def test_side_b_is_not_deduplicated_when_its_anchors_are_used_once(lh, oracle, m
     assert sess.pass_counts()["per_pair_passes"] == n_pp
     assert np.max(np.abs(got_many[:n] - want_once)) < TIGHT and np.max(np.abs(got_many[n:2 * n] - want_shared)) < TIGHT
     sess.close()
-    fused, fc = _run(lh, monkeypatch, "1", build, xa, ca, ta, xb, cb, tb, once, 10.0, repeat=2)
-    assert fc["fused_passes"] == 2
-    assert np.array_equal(fused[0], first) and np.array_equal(fused[1], first)
 
 
-def test_fused_pass_errors_and_fallbacks(lh, oracle, monkeypatch):
-    """An anchor outside its structure raises like the reference's index panic; an environment beyond the group buffer (a dense cluster)
-    sends the call to the regular pipeline (second pass over the overflowed pairs included); categories outside the map raise."""
+def test_per_pair_side_b_errors_and_fallbacks(lh, oracle, monkeypatch):
+    """An anchor outside its structure raises like the reference's index panic; an environment beyond its slot (a dense cluster) repeats
+    the pass with larger slots; categories outside the map raise."""
     import torch
     from loco_hd_amd.device import DeviceSession
 
@@ -191,12 +178,12 @@ def test_fused_pass_errors_and_fallbacks(lh, oracle, monkeypatch):
     pairs = np.stack([rng.permutation(n), rng.permutation(n)], 1)
     build = lambda mod: mod.LoCoHD(cats, mod.WeightFunction("hyper_exp", [1.0, 0.15]))
     want = np.asarray(build(oracle).from_arrays(xa, ca, np.zeros_like(ta), xb, cb, np.zeros_like(tb), pairs, 8.0))
-    got, counts = _run(lh, monkeypatch, "1", build, xa, ca, np.zeros_like(ta), xb, cb, np.zeros_like(tb), pairs, 8.0)
+    got, counts = _run(lh, monkeypatch, build, xa, ca, np.zeros_like(ta), xb, cb, np.zeros_like(tb), pairs, 8.0, per_pair="1")
     assert np.max(np.abs(got[0] - want)) < TIGHT and np.array_equal(got[0], got[1])
-    assert counts["fused_passes"] >= 1 and counts["passes"] > counts["fused_passes"]  # fused attempt, then the regular pipeline
-    monkeypatch.setenv("LCHD_FUSED", "1")
+    assert counts["passes"] > 2  # the overflow repeated a pass
+    monkeypatch.setenv("LCHD_PER_PAIR", "1")
     sess = DeviceSession(build(lh))
-    monkeypatch.delenv("LCHD_FUSED")
+    monkeypatch.delenv("LCHD_PER_PAIR")
     a, b = sess.upload(xa[1000:], ca[1000:], np.zeros(n - 1000, np.int32)), sess.upload(xb[1000:], cb[1000:], np.zeros(n - 1000, np.int32))
     bad = np.stack([np.arange(4000), np.arange(4000)], 1)
     bad[3999, 1] = 4000
