@@ -192,6 +192,9 @@ struct lchd_ctx {
     double* d_powtab = nullptr;  // k^(1/e) | k^(-1/e) for the configured Hellinger exponent (allocated when one is first configured)
     double powtab_e = 0.0;       // the exponent the table holds
     DoneState* d_done = nullptr;     // 'last workgroup' counters / accumulators of k_pair_meta (zero between kernels)
+    uint32_t* d_left = nullptr;      // two counter slots of the leftover list (SweepArgs::left_count / left_zero), 128 B apart
+    int left_slot = 0;               // the slot the next record pass appends to (zero by then: the previous one zeroed it)
+    int64_t last_left = 0;           // pairs the last pass left to the INDIRECT companion
     // host-pointer calls: one grow-only device block + pinned staging block per context (no allocation in the steady state)
     char *d_io = nullptr, *h_io = nullptr;
     size_t io_cap = 0;
@@ -367,6 +370,8 @@ extern "C" int lchd_ctx_create(int32_t device, lchd_ctx** out) {
     // (+ one cache line behind it: k_dense_fused's row counter, zero between launches -- k_dense_publish resets it)
     if ((e = hipMalloc(&c->d_done, sizeof(DoneState) + 128)) != hipSuccess) return bail(e, "hipMalloc(done)");
     if ((e = hipMemset(c->d_done, 0, sizeof(DoneState) + 128)) != hipSuccess) return bail(e, "hipMemset(done)");
+    if ((e = hipMalloc(&c->d_left, 256)) != hipSuccess) return bail(e, "hipMalloc(leftover counters)");
+    if ((e = hipMemset(c->d_left, 0, 256)) != hipSuccess) return bail(e, "hipMemset(leftover counters)");
     init_device_kernels();  // per device, not per process
     init_dense_fused_kernels();
     launch_fill_sqrt_tables(c->stream, c->d_tabs, c->d_tabs + 65536);
@@ -390,6 +395,7 @@ extern "C" void lchd_ctx_destroy(lchd_ctx* c) {
     (void)hipFree(c->d_powtab);
     (void)hipFree(c->d_wide_scratch);
     (void)hipFree(c->d_done);
+    (void)hipFree(c->d_left);
     (void)hipFree(c->d_io);
     (void)hipFree(c->d_ovf_bits);
     (void)hipFree(c->d_ovf_lists);
@@ -787,6 +793,7 @@ static int begin_pass(lchd_ctx* c) {
     if (c->status_dirty) {
         HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(DeviceStatus), c->stream));
         HIP_TRY(hipMemsetAsync(c->d_done, 0, sizeof(DoneState), c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_left, 0, 256, c->stream));
         c->status_dirty = false;
     }
     HostStatus* h = c->h_status;
@@ -888,6 +895,7 @@ struct SideBufs {
 struct PassBufs {
     SideBufs a, b;
     int4* pair_meta;
+    uint32_t* left_list;  // pairs the team kernel's rule leaves over (SweepArgs::left_list)
     char* zero_base;
     size_t zero_bytes;
 };
@@ -933,6 +941,7 @@ static void carve_pass(Arena& ar, int64_t n_a, int cells_a, int64_t envs_a, int6
         b.ovf_list = cap <= 16384 ? ar.take<uint32_t>(ne) : nullptr;
     }
     pb.pair_meta = ar.take<int4>((size_t)n_pairs);
+    pb.left_list = ar.take<uint32_t>((size_t)n_pairs);
 }
 
 static int next_pow2_host(int64_t n) {
@@ -1113,7 +1122,14 @@ static int prims_enqueue(lchd_ctx* c) {
     sw.n_pairs = n_pairs;
     sw.out = P.out;
     sw.meta = pb.pair_meta;
+    if (!c->deterministic) {  // (deterministic mode: no team kernels, no companion)
+        sw.left_list = pb.left_list;
+        sw.left_count = c->d_left + 32 * c->left_slot;
+        sw.left_zero = c->d_left + 32 * (c->left_slot ^ 1);
+        sw.left_expected = P.subset ? n_pairs : c->last_left;
+    }
     P.sweep_info = launch_sweep(s, c->tune, c->h_cfg.n_categories, c->hellinger2, c->unit_weights, c->wf_pow, c->sweep_hint, sw);
+    if (P.sweep_info & 4) c->left_slot ^= 1;  // (the record pass ran and zeroed the other slot)
     mark(c, 4);
     if (a->ev_used) { HIP_TRY(hipEventRecord(a->ev_used, s)); a->used_valid = true; }
     if (b->ev_used) { HIP_TRY(hipEventRecord(b->ev_used, s)); b->used_valid = true; }
@@ -1320,6 +1336,8 @@ static int finish_passes(lchd_ctx* c, uint32_t* flags_out) {
                 c->per_pair_streak = 0;
             }
         }
+        if (c->h_status->n_small != ~0ull && !P.subset)  // (sizes the next pass's companion launch when it walks the leftover list)
+            c->last_left = P.n_pairs - (int64_t)std::min<unsigned long long>((P.sweep_info & 1) ? c->h_status->n_c8 : c->h_status->n_duo, (unsigned long long)P.n_pairs);
         if (c->h_status->n_small != ~0ull)  // what the pairs looked like this time picks the sweep kernels of the next pass of this configuration
             c->sweep_hint = 4 | (2 * c->h_status->n_duo >= (unsigned long long)P.n_pairs ? 1 : 0) |
                             (2 * c->h_status->n_c8 >= (unsigned long long)P.n_pairs ? 2 : 0) |

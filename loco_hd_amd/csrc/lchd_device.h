@@ -327,6 +327,15 @@ struct SweepArgs {
     int32_t gen_tab;          // set by launch_sweep: MODE_GEN may use power tables (Hellinger with a general exponent, unit category weights)
     int32_t forced;           // set by launch_sweep: the host picked the sweep kernels (hint from the previous pass): no device-side decision
     int32_t sd_fast;          // the configuration qualifies for k_sweep_inc (lchd_sweep_inc.hip): 0 no, 1 Kullback-Leibler form, 2 Renyi form
+    // Leftover list (round 6): in a pass whose sweep kernels the host picked (forced: the rule is known at launch) k_pair_meta appends
+    // the pairs the team kernel's rule leaves over to left_list (wave-aggregated, a handful of atomics per launch) and the INDIRECT
+    // companion walks that list instead of scanning every pair record for them (C2a: 223 of 10^6 pairs; 16.6 -> ~3 us per pass).
+    // Two counter slots take turns: the pass that appends to one zeroes the other for the next pass -- no memset, no reset kernel.
+    uint32_t* left_list;      // [P] workspace (nullptr: no list, the companion scans the records)
+    uint32_t* left_count;     // this pass's counter slot (zero when the pass starts)
+    uint32_t* left_zero;      // the other slot: zeroed by k_pair_meta of this pass
+    int32_t left_listing;     // set by launch_sweep: k_pair_meta appends and the companion reads the list
+    int64_t left_expected;    // pairs the previous pass of the context left over (sizes the companion's grid; any grid is correct)
 };
 // sweep_hint: 0 = unknown (launch every candidate kernel, the device decides from the pair records); otherwise what
 // k_pair_meta counted in the previous pass of this configuration: 4 | 1 (pairs of at most 240 merged events were the
@@ -334,7 +343,8 @@ struct SweepArgs {
 // + the indirect one); neither: the plain k_sweep only.  Any choice is correct for any input; the hint only picks the launch set.
 // ... | 8 (every pair of the previous pass had at most 240 events) | 16 (... both environments <= 255 points): the companion
 // launch for the larger pairs is left out.  Returns 1 (the "small" rule of this pass was the 8-bit-count one) | 2 (the companion
-// launch was left out: the caller must check this pass's counts, HostStatus::n_duo / n_c8 against the number of pairs).
+// launch was left out: the caller must check this pass's counts, HostStatus::n_duo / n_c8 against the number of pairs) | 4 (k_pair_meta
+// ran with the leftover-list counters of `a`: the caller swaps the two counter slots for the next pass).
 int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinger2, bool unit_weights, bool wf_pow, int sweep_hint,
                  const SweepArgs& a);
 // Kullback-Leibler / Renyi in O(1) per event (lchd_sweep_inc.hip): unit weights, CDF-keyed environments of at most 512 points, tiny eps;

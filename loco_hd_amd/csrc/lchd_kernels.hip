@@ -73,7 +73,19 @@ __global__ void k_pair_meta(SweepArgs args) {
         // the host picks the next pass's kernels from them.
         n_duo += (nA + nB - 2 <= kDuoTileFwd) ? 1 : 0;
         n_c8 += pair_is_small(args.c8_rule, nA, nB) ? 1 : 0;
+        if (args.left_listing) {  // (uniform) the pairs the team kernel of this pass leaves to the INDIRECT companion: the test of its scan
+            const bool left = nA > 0 && !pair_is_small(args.small_rule, nA, nB);
+            const unsigned long long lm = __ballot(left);
+            if (lm) {  // (rare: a few hundred pairs of a million)
+                const int lane = threadIdx.x & 63, leader = __ffsll((long long)lm) - 1;
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd(args.left_count, (uint32_t)__popcll(lm));
+                base = (uint32_t)__shfl((int)base, leader);
+                if (left) args.left_list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u))] = (uint32_t)p;
+            }
+        }
     }
+    if (args.left_zero && blockIdx.x == 0 && threadIdx.x == 0) *args.left_zero = 0u;  // the next pass's counter slot
     // pairs that fit one 32-lane tile: if they are the majority, k_sweep_duo sweeps them and k_sweep only the rest.  One
     // partial count per workgroup; the workgroup that finishes LAST folds them, publishes what the host wants to know into
     // the host-mapped mirror and resets the device status for the next pass -- no separate summing kernel, no memset before
@@ -161,7 +173,10 @@ int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinge
     // launch for the larger pairs would find nothing to do and is left out; the host checks the counts of THIS pass afterwards
     // and repeats it with the full launch set if a larger pair turned up after all (the returned bit 2 says the launch was left out)
     const bool no_others = hint == 1 && (hint_bits & (use_c8 ? 16 : 8)) != 0;
-    const int info = (use_c8 ? 1 : 0) | (no_others ? 2 : 0);
+    // the leftover list: only where the rule is known at launch and a companion will read it (otherwise the device decides the rule
+    // from this very record pass and the companion scans the records)
+    a.left_listing = (a.left_list && a.left_count && !wide && (use_duo || use_c8) && hint == 1 && !no_others) ? 1 : 0;
+    const int info = (use_c8 ? 1 : 0) | (no_others ? 2 : 0) | (a.left_zero ? 4 : 0);
     {
         const int64_t nb = (a.n_pairs + 255) / 256;
         const int mgrid = (int)(nb < kMetaPartials ? nb : kMetaPartials);
@@ -170,7 +185,7 @@ int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinge
     if (wide) {
         const int fm = (a.env_a.cdf_keys && a.env_b.cdf_keys) ? F_KEY : F_ANY;
         launch_sweep_wide(s, !hellinger2 ? MODE_GEN : (unit_weights ? MODE_H2U : MODE_H2W), n_categories, a.n_pairs, fm, a);
-        return 0;
+        return info & 4;
     }
     if (use_duo || use_c8) {
         // Without a hint the small-pair kernel, its companion and the plain sweep are all launched and the number of small
@@ -179,7 +194,11 @@ int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinge
         a.forced = hint != 0;
         if (hint != 2) {
             a.duo_enabled = 1;
-            const unsigned bgrid = grid < LCHD_COMPANION_GRID ? grid : LCHD_COMPANION_GRID;  // the listed (larger) pairs are a minority whenever this launch does anything
+            unsigned bgrid = grid < LCHD_COMPANION_GRID ? grid : LCHD_COMPANION_GRID;  // the listed (larger) pairs are a minority whenever this launch does anything
+            if (a.left_listing) {  // one wavefront per listed pair, sized from what the previous pass left over (a grid-stride loop: any grid is correct)
+                const int64_t want = (a.left_expected + a.left_expected / 4 + kSweepWaves - 1) / kSweepWaves + 8;
+                bgrid = (unsigned)std::min<int64_t>(bgrid, std::max<int64_t>(want, 16));
+            }
             // (team mode: 0 Hellinger-2 with unit weights, 1 with category weights, 2 Kolmogorov-Smirnov with unit weights)
             const int tm = ks_team ? 2 : (unit_weights ? 0 : 1);
             if (use_duo) {
@@ -212,7 +231,7 @@ int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinge
     } else {
         launch_sweep_plain(s, unit_weights ? MODE_H2U : MODE_H2W, small, cmax, grid, fmode, a);
     }
-    return info & 1;
+    return info & 5;
 }
 
 // Kernels that may be launched with more than 64 KB of dynamic LDS need the limit raised per DEVICE: lchd_ctx_create calls this

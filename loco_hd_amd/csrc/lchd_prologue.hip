@@ -471,7 +471,10 @@ __global__ void k_pair_anchor_recs(const int64_t* __restrict__ anchors, int64_t 
     uint32_t dup = 0;
     for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n_pairs; p += (int64_t)gridDim.x * blockDim.x) {
         int64_t i = anchors[2 * p + 1];
-        if (i < 0 || i >= c.n) i = 0;  // (flagged by k_prep_count; the pair record marks the pair unusable)
+        if (i < 0 || i >= c.n) {  // src/locohd.rs:521: the reference's index panic (the pair record marks the pair unusable)
+            atomicOr(&st->flags, ST_BAD_ANCHOR);  // (the one-workgroup prologue does not look at this side's anchors in this mode)
+            i = 0;
+        }
         // how many pairs share their side-B anchor with an earlier one?  The side's flag region (zeroed by the prologue, otherwise unused
         // in this mode) as a bit set, one returning atomic per pair: the count tells the host when this side has stopped being "used
         // once" (a pass per pair is then a waste).  (Plain loads and stores do not work: a small list's threads all load before any stores.)

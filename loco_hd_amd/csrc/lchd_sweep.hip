@@ -300,7 +300,18 @@ __global__ __launch_bounds__(64 * kSweepWaves, (sweep_waves_per_simd<CMAX, MODE,
     unsigned long long todo = 0;
     int4 mm = make_int4(0, 0, 0, 0);
     bool ok = true;
+    // (the leftover list of a forced pass, SweepArgs::left_listing: one listed pair per step instead of the scan below)
+    const uint32_t n_left = (INDIRECT && args.left_listing) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)*args.left_count) : 0u;
     auto advance = [&]() -> bool {
+        if (args.left_listing) {  // (uniform)
+            if (blk >= (int64_t)n_left) return false;
+            p_cur = (int64_t)args.left_list[blk];
+            blk += pstride;
+            const int4 m1 = args.meta[p_cur];
+            mx = __builtin_amdgcn_readfirstlane(m1.x); my = __builtin_amdgcn_readfirstlane(m1.y);
+            mz = __builtin_amdgcn_readfirstlane(m1.z); mw = __builtin_amdgcn_readfirstlane(m1.w);
+            return true;
+        }
         while (todo == 0) {
             if (blk * 64 >= total) return false;
             const int64_t pp = blk * 64 + lane;

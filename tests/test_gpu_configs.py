@@ -499,6 +499,49 @@ def test_two_pairs_per_wavefront_eight_bit_sweep_around_its_limits(lh, oracle, m
     assert np.max(np.abs(outs["team"] - outs["single"])) < 1e-13
 
 
+def test_leftover_list_of_hinted_passes_follows_a_changing_pair_list(lh, oracle, monkeypatch):
+    """From the second pass of a context on, the record pass LISTS the pairs the team kernel's rule leaves over and the INDIRECT companion
+    walks that list (sized from what the previous pass left) instead of scanning every record.  Lists whose leftovers grow from a
+    dozen to hundreds and shrink again, on one session: every call against the oracle, and bit for bit against a fresh
+    session's first (scanning) pass of the same list."""
+    import torch
+    from loco_hd_amd.device import DeviceSession
+
+    monkeypatch.setenv("LCHD_NO_INLINE_META", "1")
+    rng = np.random.default_rng(77)
+    n, ncat = 4000, 10
+    side = (n / 0.055) ** (1 / 3)
+    xa, xb = rng.uniform(0, side, (n, 3)), rng.uniform(0, side, (n, 3))
+    ca, cb = rng.integers(0, ncat, n).astype(np.int32), rng.integers(0, ncat, n).astype(np.int32)
+    cats = [f"c{i}" for i in range(ncat)]
+    tag = np.zeros(n, dtype=np.int32)
+    wf = ("hyper_exp", [1.0, 0.1])
+    ra, rb = np.linalg.norm(xa - side / 2, axis=1), np.linalg.norm(xb - side / 2, axis=1)
+    rim_a, rim_b = np.argsort(ra)[n // 3:], np.argsort(rb)[n // 3:]        # smaller environments: the team rule takes (almost) all
+    core_a, core_b = np.argsort(ra)[: n // 6], np.argsort(rb)[: n // 6]    # bulk-sized ones: many pairs beyond 480 merged events
+    def mix(n_rim, n_core):
+        return np.concatenate([np.stack([rng.choice(rim_a, n_rim), rng.choice(rim_b, n_rim)], 1),
+                               np.stack([rng.choice(core_a, n_core), rng.choice(core_b, n_core)], 1)]).astype(np.int64)
+    lists = [mix(9000, 20), mix(6000, 3000), mix(9000, 0), mix(7000, 1500), mix(9000, 5)]
+    lo = oracle.LoCoHD(cats, oracle.WeightFunction(*wf), n_of_threads=8)
+    sess = DeviceSession(lh.LoCoHD(cats, lh.WeightFunction(*wf)))
+    a, b = sess.upload(xa, ca), sess.upload(xb, cb)
+    left = []
+    for k, pairs in enumerate(lists):
+        want, sizes = lo.from_arrays(xa, ca, tag, xb, cb, tag, pairs, 10.0, return_env_sizes=True)
+        want, sizes = np.asarray(want), np.asarray(sizes)
+        left.append(int(np.sum(~((sizes.max(axis=1) <= 255) & (sizes.sum(axis=1) - 2 <= 480)))))
+        got = sess.from_primitives(a, b, torch.from_numpy(pairs).cuda(), 10.0).cpu().numpy()
+        assert np.max(np.abs(got - want)) < TIGHT, (k, left)
+        fresh = DeviceSession(lh.LoCoHD(cats, lh.WeightFunction(*wf)))
+        fa, fb = fresh.upload(xa, ca), fresh.upload(xb, cb)
+        first = fresh.from_primitives(fa, fb, torch.from_numpy(pairs).cuda(), 10.0).cpu().numpy()
+        fresh.close()
+        assert np.array_equal(got, first), (k, left)
+    sess.close()
+    assert left[1] > 10 * max(left[0], 1) and left[2] * 10 < left[1] and left[3] > 100, left  # the list did grow and shrink (15, 403, 12, 193, 15)
+
+
 def test_regular_batch_of_large_structures_uses_the_per_structure_cell_build(lh, oracle):
     """64 frames of an 11 000-atom structure: the one-workgroup-per-structure cell list at (almost) its LDS limit, against
     the oracle on a sample of frames and against the generic cell-list path."""
