@@ -1101,6 +1101,8 @@ static int prims_enqueue(lchd_ctx* c) {
     } else if (!launch_env_cells(s, cap, c->d_cfg, tag_list, esa, esb, thr, c->d_status))
         return fail(LCHD_EUNSUPPORTED, cat16 ? "with more than 255 categories an environment may hold at most 8192 points (capacity %d asked for)"
                                              : "no environment kernel variant with capacity %d", cap);
+    if (c->deterministic)  // one order among equal keys, whatever order the cell lists' and the buckets' atomics produced (utils.rs:25-39: a stable sort)
+        launch_env_canon(s, sa.env, same ? sa.env : sb.env, max_env_a, same ? 0 : max_env_b, c->d_status);
     if (dict_sets) {
         launch_env_key_sets(s, c->d_cfg, sa.env, sb.env, n_wf, max_env_a + max_env_b, c->d_status);
         for (SideBufs* sb_ : {&sa, &sb}) {  // the sweeps' view of the store: the F sets
@@ -2296,6 +2298,7 @@ static int dense_pass(lchd_ctx* c, const lchd_cloud& a, const lchd_cloud& b, con
             !launch_env_rows(s, cap_b, c->d_cfg, b.view(cat16), d_mb, cols_b, rows, cols_b, diag2(b), eb, c->d_status, exb))
             return fail(LCHD_EUNSUPPORTED, "no dense environment kernel for this row length");
     }
+    if (c->deterministic) launch_env_canon(s, ea, eb, rows, rows, nullptr);  // one order among equal keys (a row's sort places ties by LDS-atomic order)
     mark(c, 3);
     uint32_t f = 0;
     if (int rc2 = sweep_rows(c, ea, eb, d_wf, rows, d_out, d_meta, DRV_DMXS, &f)) return rc2;

@@ -398,6 +398,9 @@ struct OverflowSelect {
     int32_t* sel_wf;
 };
 void launch_env_key_sets(hipStream_t s, const DevConfig* cfg, const EnvStore& ea, const EnvStore& eb, int n_sets, int64_t max_envs, const DeviceStatus* st);
+// deterministic mode: the categories of every run of equal keys in ascending order (positions >= 1), one wavefront per environment;
+// st != nullptr: the environments in use are DeviceStatus::n_unique (n_a / n_b bound the launch), otherwise exactly n_a / n_b
+void launch_env_canon(hipStream_t s, const EnvStore& ea, const EnvStore& eb, int64_t n_a, int64_t n_b, const DeviceStatus* st);
 void launch_mark_overflow(hipStream_t s, const uint32_t* list_a, uint32_t na, const uint32_t* list_b, uint32_t nb, uint32_t* bits_a, uint32_t* bits_b);
 void launch_count_overflow(hipStream_t s, const OverflowSelect& a, unsigned long long* total);
 void launch_write_overflow(hipStream_t s, const OverflowSelect& a);

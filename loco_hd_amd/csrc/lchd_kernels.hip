@@ -137,7 +137,10 @@ int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinge
     // than that the table loads show, coarser the last round's imbalance does (measured on C2a: 4096 +2.8 %, 16384 +0.5 %)
     const int64_t gcap = 8192;
     // ... the team sweeps (shorter iterations, a smaller table load per workgroup): 16384 (C2a 1.3648 -> 1.358 ms, C3 0.7835 -> 0.7769; 32768: no further gain)
-    const int64_t tcap = 16384;
+    // ... but a launch of at most 32768 team workgroups' worth of pairs (a rank's 125 000-pair share of C2a under strong scaling) is cut into
+    // 4096: every workgroup then amortises its LDS table load over ~4 rounds (measured with --emulate-world 8, per-rank step median:
+    // 0.214 -> 0.200 ms; the same cap on the 10^6-pair launches costs 1-5 %: C4 sweep 2.69 -> 2.83 ms)
+    const int64_t tcap_big = 16384, tcap_small = 4096, tcap_switch = 32768;
     const unsigned grid = (unsigned)(blocks < gcap ? blocks : gcap);
     const int cmax = std::max(n_categories, t.force_cmax);  // (force_cmax: test hook)
     const bool small = a.env_a.stride <= kSqrtTab && a.env_b.stride <= kSqrtTab && !t.force_bigenv;  // every count fits the LDS tables
@@ -204,9 +207,11 @@ int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinge
             if (use_duo) {
                 constexpr int kTeamPairs = (64 / LCHD_DUO_TL) * kSweepWaves;  // pairs per workgroup and round
                 const int64_t dblocks = (a.n_pairs + kTeamPairs - 1) / kTeamPairs;
+                const int64_t tcap = dblocks <= tcap_switch ? tcap_small : tcap_big;
                 const unsigned dgrid = (unsigned)(dblocks < tcap ? dblocks : tcap);
                 const int64_t tblocks = (a.n_pairs + 2 * kSweepWaves - 1) / (2 * kSweepWaves);
-                const unsigned tgrid = (unsigned)(tblocks < tcap ? tblocks : tcap);
+                const int64_t tcap2 = tblocks <= tcap_switch ? tcap_small : tcap_big;
+                const unsigned tgrid = (unsigned)(tblocks < tcap2 ? tblocks : tcap2);
                 // the four-pairs team kernel, the INDIRECT companion for the pairs its rule leaves over and -- a pass without a hint --
                 // the second team rule's kernel
                 launch_team(s, cmax, tm, true, dgrid, a);
@@ -215,6 +220,7 @@ int launch_sweep(hipStream_t s, const Tuning& t, int n_categories, bool hellinge
             } else if (c8_team) {
                 constexpr int kTeamPairs = 2 * kSweepWaves;
                 const int64_t dblocks = (a.n_pairs + kTeamPairs - 1) / kTeamPairs;
+                const int64_t tcap = dblocks <= tcap_switch ? tcap_small : tcap_big;
                 const unsigned dgrid = (unsigned)(dblocks < tcap ? dblocks : tcap);
                 launch_team(s, cmax, tm, false, dgrid, a);
                 if (!no_others) launch_sweep_indirect(s, cmax, tm, bgrid, a);
@@ -460,6 +466,84 @@ void launch_env_key_sets(hipStream_t s, const DevConfig* cfg, const EnvStore& ea
     if (n_sets <= 0 || max_envs <= 0) return;
     const int64_t nb = (max_envs + 3) / 4;
     k_env_key_sets<<<(unsigned)(nb < 8192 ? nb : 8192), 256, 0, s>>>(cfg, ea, eb, n_sets, st);
+}
+
+// ---- deterministic mode: one order among equal keys ---------------------------------------------------------------------------
+// The reference sorts an environment with a STABLE sort (utils.rs:25-39): equal distances keep their input order, one order for one
+// input.  The environment kernels here break ties by the position a point happened to get in a cell list or a bucket (global / LDS
+// atomics: another order in another run), and although a zero-width interval never counts, the O(1) Bhattacharyya update sees the
+// categories in that order: scores moved by a few 1e-16 from run to run on lattice inputs.  Under lchd_ctx_set_deterministic one wavefront
+// per environment sorts the CATEGORIES of every run of equal keys (positions >= 1: the first point is the anchor) -- two points of one
+// key and one category are interchangeable, so the stored (key, category) sequence is then a function of the input alone.  Environments
+// without ties (every random cloud) cost one read of their keys.
+__global__ __launch_bounds__(256) void k_env_canon(EnvStore ea, EnvStore eb, int64_t n_a, int64_t n_b, const DeviceStatus* st) {
+    __shared__ uint32_t cnt_s[4][256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t nu_a = st ? (int64_t)st->n_unique[0] : n_a, nu_b = st ? (int64_t)st->n_unique[1] : n_b;
+    for (int64_t e = (int64_t)blockIdx.x * 4 + wave; e < nu_a + nu_b; e += (int64_t)gridDim.x * 4) {
+        const bool on_b = e >= nu_a;
+        const EnvStore& es = on_b ? eb : ea;
+        const int64_t slot = on_b ? e - nu_a : e;
+        const int len = es.len[slot];
+        if (len < 3) continue;
+        const uint64_t* __restrict__ key = es.key + slot * es.stride;
+        uint8_t* const c8 = es.cat + slot * es.stride * (es.cat16 ? 2 : 1);
+        uint16_t* const c16 = reinterpret_cast<uint16_t*>(c8);
+        const bool wide = es.cat16 != 0;
+        bool any = false;
+        for (int i0 = 2; i0 < len; i0 += 64) {
+            const int i = i0 + lane;
+            any |= __ballot(i < len && key[i] == key[i - 1]) != 0ull;
+        }
+        if (!any) continue;
+        for (int i0 = 1; i0 < len; i0 += 64) {
+            const int i = i0 + lane;
+            const bool head = i + 1 < len && (i == 1 || key[i] != key[i - 1]) && key[i + 1] == key[i];
+            int end = i + 1;
+            if (head) {
+                const uint64_t k0 = key[i];
+                while (end < len && key[end] == k0) ++end;
+                if (end - i <= 64 || wide) {  // a short run (every lattice): insertion sort by this lane
+                    for (int p = i + 1; p < end; ++p) {
+                        const uint32_t v = wide ? (uint32_t)c16[p] : (uint32_t)c8[p];
+                        int q = p - 1;
+                        while (q >= i && (wide ? (uint32_t)c16[q] : (uint32_t)c8[q]) > v) {
+                            if (wide) c16[q + 1] = c16[q]; else c8[q + 1] = c8[q];
+                            --q;
+                        }
+                        if (wide) c16[q + 1] = (uint16_t)v; else c8[q + 1] = (uint8_t)v;
+                    }
+                }
+            }
+            // long runs (thousands of +inf entries of a distance matrix): the wavefront counts the run's categories and writes them out in order
+            unsigned long long longs = __ballot(head && end - i > 64 && !wide);
+            while (longs) {
+                const int src = __ffsll((long long)longs) - 1;
+                longs &= longs - 1;
+                const int s0 = __shfl(i, src), s1 = __shfl(end, src);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) cnt_s[wave][4 * lane + k] = 0u;
+                wave_sync_lds();
+                for (int p = s0 + lane; p < s1; p += 64) atomicAdd(&cnt_s[wave][c8[p]], 1u);
+                wave_sync_lds();
+                uint32_t c[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) c[k] = cnt_s[wave][4 * lane + k];
+                const uint32_t mine = c[0] + c[1] + c[2] + c[3];
+                uint32_t at = (uint32_t)s0 + wave_incl_scan_u32(mine) - mine;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    for (uint32_t r = 0; r < c[k]; ++r) c8[at++] = (uint8_t)(4 * lane + k);
+                wave_sync_lds();
+            }
+        }
+    }
+}
+void launch_env_canon(hipStream_t s, const EnvStore& ea, const EnvStore& eb, int64_t n_a, int64_t n_b, const DeviceStatus* st) {
+    const int64_t n = n_a + n_b;
+    if (n <= 0) return;
+    const int64_t nb = (n + 3) / 4;
+    k_env_canon<<<(unsigned)(nb < 8192 ? nb : 8192), 256, 0, s>>>(ea, eb, n_a, n_b, st);
 }
 
 // ---- the pairs of a finished pass that touch an overflowed environment (EnvSide::ovf_list) ----------------------------------

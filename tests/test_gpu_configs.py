@@ -887,6 +887,53 @@ def test_deterministic_switch_makes_a_pairs_score_independent_of_batch_and_histo
     assert np.array_equal(whole[:64], few)
 
 
+def test_deterministic_switch_gives_the_same_bits_every_run_on_lattice_inputs(lh, oracle):
+    """The reference sorts an environment with a stable sort (utils.rs:25-39): one input, one order, one score.  The environment
+    kernels place points of EQUAL distance in the order their atomics happened to complete -- another order in another run, and the
+    O(1) Hellinger update then rounds differently (a few 1e-16).  Under the determinism switch the categories inside every run of
+    equal keys are sorted (k_env_canon): lattice structures -- dozens of exact ties per environment, between points of different
+    categories -- scored 20 times through from_primitives (cell lists with global atomics) and through from_coords (row sorts with
+    LDS atomics over 16 wavefronts) give the same bits every time, and match the oracle."""
+    import itertools
+
+    import torch
+    from loco_hd_amd.device import DeviceSession
+
+    rng = np.random.default_rng(606)
+    n_cat = 7
+    cats = [f"c{i}" for i in range(n_cat)]
+    grid = np.array(list(itertools.product(range(16), repeat=3)), dtype=float) * 1.5
+    xa = grid[rng.permutation(len(grid))]
+    xb = grid[rng.permutation(len(grid))] + np.array([0.75, 0.0, 0.0])
+    ca, cb = rng.integers(0, n_cat, len(xa)).astype(np.int32), rng.integers(0, n_cat, len(xb)).astype(np.int32)
+    tag = np.zeros(len(xa), dtype=np.int32)
+    pairs = np.stack([rng.integers(0, len(xa), 5000), rng.integers(0, len(xb), 5000)], 1).astype(np.int64)
+    for wf in (("hyper_exp", [1.0, 0.2]), ("uniform", [1.0, 5.0])):  # (the uniform CDF adds long runs of equal F below x_min)
+        want = np.asarray(oracle.LoCoHD(cats, oracle.WeightFunction(*wf), n_of_threads=8).from_arrays(xa, ca, tag, xb, cb, tag, pairs[:600], 6.0))
+        sess = DeviceSession(lh.LoCoHD(cats, lh.WeightFunction(*wf), deterministic=True))
+        a, b, d_pairs = sess.upload(xa, ca, tag), sess.upload(xb, cb, tag), torch.from_numpy(pairs).cuda()
+        first = sess.from_primitives(a, b, d_pairs, 6.0).cpu().numpy()
+        assert np.max(np.abs(first[:600] - want)) < 1e-11
+        for _ in range(19):
+            assert np.array_equal(sess.from_primitives(a, b, d_pairs, 6.0).cpu().numpy(), first)
+        sess.close()
+        other = DeviceSession(lh.LoCoHD(cats, lh.WeightFunction(*wf), deterministic=True))  # another context, another workspace: the same bits
+        a, b = other.upload(xa, ca, tag), other.upload(xb, cb, tag)
+        assert np.array_equal(other.from_primitives(a, b, d_pairs, 6.0).cpu().numpy(), first)
+        other.close()
+    # dense rows: 12^3 lattice points, every row of the distance matrix is full of ties
+    g2 = np.array(list(itertools.product(range(12), repeat=3)), dtype=float)
+    ya, yb = g2[rng.permutation(len(g2))], g2[rng.permutation(len(g2))]
+    sa, sb = rng.choice(cats, len(ya)).tolist(), rng.choice(cats, len(yb)).tolist()
+    det = lh.LoCoHD(cats, lh.WeightFunction("hyper_exp", [1.0, 0.3]), deterministic=True)
+    first = np.asarray(det.from_coords(sa, sb, ya, yb))
+    want = np.asarray(oracle.LoCoHD(cats, oracle.WeightFunction("hyper_exp", [1.0, 0.3])).from_coords(sa[:40], sb[:40], ya[:40], yb[:40]))
+    sub = np.asarray(lh.LoCoHD(cats, lh.WeightFunction("hyper_exp", [1.0, 0.3]), deterministic=True).from_coords(sa[:40], sb[:40], ya[:40], yb[:40]))
+    assert np.max(np.abs(sub - want)) < 1e-11
+    for _ in range(19):
+        assert np.array_equal(np.asarray(det.from_coords(sa, sb, ya, yb)), first)
+
+
 @pytest.mark.parametrize("n_cat,sd", [(5, None), (8, None), (12, None), (16, None), (11, ("Kolmogorov-Smirnov", []))])
 def test_prefix_count_rows_give_the_same_bits_as_the_per_tile_histogram(lh, oracle, monkeypatch, n_cat, sd):
     """Configurations of at most 16 categories: k_env_group writes prefix-count rows next to every environment (EnvStore::pre) and the
