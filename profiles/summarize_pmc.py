@@ -24,12 +24,12 @@ def main(dirs):
                     disp = row.get("Dispatch_Id") or row.get("Dispatch Id") or "0"
                     acc[name][row["Counter_Name"]][disp] += float(row["Counter_Value"])
         for name in sorted(acc, key=lambda n: -sum(sum(v.values()) for v in acc[n].values())):
-            if not name.startswith("void lchd") and not name.startswith("lchd"):
+            if not name.startswith("void lchd") and not name.startswith("lchd") and "k_floor" not in name:  # (k_floor: profiles/ubench/dense_floor.hip)
                 continue
             counters = acc[name]
             n_disp = max(len(v) for v in counters.values())
             per = {c: round(sum(v.values()) / max(len(v), 1)) for c, v in sorted(counters.items())}
-            short = name.split("(")[0]
+            short = name.rsplit("(", 1)[0] if name.endswith(")") else name  # (drop the argument list, keep "(anonymous namespace)::")
             print(f"{short} | dispatches {n_disp} | per-dispatch: {per}")
 
 
