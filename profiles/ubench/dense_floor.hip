@@ -36,7 +36,6 @@
 
 namespace {
 
-constexpr int kQ = 10;        // events per thread and side
 constexpr int kPart = 2048;   // sqrt(k), k < kPart, in LDS
 
 __device__ __forceinline__ uint32_t scan_u32(uint32_t x) {  // inclusive prefix sum over the 64 lanes (DPP)
@@ -102,13 +101,13 @@ __device__ __forceinline__ uint32_t mix(uint32_t x) {  // a bijection of the 32-
 }
 
 // NT threads, 2 * kQ * NT events per row pair, NB buckets; rows r = blockIdx, + gridDim, ...
-// WPE: wavefronts per SIMD the register budget is cut for (4: 128 registers, 2: 256)
-template <int NT, int NB, int WPE>
+// WPE: wavefronts per SIMD the register budget is cut for (4: 128 registers, 2: 256); kQ: events per thread and side
+template <int NT, int NB, int WPE, int kQ>
 __global__ __launch_bounds__(NT, WPE) void k_floor(int n_rows, const double* __restrict__ sqrt_tab, const double* __restrict__ exp2_tab, double* out) {
     constexpr int kWaves = NT / 64, kCap = 2 * kQ * NT, NW = 3;  // 12 category slots
     constexpr int kEpl = 13;                                    // events per lane and sweep round (odd: no LDS bank folding)
     constexpr int kR0 = kEpl * NT;                              // ranks of the first round
-    static_assert(kCap - kR0 <= kR0 && (NB / 2) % (4 * NT) == 0, "two rounds; whole 16-byte groups of histogram words per thread");
+    static_assert((NB / 2) % (4 * NT) == 0, "whole 16-byte groups of histogram words per thread");
     constexpr size_t kHistOff = (size_t)(kCap + 8) * 4, kPartOff = (size_t)kR0 * 8;
     constexpr size_t kA = kHistOff + (size_t)NB * 2 + 16, kB = kPartOff + (size_t)kPart * 8 + 16;
     constexpr size_t kLabOff = kA > kB ? kA : kB;
@@ -225,12 +224,11 @@ __global__ __launch_bounds__(NT, WPE) void k_floor(int n_rows, const double* __r
 #pragma unroll
             for (int q = 0; q < kQ; ++q) kk[side][q] = 1.0 - f_exp_nonpos(-0.1 * f_sqrt(kk[side][q] * 1.0e4), exp_tab);
         __syncthreads();
-        // label-only sweep, two rounds of ranks
+        // label-only sweep, rounds of kR0 ranks
         double acc = 0.0;
         int base_na = 0, base_nb = 0, swept = 0;
 #pragma unroll 1
-        for (int rd = 0; rd < 2; ++rd) {
-            const int rbase = rd * kR0;
+        for (int rbase = 0; rbase < kCap; rbase += kR0) {
             const int n = min(kCap - rbase, kR0);
             const uint8_t* const sval = lab + rbase;
             const int epl = ((n + NT - 1) / NT) | 1;
@@ -357,20 +355,20 @@ __global__ __launch_bounds__(NT, WPE) void k_floor(int n_rows, const double* __r
     }
 }
 
-template <int NT, int NB, int WPE>
+template <int NT, int NB, int WPE, int kQ>
 void run(const char* name, int n_rows, int grid, const double* d_sqrt, const double* d_exp, double* d_out, int reps) {
     constexpr int kCap = 2 * kQ * NT, kR0 = 13 * NT;
     constexpr size_t kHistOff = (size_t)(kCap + 8) * 4, kPartOff = (size_t)kR0 * 8;
     constexpr size_t kA = kHistOff + (size_t)NB * 2 + 16, kB = kPartOff + (size_t)kPart * 8 + 16;
     const size_t lds = (kA > kB ? kA : kB) + (size_t)kCap + 16;
-    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_floor<NT, NB, WPE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_floor<NT, NB, WPE, kQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    for (int i = 0; i < 2; ++i) k_floor<NT, NB, WPE><<<grid, NT, lds>>>(n_rows, d_sqrt, d_exp, d_out);
+    for (int i = 0; i < 2; ++i) k_floor<NT, NB, WPE, kQ><<<grid, NT, lds>>>(n_rows, d_sqrt, d_exp, d_out);
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0));
-    for (int i = 0; i < reps; ++i) k_floor<NT, NB, WPE><<<grid, NT, lds>>>(n_rows, d_sqrt, d_exp, d_out);
+    for (int i = 0; i < reps; ++i) k_floor<NT, NB, WPE, kQ><<<grid, NT, lds>>>(n_rows, d_sqrt, d_exp, d_out);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
     float ms = 0.f;
@@ -401,8 +399,10 @@ int main(int argc, char** argv) {
     CHECK(hipMemcpy(d_sqrt, hs.data(), sizeof(double) * kPart, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(d_exp, he.data(), sizeof(double) * 64, hipMemcpyHostToDevice));
     // the same 2.048 x 10^8 events either way
-    run<512, 8192, 4>("two workgroups of 512 threads per CU (128 registers), 10 240 events per row pair", 20000, 512, d_sqrt, d_exp, d_out, reps);
-    run<512, 8192, 2>("one workgroup of 512 threads per CU (256 registers: what the code wants unconstrained is 210), 10 240 events per row pair", 20000, 256, d_sqrt, d_exp, d_out, reps);
-    run<1024, 16384, 4>("one workgroup of 1024 threads per CU (128 registers), 20 480 events per row pair", 10000, 256, d_sqrt, d_exp, d_out, reps);
+    run<512, 8192, 4, 10>("two workgroups of 512 threads per CU (128 registers), 10 240 events per row pair", 20000, 512, d_sqrt, d_exp, d_out, reps);
+    run<512, 8192, 2, 10>("one workgroup of 512 threads per CU (256 registers: what the code wants unconstrained is 210), 10 240 events per row pair", 20000, 256, d_sqrt, d_exp, d_out, reps);
+    run<1024, 16384, 4, 10>("one workgroup of 1024 threads per CU (128 registers), 20 480 events per row pair", 10000, 256, d_sqrt, d_exp, d_out, reps);
+    // (tried and not kept: 512 threads with 40 events per thread for the 20 480-event row pair -- 119 spilled dwords even at 256
+    //  registers, 3.07 ms per 2 x 10^8 events)
     return 0;
 }
