@@ -931,7 +931,7 @@ static void carve_pass(Arena& ar, int64_t n_a, int cells_a, int64_t envs_a, int6
         b.env.len = ar.take<int32_t>(ne);
         b.env.cat0 = (cap == kEnvGroupCap && !cat16) ? ar.take<uint8_t>(ne) : nullptr;  // (written by k_env_group only: prims_enqueue drops it otherwise)
         const int pw = side ? pre_words_b : pre_words_a;  // prefix-count rows (k_env_group, configurations of at most 16 categories)
-        b.env.pre = pw > 0 ? ar.take<uint64_t>(ne * (size_t)cap * (size_t)pw) : nullptr;
+        b.env.pre = pw > 0 ? ar.take<uint64_t>(ne * (size_t)(cap / kPreStep) * (size_t)pw) : nullptr;  // (one row per kPreStep points)
         b.env.pre_words = pw;
         b.env.stride = cap;
         b.env.cdf_keys = 0;
@@ -1029,8 +1029,10 @@ static int prims_enqueue(lchd_ctx* c) {
         const int cm = std::max(c->h_cfg.n_categories, c->tune.force_cmax);
         const bool team_cfg = (c->hellinger2 || c->sd_fast == 3) && c->unit_weights && key_sets >= 1 && !c->tune.no_duo && !c->tune.no_count8 &&
                               !c->tune.no_c8_team && !c->tune.force_generic && !c->tune.force_wide && !c->tune.force_bigenv;
+        // (17 .. 28 slots -- three / four count words, the LDS-byte form of the team sweep -- were built and measured in round 6: C5's
+        //  k_sweep_duo<28, 32, 480> 1.690 ms with rows against 1.679 without, k_env_group 0.93 against 0.77 ms: no rows there)
         if (group && team_cfg && cm <= 16 && !per_pair && !c->deterministic && c->tune.pre_rows >= 0 && (n_pairs > 4096 || c->tune.no_inline_meta || c->tune.pre_rows > 0))
-            pre_words = cm <= 8 ? 1 : 2;
+            pre_words = team_pre_words(cm);
     }
     PassBufs pb{};
     {

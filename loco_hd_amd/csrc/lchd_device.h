@@ -163,15 +163,23 @@ struct EnvStore {
                        // sweep needs no CDF evaluation: a pair reads the set of its weight function); 0: keys are the distances
     int32_t cat16;     // 1: `cat` holds 16-bit category ids (more than 255 categories): two bytes per point
     int64_t set_stride;  // elements between two key sets (slots x stride); categories and lengths exist once
-    uint64_t* pre;       // prefix-count rows, or null: row i of environment e = pre[(e * stride + i) * pre_words ...] = the category counts of the
-                         // environment's first i + 1 sorted points as 8-bit fields (slot c in byte c % 8 of word c / 8), written by
-                         // k_env_group for configurations of at most 16 categories: the team sweeps read a chunk's start counts
-                         // from them instead of building a histogram and a scan per tile (lchd_team_tile.h, PRE)
-    int32_t pre_words;   // u64 words per row (1: up to 8 categories, 2: up to 16)
+    uint64_t* pre;       // prefix-count rows, or null: row j of environment e = pre[(e * stride / kPreStep + j) * pre_words ...] = the category
+                         // counts of the environment's first kPreStep * j + 1 sorted points (one row per kPreStep points) as 8-bit fields
+                         // (slot c in byte c % 8 of word c / 8), written by k_env_group for configurations of at most 16 categories: the
+                         // team sweeps read a chunk's start counts from them -- the row below the chunk's start plus the one-hot fields of
+                         // at most kPreStep - 1 category bytes -- instead of building a histogram and a scan per tile (lchd_team_tile.h, PRE)
+    int32_t pre_words;   // u64 words per row (1: up to 8 category slots, 2: up to 16, 3: up to 24, 4: up to 32)
     int32_t pad_pre;
     uint8_t* cat0;       // [slots] category of every environment's first (sorted) point, or null: what k_pair_meta puts into the pair records -- one
                          // gather into a small array instead of one into the store itself (k_env_group writes it; the other environment kernels do not)
 };
+#ifndef LCHD_PRE_STEP
+#define LCHD_PRE_STEP 4
+#endif
+constexpr int kPreStep = LCHD_PRE_STEP;  // points per prefix-count row (round 6: every row of round 5's store cost the sweeps one 128-byte line per lane)
+// u64 words of a prefix-count row that the team sweep of `cmax` category slots reads: TeamTile<CM>::NW of the instantiation launch_team
+// picks (8, 12 / 16 slots); 0: no instantiation reads rows (k_env_group's writer handles up to four words)
+inline int team_pre_words(int cmax) { return cmax <= 8 ? 1 : (cmax <= 16 ? 2 : 0); }
 constexpr int kMaxKeySets = 4;  // weight-function dictionaries of up to 4 entries get one key set each (k_env_group); larger ones keep distance keys
 
 // One structure (or batch of structures) of a from_primitives pass as the prologue sees it: the inputs, and the arrays the

@@ -112,8 +112,8 @@ void env_group_overflow(const LCHD_AS4 EnvSide* p, DeviceStatus* st, int side, i
     if (p->env.pre) {  // (row 0 of the one-point environment)
         const uint32_t cs = (int)cat < n_cat ? cat : 0u;
         const uint64_t one = 1ull << ((cs & 7u) * 8u);
-        if (p->env.pre_words > 1) { p->env.pre[((size_t)(uint32_t)e << 9) * 2] = cs < 8u ? one : 0ull; p->env.pre[((size_t)(uint32_t)e << 9) * 2 + 1] = cs >= 8u ? one : 0ull; }
-        else p->env.pre[(size_t)(uint32_t)e << 9] = one;
+        const size_t r0 = ((size_t)(uint32_t)e << 9) / kPreStep;
+        for (int k = 0; k < p->env.pre_words; ++k) p->env.pre[r0 * p->env.pre_words + k] = (cs >> 3) == (uint32_t)k ? one : 0ull;
     }
 }
 
@@ -489,30 +489,42 @@ __global__ __launch_bounds__(64 * LCHD_GROUP_WPB) __attribute__((amdgpu_waves_pe
                 }
             }
             // prefix-count rows (EnvStore::pre): per environment an inclusive scan of the sorted points' one-hot category fields -- 8-bit
-            // fields, one or two u64 words per point; the team sweeps read a lane's chunk-start counts from them (lchd_team_tile.h, PRE).
+            // fields, one to four u64 words per row, one row per kPreStep points (rows 0, 4, 8, ...: the counts of the first 1, 5, 9, ...
+            // points); the team sweeps read a lane's chunk-start counts from them (lchd_team_tile.h, PRE).
             // (An environment of more than 255 points overflows its fields: no team rule sweeps such a pair.)
             if (p->env.pre) {
+                // lane l takes points kPreStep l .. kPreStep l + kPreStep - 1 of a round: ONE scan per count word over the lanes' sums serves
+                // 64 rows (a scan per point, as round 5 wrote its rows, cost the environment kernel four times the vector instructions)
                 uint64_t* __restrict__ opre = p->env.pre;
-                const int nw = p->env.pre_words;
+                const int nw = p->env.pre_words;  // 1 .. 4 (8 .. 32 category slots)
                 for (int q = 0; q < G; ++q) {
                     const int s0 = (int)lds.gstart[q], c0 = (int)lds.gcount[q];
-                    const uint32_t row0 = (uint32_t)((e_first + q) << 9);
-                    uint64_t car0 = 0ull, car1 = 0ull;
-                    for (int i0 = 0; i0 < c0; i0 += 64) {
-                        const int i = i0 + lf;
-                        const bool act = i < c0;
-                        const uint32_t cat_raw = (uint32_t)lds.val[s0 + (act ? i : 0)] & 0xFFu;
-                        const uint32_t cat = (int)cat_raw < n_cat ? cat_raw : 0u;  // (as stored)
-                        const uint64_t one = act ? (1ull << ((cat & 7u) * 8u)) : 0ull;
-                        const uint64_t w0 = wave_incl_scan_fields((cat < 8u) ? one : 0ull) + car0;
-                        car0 = readlane_u64(w0, 63);
-                        if (nw > 1) {
-                            const uint64_t w1 = wave_incl_scan_fields((cat >= 8u) ? one : 0ull) + car1;
-                            car1 = readlane_u64(w1, 63);
-                            if (act) { opre[(size_t)(row0 + (uint32_t)i) * 2] = w0; opre[(size_t)(row0 + (uint32_t)i) * 2 + 1] = w1; }
-                        } else if (act) {
-                            opre[row0 + (uint32_t)i] = w0;
+                    const uint32_t row0 = (uint32_t)((e_first + q) << 9) / (uint32_t)kPreStep;
+                    uint64_t car[4] = {0ull, 0ull, 0ull, 0ull};
+                    for (int i0 = 0; i0 < c0; i0 += 64 * kPreStep) {
+                        const int i = i0 + lf * kPreStep;  // this lane's first point: the point of its row
+                        uint64_t mine[4] = {0ull, 0ull, 0ull, 0ull}, first[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+                        for (int m = 0; m < kPreStep; ++m) {
+                            const bool act = i + m < c0;
+                            const uint32_t cat_raw = (uint32_t)lds.val[s0 + (act ? i + m : 0)] & 0xFFu;
+                            const uint32_t cat = (int)cat_raw < n_cat ? cat_raw : 0u;  // (as stored)
+                            const uint64_t one = act ? (1ull << ((cat & 7u) * 8u)) : 0ull;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const uint64_t o = (cat >> 3) == (uint32_t)k ? one : 0ull;
+                                mine[k] += o;
+                                if (m == 0) first[k] = o;
+                            }
                         }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (k < nw) {  // (wave-uniform)
+                                const uint64_t incl = wave_incl_scan_fields(mine[k]);
+                                const uint64_t row = incl - mine[k] + car[k] + first[k];  // the counts of the first i + 1 points
+                                car[k] += readlane_u64(incl, 63);
+                                if (i < c0) opre[(size_t)(row0 + (uint32_t)(i / kPreStep)) * (size_t)nw + k] = row;
+                            }
                     }
                 }
             }

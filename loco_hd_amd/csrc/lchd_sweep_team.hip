@@ -184,8 +184,8 @@ __global__ __launch_bounds__(64 * kSweepWaves, ((CMAX <= 16 && !(WGT && CMAX > 8
         wave_sync_lds();
 
         // (PRE: the prefix-count rows of the two environments; an unusable pair's records may name slots that do not exist: row 0 of slot 0)
-        const uint64_t* preA = PRE ? args.env_a.pre + (valid ? offA * (uint64_t)TT::NW : 0ull) : nullptr;
-        const uint64_t* preB = PRE ? args.env_b.pre + (valid ? offB * (uint64_t)TT::NW : 0ull) : nullptr;
+        const uint64_t* preA = PRE ? args.env_a.pre + (valid ? offA / kPreStep * (uint64_t)TT::NW : 0ull) : nullptr;  // (slot strides are multiples of kPreStep)
+        const uint64_t* preB = PRE ? args.env_b.pre + (valid ? offB / kPreStep * (uint64_t)TT::NW : 0ull) : nullptr;
         const double acc = TT::run(sA, cA, sB, cB, mA, mB, T, epl, epl_w, c0a, c0b, F0, Finf0, t_sqrt, t_rsqrt, w_s, lcl, tl, preA, preB);
         if (tl == TL - 1 && live && mine) args.out[p] = valid ? acc : nan("");  // (categories were checked when the environments were built)
     }
@@ -202,7 +202,7 @@ template <int TM>
 static void launch_team_t(hipStream_t s, int cmax, bool tile240, unsigned grid, const SweepArgs& a) {
     // both stores carry prefix-count rows of the width this slot count reads (k_env_group wrote them): the PRE instantiations
     if constexpr (TM != 1) {
-        const int nw = cmax <= 8 ? 1 : 2;
+        const int nw = team_pre_words(cmax);
         if (cmax <= 16 && a.env_a.pre && a.env_b.pre && a.env_a.pre_words == nw && a.env_b.pre_words == nw) {
             if (cmax <= 8) launch_team_c<8, TM, true>(s, tile240, grid, a);
             else if (cmax <= 12) launch_team_c<12, TM, true>(s, tile240, grid, a);

@@ -106,10 +106,12 @@ __device__ __forceinline__ double team_sum_f64(double v) {  // the last lane of 
 
 // CMAX category slots, teams of TL lanes, pairs of at most TILE_ merged events; WGT: category weights other than 1; KSM: the
 // Kolmogorov-Smirnov distance on unit weights (see k_sweep_duo for the two forms).
-// PRE: the packed counts at a lane's chunk start are READ from the environments' prefix-count rows (EnvStore::pre: row r = the counts
-// of the first r + 1 sorted points of the environment, the anchor included, as 8-bit fields -- written once per environment by
-// k_env_group) instead of being built per tile from a histogram of the lane's chunk and a scan over the team: the position the merge
-// path hands a lane IS the row index.  An environment that is swept many times (C2a: 100 pairs per anchor) pays for its rows once.
+// PRE: the packed counts at a lane's chunk start are READ from the environments' prefix-count rows (EnvStore::pre: row j = the counts
+// of the first kPreStep * j + 1 sorted points of the environment, the anchor included, as 8-bit fields -- written once per environment
+// by k_env_group) instead of being built per tile from a histogram of the lane's chunk and a scan over the team: the position i the
+// merge path hands a lane names row i / kPreStep, and the one-hot fields of the i % kPreStep staged category bytes between that row
+// and the chunk's start are added here.  An environment that is swept many times (C2a: 100 pairs per anchor) pays for its rows once.
+// (Round 5 stored a row per point: a lane's 16-byte read then touched a 128-byte line of its own -- 8.0 GB per 10^6 C2a pairs.)
 template <int CMAX, int TL, int TILE_, bool WGT = false, bool KSM = false, bool PRE = false>
 struct TeamTile {
     static_assert(!KSM || (!WGT && CMAX <= 16), "the Kolmogorov-Smirnov form: unit weights, one or two count words per side");
@@ -159,11 +161,23 @@ struct TeamTile {
 
         uint64_t exA[NW], exB[NW];
         if constexpr (PRE) {
-            // the rows of the two chunk starts: i0 / j0 non-anchor points of A / B lie before this lane's first event
+            // the rows at or below the two chunk starts (i0 / j0 non-anchor points of A / B lie before this lane's first event), and the
+            // one-hot fields of the up to kPreStep - 1 points between a row and its chunk start
+            const int ra_ = i0 / kPreStep, rb_ = j0 / kPreStep;
 #pragma unroll
             for (int k = 0; k < NW; ++k) {
-                exA[k] = preA[(size_t)i0 * NW + k];
-                exB[k] = preB[(size_t)j0 * NW + k];
+                exA[k] = preA[(size_t)ra_ * NW + k];
+                exB[k] = preB[(size_t)rb_ * NW + k];
+            }
+#pragma unroll
+            for (int m = 0; m < kPreStep - 1; ++m) {
+                const unsigned ca_ = cA[min(ra_ * kPreStep + m, max(mA - 1, 0))], cb_ = cB[min(rb_ * kPreStep + m, max(mB - 1, 0))];
+                const uint64_t oa_ = m < (i0 % kPreStep) ? (1ull << ((ca_ % FPW) * FB)) : 0ull, ob_ = m < (j0 % kPreStep) ? (1ull << ((cb_ % FPW) * FB)) : 0ull;
+                if constexpr (NW == 1) { exA[0] += oa_; exB[0] += ob_; }
+                else {
+#pragma unroll
+                    for (int k = 0; k < NW; ++k) { exA[k] += (int)(ca_ / FPW) == k ? oa_ : 0ull; exB[k] += (int)(cb_ / FPW) == k ? ob_ : 0ull; }
+                }
             }
         } else {
         // pass 1: 4-bit-per-category histogram of the lane's chunk

@@ -936,8 +936,9 @@ def test_deterministic_switch_gives_the_same_bits_every_run_on_lattice_inputs(lh
 
 @pytest.mark.parametrize("n_cat,sd", [(5, None), (8, None), (12, None), (16, None), (11, ("Kolmogorov-Smirnov", []))])
 def test_prefix_count_rows_give_the_same_bits_as_the_per_tile_histogram(lh, oracle, monkeypatch, n_cat, sd):
-    """Configurations of at most 16 categories: k_env_group writes prefix-count rows next to every environment (EnvStore::pre) and the
-    team sweeps read a chunk's start counts from them (lchd_team_tile.h, PRE) instead of a histogram + scan per tile -- integer counts
+    """Configurations of at most 16 categories: k_env_group writes a prefix-count row per four points next to
+    every environment (EnvStore::pre) and the team sweeps read a chunk's start counts from them -- the row below the chunk's start plus
+    the one-hot fields of up to three category bytes (lchd_team_tile.h, PRE) -- instead of a histogram + scan per tile: integer counts
     either way, so the scores are bitwise those of LCHD_PRE_ROWS=-1; both follow the oracle (pmf.rs:47-63 counts the same points).
     One object on both sides, a weight-function dictionary and a tag rule ride along.  (Bitwise on coordinates without exact distance
     ties; a second structure on a lattice is compared with the oracle only: the order of TIED points of different categories inside an
