@@ -60,7 +60,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 PRIME_STEPS = 6  # untimed set-up passes in front of the warm-up steps (Harness.run)
 
 

@@ -4,7 +4,7 @@
 # Kernel trace and the PMC passes are separate runs (never --pmc together with a trace other than --kernel-trace); the program
 # itself follows `--` (no env / bash -c hop under the profiler).
 set -o pipefail
-ROUND=${1:-r05}; TAG=${2:-x}; shift 2
+ROUND=${1:-r06}; TAG=${2:-x}; shift 2
 WLS=${@:-c2a c5 c4 c3 c2b}
 REPO=$PWD
 OUT=$REPO/gpurun_out/prof_${ROUND}_${TAG}

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Secondary measurements of a round (run through gpurun from the repository root): bash profiles/collect_extra.sh r03 a
 #   -> gpurun_out/extra_r03_a/{other_workloads,call_latencies,dense_host_calls,bench_c2b_20000atoms,emulated_strong_w8_<w>[_1stream]}.json, fuzz.log
-ROUND=${1:-r05}; TAG=${2:-x}
+ROUND=${1:-r06}; TAG=${2:-x}
 OUT=gpurun_out/extra_${ROUND}_${TAG}
 mkdir -p $OUT
 python3 profiles/other_workloads.py > $OUT/other_workloads.json 2> $OUT/other_workloads.err

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Copy what profiles/collect_final.sh left under gpurun_out/ into profiles/<round>/ under the names the documents cite:
-#   bash profiles/install_final.sh r05 f
-ROUND=${1:-r05}; TAG=${2:-f}
+#   bash profiles/install_final.sh r06 f
+ROUND=${1:-r06}; TAG=${2:-f}
 P=gpurun_out/prof_${ROUND}_${TAG}; E=gpurun_out/extra_${ROUND}_${TAG}; F=gpurun_out/final_${ROUND}; D=profiles/$ROUND
 mkdir -p $D
 for W in c2a c2b c3 c4 c5; do
