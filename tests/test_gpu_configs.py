@@ -992,3 +992,43 @@ def test_prefix_count_rows_give_the_same_bits_as_the_per_tile_histogram(lh, orac
                 assert np.max(np.abs(ab - want_ab)) < 1e-11 and np.max(np.abs(aa - want_aa)) < 1e-11
         for (ab0, aa0), (ab1, aa1) in zip(got["-1"], got["0"]):
             assert np.array_equal(ab0, ab1) and np.array_equal(aa0, aa1)
+
+
+@pytest.mark.parametrize("n_cat", [6, 13])
+def test_prefix_count_rows_on_environments_of_a_few_points(lh, oracle, monkeypatch, n_cat):
+    """Rows exist for every FOURTH point of an environment (EnvStore::pre, kPreStep): a chunk that starts at point i reads row i / 4 and
+    adds the i % 4 category bytes behind it (lchd_team_tile.h).  Sparse clouds and several thresholds give environments of 1, 2, ... ~15
+    points -- every residue of the row step on both sides, anchors alone, rows that are an environment's last point -- swept with rows
+    (forced for a call of any size) and without: the same bits, both at the oracle."""
+    import torch
+    from loco_hd_amd.device import DeviceSession
+
+    rng = np.random.default_rng(700 + n_cat)
+    cats = [f"c{i}" for i in range(n_cat)]
+    n = 900
+    side = (n / 0.004) ** (1 / 3)
+    xa, xb = rng.uniform(0, side, (n, 3)), rng.uniform(0, side, (n, 3))
+    ca, cb = rng.integers(0, n_cat, n).astype(np.int32), rng.integers(0, n_cat, n).astype(np.int32)
+    tag = np.zeros(n, dtype=np.int32)
+    pairs = np.stack([rng.integers(0, n, 6000), rng.integers(0, n, 6000)], 1).astype(np.int64)
+    lo = oracle.LoCoHD(cats, oracle.WeightFunction("hyper_exp", [1.0, 0.2]))
+    sizes = set()
+    for thr in (4.0, 7.5, 9.0):
+        want = np.asarray(lo.from_arrays(xa, ca, tag, xb, cb, tag, pairs, thr))
+        got = {}
+        for hook in ("-1", "1"):
+            monkeypatch.setenv("LCHD_PRE_ROWS", hook)
+            sess = DeviceSession(lh.LoCoHD(cats, lh.WeightFunction("hyper_exp", [1.0, 0.2])))
+            monkeypatch.delenv("LCHD_PRE_ROWS")
+            a, b = sess.upload(xa, ca, tag), sess.upload(xb, cb, tag)
+            d_pairs = torch.from_numpy(pairs).cuda()
+            outs = [sess.from_primitives(a, b, d_pairs, thr).cpu().numpy() for _ in range(3)]  # (the third pass runs the hinted launch set)
+            sess.close()
+            for o in outs:
+                assert np.max(np.abs(o - want)) < 1e-11
+            got[hook] = outs
+        for o0, o1 in zip(got["-1"], got["1"]):
+            assert np.array_equal(o0, o1)
+        d = np.sqrt(((xa[pairs[:200, 0], None, :] - xa[None, :, :]) ** 2).sum(-1))
+        sizes |= set((d < thr).sum(1).tolist())
+    assert {1, 2, 3, 4, 5, 6, 7, 8, 9} <= sizes  # (environment sizes the thresholds produced, anchor included)
