@@ -100,6 +100,14 @@ __device__ __forceinline__ uint32_t mix(uint32_t x) {  // a bijection of the 32-
     return x;
 }
 
+// -DFLOOR_STAMPS: s_memtime deltas of wavefront 0 per phase (barrier waits included), summed over the launch
+#ifdef FLOOR_STAMPS
+__device__ unsigned long long g_floor_stamps[16];
+#define FSTAMP(i) do { if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); fst_acc[i] += t_ - fst_last; fst_last = t_; } } while (0)
+#else
+#define FSTAMP(i) do { } while (0)
+#endif
+
 // NT threads, 2 * kQ * NT events per row pair, NB buckets; rows r = blockIdx, + gridDim, ...
 // WPE: wavefronts per SIMD the register budget is cut for (4: 128 registers, 2: 256); kQ: events per thread and side
 template <int NT, int NB, int WPE, int kQ>
@@ -123,6 +131,12 @@ __global__ __launch_bounds__(NT, WPE) void k_floor(int n_rows, const double* __r
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < 64) exp_tab[tid] = exp2_tab[tid];
     if (tid == 64) Ws[kR0 + kPart] = 0.0;  // the weight of "not a rank of this round"
+#ifdef FLOOR_STAMPS
+    __shared__ unsigned long long fst_acc[16];
+    if (tid < 16) fst_acc[tid] = 0ull;
+    __syncthreads();
+    unsigned long long fst_last = __builtin_amdgcn_s_memtime();
+#endif
     for (int r = blockIdx.x; r < n_rows; r += gridDim.x) {
         // keys: an integer hash per (row, event) -- the high 32 bits of the f64 key ARE the surrogate, distinct by construction
         double kk[2][kQ];
@@ -139,6 +153,7 @@ __global__ __launch_bounds__(NT, WPE) void k_floor(int n_rows, const double* __r
         if (tid < 2 * NW) base_cnt[0][tid] = 0ull;
         if (tid == 0) carry_h[0] = carry_h[1] = 0.0;
         __syncthreads();
+        FSTAMP(0);   // keys (hash), histogram cleared
         // counting sort: bucket, slot from the returning atomic
 #pragma unroll
         for (int side = 0; side < 2; ++side)
@@ -150,6 +165,7 @@ __global__ __launch_bounds__(NT, WPE) void k_floor(int n_rows, const double* __r
                 bs[side][q] = b | (((old >> sh) & 0xFFFFu) << 15);
             }
         __syncthreads();
+        FSTAMP(1);   // bucket + returning atomic
         {
             constexpr int kScanW = NB / 2 / NT;
             uint32_t c[2 * kScanW];
@@ -183,6 +199,7 @@ __global__ __launch_bounds__(NT, WPE) void k_floor(int n_rows, const double* __r
             if (tid == 0) hist[NB / 2] = (uint32_t)kCap;
         }
         __syncthreads();
+        FSTAMP(2);   // scan of the bucket counters
 #pragma unroll
         for (int side = 0; side < 2; ++side)
 #pragma unroll
@@ -194,6 +211,7 @@ __global__ __launch_bounds__(NT, WPE) void k_floor(int n_rows, const double* __r
             }
         if (tid < 8) sur[kCap + tid] = ~0u;
         __syncthreads();
+        FSTAMP(3);   // surrogates to their bucket positions
         // rank among the bucket's surrogates (six read blind, the rest in a loop), label to the rank
 #pragma unroll
         for (int side = 0; side < 2; ++side)
@@ -210,6 +228,7 @@ __global__ __launch_bounds__(NT, WPE) void k_floor(int n_rows, const double* __r
                 bs[side][q] = lo + less;
             }
         __syncthreads();  // (labels below go to their own array, but the weights will overwrite the surrogates)
+        FSTAMP(4);   // ranking
         uint32_t rk2[kQ];
 #pragma unroll
         for (int q = 0; q < kQ; ++q) {
@@ -224,6 +243,7 @@ __global__ __launch_bounds__(NT, WPE) void k_floor(int n_rows, const double* __r
 #pragma unroll
             for (int q = 0; q < kQ; ++q) kk[side][q] = 1.0 - f_exp_nonpos(-0.1 * f_sqrt(kk[side][q] * 1.0e4), exp_tab);
         __syncthreads();
+        FSTAMP(5);   // labels to their ranks, sqrt table, F in registers
         // label-only sweep, rounds of kR0 ranks
         double acc = 0.0;
         int base_na = 0, base_nb = 0, swept = 0;
@@ -256,6 +276,7 @@ __global__ __launch_bounds__(NT, WPE) void k_floor(int n_rows, const double* __r
             const uint32_t sna = scan_u32(n_al);
             if (lane == 63) wtot_a[wave] = sna;
             __syncthreads();
+            FSTAMP(6);   // chunk counts: label histogram per lane, scans, barrier
             const int par = swept & 1;
             uint64_t run = 0ull;
             uint32_t run_a = 0u, tot_a = 0u;
@@ -322,6 +343,7 @@ __global__ __launch_bounds__(NT, WPE) void k_floor(int n_rows, const double* __r
                     if (e == 0) firstH = H; else Ws[d0 + e] = Hp - H;
                     Hp = H;
                 }
+            FSTAMP(7);   // event loop
             const int last = (n - 1) / epl;
             if (lane == 63) st_h[wave] = Hp;
             if (tid == last) carry_h[(swept + 1) & 1] = Hp;
@@ -330,12 +352,14 @@ __global__ __launch_bounds__(NT, WPE) void k_floor(int n_rows, const double* __r
             __syncthreads();
             if (lane == 0 && d0 < d1) Ws[d0] = (wave == 0 ? carry_h[swept & 1] : st_h[wave - 1]) - firstH;
             __syncthreads();
+            FSTAMP(8);   // stitch: weights of the chunks' first ranks (two barriers)
 #pragma unroll
             for (int q = 0; q < kQ; ++q) {
                 const uint32_t ia = (rk2[q] & 0xFFFFu) - (uint32_t)rbase, ib = (rk2[q] >> 16) - (uint32_t)rbase;
                 acc = fma(kk[0][q], Ws[ia < (uint32_t)n ? ia : (uint32_t)(kR0 + kPart)], acc);
                 acc = fma(kk[1][q], Ws[ib < (uint32_t)n ? ib : (uint32_t)(kR0 + kPart)], acc);
             }
+            FSTAMP(10);  // every thread picks up the weights of its events
             base_na += seg_a;
             base_nb += n - seg_a;
             ++swept;
@@ -352,7 +376,12 @@ __global__ __launch_bounds__(NT, WPE) void k_floor(int n_rows, const double* __r
             out[r] = sum + carry_h[swept & 1];  // F(inf) = 1
         }
         __syncthreads();
+        FSTAMP(9);   // sum, write
     }
+#ifdef FLOOR_STAMPS
+    __syncthreads();
+    if (tid < 16) atomicAdd(&g_floor_stamps[tid], fst_acc[tid]);
+#endif
 }
 
 template <int NT, int NB, int WPE, int kQ>
@@ -379,6 +408,19 @@ void run(const char* name, int n_rows, int grid, const double* d_sqrt, const dou
     double cs = 0.0;
     bool sane = true;
     for (double v : h) { cs += v; sane = sane && v > 0.0 && v < 1.0; }
+#ifdef FLOOR_STAMPS
+    {
+        unsigned long long st[16], z[16] = {0};
+        CHECK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_floor_stamps), sizeof st));
+        CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_floor_stamps), z, sizeof z));
+        static const char* names[11] = {"keys + clear", "bucket atomics", "scan", "scatter", "ranking", "labels + F", "chunk counts", "event loop", "stitch", "sum", "pick-up"};
+        double tot = 0.0;
+        for (int i = 0; i < 11; ++i) tot += (double)st[i];
+        printf("# %s: share of wavefront 0's s_memtime ticks per phase:", name);
+        for (int i = 0; i < 11; ++i) printf(" %s %.1f %%;", names[i], 100.0 * (double)st[i] / tot);
+        printf("\n");
+    }
+#endif
     const double events = (double)n_rows * kCap;
     printf("{\"shape\": \"%s\", \"threads\": %d, \"waves_per_simd_budget\": %d, \"events_per_row_pair\": %d, \"buckets\": %d, \"lds_bytes\": %zu, \"workgroups\": %d, \"row_pairs\": %d, "
            "\"ms_per_launch\": %.4f, \"events_per_s\": %.4g, \"ns_per_event_and_cu\": %.3f, \"ms_per_2e8_events\": %.3f, \"checksum\": %.12g, \"scores_in_0_1\": %s}\n",
