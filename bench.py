@@ -289,7 +289,13 @@ def base_result(args, world, total_pairs, elapsed, label, extra_cfg):
         "metric": "anchor-pair LoCoHD scores/sec", "value": total_pairs * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": label, "setup_passes_before_warmup": PRIME_STEPS, "streams": getattr(args, "streams", 1), **extra_cfg},
+        "config": {"workload": label, "setup_passes_before_warmup": PRIME_STEPS, "streams": getattr(args, "streams", 1),
+                   "streams_note": ("consecutive steps alternate between two sessions; on ONE stream (the default at N = 1) they run one after the other, "
+                                    "so a launch of the dominant kernel has the chip to itself and roofline.achieved / frac mean what SURVEY 8d defines; "
+                                    "on TWO streams (the default for N > 1 and --emulate-world, --streams 2) the steps overlap -- measured at N = 1: "
+                                    "+9 % c2a, +10 % c3, +3 % c5 (profiles/r06/x_two_streams_at_n1.txt) -- and a like-for-like single-GPU reference "
+                                    "of an N > 1 line is `--gpus 1 --streams 2`"),
+                   **extra_cfg},
     }
 
 
